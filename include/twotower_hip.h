@@ -1,0 +1,177 @@
+/*
+ * twotower_hip.h — C ABI of the MI355X (gfx950) two-tower retrieval training hot path.
+ *
+ * This is the drop-in boundary.  Plain pointers and sizes only; no
+ * torch / HIP C++ types.  All pointers are DEVICE pointers unless a comment says HOST.
+ * `stream` is a hipStream_t passed as void* (NULL = the default stream).  Every entry
+ * point enqueues on `stream` and returns without synchronising; it never allocates.
+ * Return value: TT_OK (0) or a TT_ERR_* code; tt_last_error() gives the message of the
+ * calling thread's last failure.  No C++ exception crosses this boundary.
+ *
+ * What each group replaces in the reference (citations into /root/reference):
+ *   - The reference declares the training path but ships no code for it:
+ *       src/models/__init__.py:1, src/training/__init__.py:1 (docstring stubs);
+ *       entry point `train-model = "src.training.train:main"`   pyproject.toml:67;
+ *       hyper-parameter schema                                  configs/data_config.yaml:54-71.
+ *     The arithmetic would have come from tensorflow / tensorflow-recommenders
+ *     (pyproject.toml:22,24).  The ops below are what those packages' CPU kernels
+ *     (tf.gather, Dense matmul, tfrs.tasks.Retrieval, Keras SGD/Adagrad) would run.
+ *   - Inputs are the int64 ids produced by
+ *       scripts/data_processing/prepare_training_data.py:113-123,209-210 (user_idx,item_idx)
+ *       src/data/preprocessor.py:478-491 (user_id_encoded, item_id_encoded, category_encoded).
+ */
+#ifndef TWOTOWER_HIP_H
+#define TWOTOWER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TT_ABI_VERSION 1
+
+enum {
+  TT_OK = 0,
+  TT_ERR_INVALID_ARG = 1,   /* null pointer, bad size/alignment, unsupported dim            */
+  TT_ERR_LAUNCH = 2,        /* hipLaunch / hip runtime error                                */
+  TT_ERR_UNSUPPORTED = 3,   /* valid request this build does not implement                  */
+  TT_ERR_WORKSPACE = 4      /* caller-provided workspace too small                          */
+};
+
+enum { TT_OPT_SGD = 0, TT_OPT_ADAGRAD = 1 };
+enum { TT_IDS_UNIFORM = 0, TT_IDS_POWERLAW = 1 };
+
+typedef void* tt_stream_t;
+
+int tt_abi_version(void);
+const char* tt_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Synthetic inputs (SURVEY.md §8d "Synthetic inputs"; no reference counterpart).
+ * Counter-based splitmix64; bit-identical to oracle/synth.py.
+ *   value(i) = fl32(fl32(u(start+i) * scale) + lo),  u in [0,1) with 24 bits.          */
+int tt_fill_uniform_f32(float* dst, int64_t n, uint64_t seed, uint64_t tensor_id,
+                        int64_t start, float lo, float scale, tt_stream_t stream);
+/* ids in [0,num_rows): variant TT_IDS_UNIFORM or TT_IDS_POWERLAW (floor(N*u^4)).        */
+int tt_fill_ids_i64(int64_t* dst, int64_t n, uint64_t seed, uint64_t tensor_id,
+                    int64_t start, int64_t num_rows, int32_t variant, tt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a1 — embedding lookup (Keras Embedding / tf.gather; configs/data_config.yaml:55).
+ *   out[b, :] = table[ids[b], :]          table [num_rows, dim] f32 row-major, dim % 4 == 0
+ * Ids outside [0,num_rows) produce a zero row and set *oob_flag (device int32, may be
+ * NULL) to 1 — the caller turns that into the error TF's CPU gather raises.
+ * The `2` form gathers the user and the item table in ONE launch.                        */
+int tt_embedding_gather_f32(const float* table, int64_t num_rows, int32_t dim,
+                            const int64_t* ids, int64_t n_ids, float* out,
+                            int32_t* oob_flag, tt_stream_t stream);
+int tt_embedding_gather2_f32(const float* table_a, int64_t rows_a, const int64_t* ids_a, float* out_a,
+                             const float* table_b, int64_t rows_b, const int64_t* ids_b, float* out_b,
+                             int32_t dim, int64_t n_ids, int32_t* oob_flag, tt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a5 — sparse optimizer on embedding rows (Keras SGD / Adagrad on IndexedSlices,
+ * duplicates summed before the update; configs/data_config.yaml:63 learning_rate).
+ *
+ * tt_sparse_plan: stable sort of (id, position) by id.  Outputs
+ *   sorted_ids [n_ids] int64, order [n_ids] int32 (positions, ascending inside equal ids).
+ * Only the ids are needed, so the plan can run before / beside the forward pass.
+ *
+ * tt_sparse_{sgd,adagrad}_f32: for every distinct id u (rows >= num_rows are skipped):
+ *   g  = sum of grads[p, :] over the positions p of u, in ascending p, sequential f32 adds
+ *   SGD:      w[u] = w[u] - fl(lr*g)
+ *   Adagrad:  acc[u] += g*g ; w[u] -= fl(lr*g) / sqrt(acc[u] + eps)      (Keras 2.15)
+ * In place.  The `2` forms update the user and the item table in one launch.             */
+int64_t tt_sparse_plan_workspace_bytes(int64_t n_ids);
+int tt_sparse_plan(const int64_t* ids, int64_t n_ids, int64_t num_rows,
+                   void* workspace, int64_t workspace_bytes,
+                   int64_t* sorted_ids, int32_t* order, tt_stream_t stream);
+int tt_sparse_sgd_f32(float* table, int64_t num_rows, int32_t dim,
+                      const float* grads, const int64_t* sorted_ids, const int32_t* order,
+                      int64_t n_ids, float lr, tt_stream_t stream);
+int tt_sparse_adagrad_f32(float* table, float* accum, int64_t num_rows, int32_t dim,
+                          const float* grads, const int64_t* sorted_ids, const int32_t* order,
+                          int64_t n_ids, float lr, float eps, tt_stream_t stream);
+int tt_sparse_update2_f32(int32_t opt,
+                          float* table_a, float* accum_a, int64_t rows_a, const float* grads_a,
+                          const int64_t* sorted_ids_a, const int32_t* order_a,
+                          float* table_b, float* accum_b, int64_t rows_b, const float* grads_b,
+                          const int64_t* sorted_ids_b, const int32_t* order_b,
+                          int32_t dim, int64_t n_ids, float lr, float eps, tt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a2 — MLP tower layers (Keras Dense; configs/data_config.yaml:56-57 *_tower_dims).
+ * All matrices f32 row-major.  x [m,k], w [k,n] (Keras kernel layout), b [n], y [m,n].
+ * k % 4 == 0 and n % 4 == 0; m arbitrary.  f32-input MFMA (exact f32 products).
+ *
+ *   fwd:  y = x@w + b ; relu != 0 applies max(.,0)
+ *   bwd:  dz is dLoss/d(pre-activation) of this layer (the caller's upstream gradient,
+ *         already masked by this layer's own ReLU — see dx_relu_src);
+ *         dx = dz@w^T, and if dx_relu_src != NULL (the [m,k] output of the previous
+ *         ReLU layer, i.e. x itself) dx is multiplied by (dx_relu_src > 0) so that it
+ *         is directly the previous layer's dz;  dx may be NULL to skip it.
+ *         dw_slabs [n_slabs, k, n] and db_slabs [n_slabs, n] receive split-K partial
+ *         sums of x^T@dz and colsum(dz); the dense update sums them in slab order.
+ *         n_slabs = tt_dense_bwd_num_slabs(m).                                            */
+int tt_dense_fwd_f32(const float* x, const float* w, const float* b, float* y,
+                     int64_t m, int32_t k, int32_t n, int32_t relu, tt_stream_t stream);
+int32_t tt_dense_bwd_num_slabs(int64_t m);
+int tt_dense_bwd_f32(const float* x, const float* w, const float* dz,
+                     float* dx, const float* dx_relu_src,
+                     float* dw_slabs, float* db_slabs,
+                     int64_t m, int32_t k, int32_t n, tt_stream_t stream);
+
+/* Dense parameter update over up to TT_MAX_DENSE_SEGS segments in one launch.
+ *   g = sum_s grad_slabs[s*slab_stride + i] (s ascending) + 2*l2*w[i]
+ *   SGD: w -= fl(lr*g);  Adagrad: acc += g*g; w -= fl(lr*g)/sqrt(acc+eps)
+ * If grad_out != NULL the summed gradient (WITHOUT the l2 term) is written there and,
+ * when apply == 0, nothing else happens (the multi-GPU path all-reduces grad_out and
+ * calls again with n_slabs = 1).  `segs` is a HOST array.                                 */
+#define TT_MAX_DENSE_SEGS 16
+typedef struct tt_dense_seg {
+  float* param;              /* [count]                                   */
+  float* accum;              /* [count] Adagrad accumulator or NULL (SGD) */
+  const float* grad_slabs;   /* [n_slabs][slab_stride]                    */
+  float* grad_out;           /* [count] or NULL                           */
+  int64_t count;
+  int64_t slab_stride;
+  int32_t n_slabs;
+  float l2;                  /* l2_regularization (configs/data_config.yaml:59); 0 for biases */
+} tt_dense_seg;
+int tt_dense_update_f32(const tt_dense_seg* segs, int32_t n_segs, int32_t opt, int32_t apply,
+                        float lr, float eps, tt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a3 + a4 — batched dot-product scorer fused with the in-batch sampled-softmax loss
+ * (tfrs.tasks.Retrieval.call: matmul(q, c^T) / temperature, optional sampling-probability
+ * correction and accidental-hit removal, CategoricalCrossentropy(from_logits=True,
+ * reduction=SUM); configs/data_config.yaml:69-70).  The [nq,nc] logits never reach HBM.
+ *
+ *   s_ij   = <q_i, c_j> * inv_temperature  - log(clip(cand_prob_j, 1e-6, 1))
+ *            (+ -inf where cand_ids_j == cand_ids_{i+diag_offset} and j != i+diag_offset)
+ *   lse_i  = log sum_j exp(s_ij)
+ *   row_i  = w_i * (lse_i - s_{i,i+diag_offset}) ;  loss = sum_i row_i
+ *   dq     = grad_scale * sum_j  w_i/T (softmax_ij - [j == i+diag_offset]) c_j ;  dc likewise.
+ *
+ * q [nq,dim], c [nc,dim] f32 row-major; dim in {32,64,128,256}; nq + diag_offset <= nc.
+ * sample_weight [nq], cand_prob [nc], cand_ids [nc] (int64) may each be NULL.
+ * Outputs: lse [nq], per_row [nq], loss [1]; dq [nq,dim], dc [nc,dim].
+ * Workspace: tt_retrieval_workspace_bytes(nq, nc, dim) bytes, 256-byte aligned.          */
+int64_t tt_retrieval_workspace_bytes(int64_t nq, int64_t nc, int32_t dim);
+int tt_retrieval_fwd_f32(const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
+                         int64_t diag_offset, float inv_temperature,
+                         const float* sample_weight, const float* cand_prob, const int64_t* cand_ids,
+                         void* workspace, int64_t workspace_bytes,
+                         float* lse, float* per_row, float* loss, tt_stream_t stream);
+int tt_retrieval_bwd_f32(const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
+                         int64_t diag_offset, float inv_temperature,
+                         const float* sample_weight, const float* cand_prob, const int64_t* cand_ids,
+                         const float* lse, float grad_scale,
+                         void* workspace, int64_t workspace_bytes,
+                         float* dq, float* dc, tt_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TWOTOWER_HIP_H */

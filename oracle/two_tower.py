@@ -1,0 +1,276 @@
+"""NumPy restatement of the two-tower retrieval training step (oracle).
+
+TEST INFRASTRUCTURE — parity unpinned for this file (see oracle/__init__.py).
+
+What each function follows:
+
+* hyper-parameters / shapes: ``/root/reference/configs/data_config.yaml:54-71``
+  (embedding_dim, *_tower_dims, l2_regularization, retrieval.temperature,
+  retrieval.candidate_sampling = "in_batch");
+* task semantics: ``tfrs.tasks.Retrieval.call`` of tensorflow-recommenders
+  0.7.x (declared at ``pyproject.toml:24``, never imported by the reference):
+  scores = q @ c.T; scores /= temperature; sampling-probability correction;
+  accidental-hit removal; CategoricalCrossentropy(from_logits, reduction=SUM);
+* optimizers: Keras 2.15 SGD / Adagrad with sparse (IndexedSlices) gradients
+  de-duplicated by summation before the update.
+
+Every function takes ``dtype``: float64 is the reference result the GPU path
+is compared with; float32 mirrors the GPU's arithmetic type where bit-exact
+comparisons are made (gather, SGD rows).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+MIN_FLOAT = np.finfo(np.float32).min / 100.0     # tfrs.layers.loss.MIN_FLOAT
+
+
+# --------------------------------------------------------------------------- a1
+def embedding_gather(table: np.ndarray, ids: np.ndarray) -> np.ndarray:
+    """E[b,:] = T[id[b],:].  TF's CPU gather raises on out-of-range ids."""
+    ids = np.asarray(ids)
+    if ids.size and (ids.min() < 0 or ids.max() >= table.shape[0]):
+        raise IndexError("embedding id out of range")
+    return table[ids]
+
+
+# --------------------------------------------------------------------------- a2
+def dense_fwd(x, w, b, relu: bool):
+    y = x @ w + b
+    return np.maximum(y, 0) if relu else y
+
+
+def dense_bwd(x, w, y, dy, relu: bool):
+    """Returns dx, dw, db for y = act(x@w+b)."""
+    if relu:
+        dy = dy * (y > 0)
+    return dy @ w.T, x.T @ dy, dy.sum(axis=0)
+
+
+def tower_fwd(x, weights, biases):
+    """ReLU on all but the last layer.  Returns activations list."""
+    acts = [x]
+    n = len(weights)
+    for l, (w, b) in enumerate(zip(weights, biases)):
+        acts.append(dense_fwd(acts[-1], w, b, relu=(l < n - 1)))
+    return acts
+
+
+def tower_bwd(acts, weights, dy):
+    n = len(weights)
+    dws, dbs = [None] * n, [None] * n
+    for l in range(n - 1, -1, -1):
+        dy, dws[l], dbs[l] = dense_bwd(acts[l], weights[l], acts[l + 1], dy, relu=(l < n - 1))
+    return dy, dws, dbs
+
+
+# ------------------------------------------------------------------------ a3+a4
+def retrieval_logits(q, c, temperature=None, candidate_sampling_probability=None,
+                     candidate_ids=None, remove_accidental_hits=False, diag_offset=0):
+    """Logits exactly as tfrs.tasks.Retrieval builds them.  Positive of query i
+    is candidate ``i + diag_offset`` (diag_offset != 0 only for the sharded
+    multi-GPU slab, where local queries face all-gathered candidates)."""
+    s = q @ c.T
+    if temperature is not None:
+        s = s / temperature
+    if candidate_sampling_probability is not None:
+        p = np.clip(np.asarray(candidate_sampling_probability, dtype=s.dtype), 1e-6, 1.0)
+        s = s - np.log(p)[None, :]
+    if remove_accidental_hits:
+        if candidate_ids is None:
+            raise ValueError("When accidental hit removal is enabled, candidate ids must be supplied.")
+        cid = np.asarray(candidate_ids)
+        nq = s.shape[0]
+        pos = np.arange(nq) + diag_offset
+        dup = (cid[pos][:, None] == cid[None, :])
+        dup[np.arange(nq), pos] = False
+        s = np.where(dup, s + MIN_FLOAT, s)
+    return s
+
+
+def retrieval_loss(q, c, temperature=None, sample_weight=None,
+                   candidate_sampling_probability=None, candidate_ids=None,
+                   remove_accidental_hits=False, diag_offset=0, dtype=np.float64):
+    """Returns (loss_sum, per_row_loss, lse).  loss = sum_i w_i (lse_i - s_ii)."""
+    q = np.asarray(q, dtype=dtype)
+    c = np.asarray(c, dtype=dtype)
+    s = retrieval_logits(q, c, temperature, candidate_sampling_probability,
+                         candidate_ids, remove_accidental_hits, diag_offset)
+    nq = s.shape[0]
+    m = s.max(axis=1, keepdims=True)
+    lse = (m + np.log(np.exp(s - m).sum(axis=1, keepdims=True)))[:, 0]
+    pos = s[np.arange(nq), np.arange(nq) + diag_offset]
+    per_row = lse - pos
+    if sample_weight is not None:
+        per_row = per_row * np.asarray(sample_weight, dtype=dtype)
+    return per_row.sum(), per_row, lse
+
+
+def retrieval_grad(q, c, temperature=None, sample_weight=None,
+                   candidate_sampling_probability=None, candidate_ids=None,
+                   remove_accidental_hits=False, diag_offset=0, dtype=np.float64):
+    """d(loss_sum)/dq, d(loss_sum)/dc."""
+    q = np.asarray(q, dtype=dtype)
+    c = np.asarray(c, dtype=dtype)
+    s = retrieval_logits(q, c, temperature, candidate_sampling_probability,
+                         candidate_ids, remove_accidental_hits, diag_offset)
+    nq = s.shape[0]
+    m = s.max(axis=1, keepdims=True)
+    p = np.exp(s - m)
+    p /= p.sum(axis=1, keepdims=True)
+    p[np.arange(nq), np.arange(nq) + diag_offset] -= 1.0
+    if sample_weight is not None:
+        p = p * np.asarray(sample_weight, dtype=dtype)[:, None]
+    if temperature is not None:
+        p = p / temperature
+    return p @ c, p.T @ q
+
+
+# --------------------------------------------------------------------------- a5
+def dedup_sum(ids, grads):
+    """IndexedSlices de-duplication: rows with equal id are summed, in ascending
+    position order (sequential accumulation in the array's dtype), exactly what
+    np.add.at does.  Returns (unique_ids ascending, summed rows)."""
+    ids = np.asarray(ids)
+    uniq, inv = np.unique(ids, return_inverse=True)
+    out = np.zeros((uniq.shape[0], grads.shape[1]), dtype=grads.dtype)
+    # first occurrence initialises (0 + g == g exactly), later ones accumulate in order
+    np.add.at(out, inv, grads)
+    return uniq, out
+
+
+def sparse_sgd(table, ids, grads, lr):
+    """In place: w[u] = w[u] - fl(lr * g_sum[u])   (two roundings)."""
+    uniq, g = dedup_sum(ids, grads)
+    lr = table.dtype.type(lr)
+    table[uniq] = table[uniq] - lr * g
+    return table
+
+
+def sparse_adagrad(table, accum, ids, grads, lr, eps=1e-7):
+    """Keras 2.15 Adagrad, sparse path: acc += g^2; w -= lr*g / sqrt(acc + eps)."""
+    uniq, g = dedup_sum(ids, grads)
+    t = table.dtype.type
+    a = accum[uniq] + g * g
+    accum[uniq] = a
+    table[uniq] = table[uniq] - (t(lr) * g) / np.sqrt(a + t(eps))
+    return table, accum
+
+
+def dense_sgd(w, g, lr):
+    w -= w.dtype.type(lr) * g
+    return w
+
+
+def dense_adagrad(w, acc, g, lr, eps=1e-7):
+    t = w.dtype.type
+    acc += g * g
+    w -= (t(lr) * g) / np.sqrt(acc + t(eps))
+    return w, acc
+
+
+# ------------------------------------------------------------------ whole step
+@dataclass
+class TowerParams:
+    weights: list
+    biases: list
+    w_accum: list = field(default_factory=list)
+    b_accum: list = field(default_factory=list)
+
+
+@dataclass
+class ModelState:
+    user_table: np.ndarray
+    item_table: np.ndarray
+    user_tower: TowerParams
+    item_tower: TowerParams
+    user_accum: np.ndarray | None = None
+    item_accum: np.ndarray | None = None
+
+
+def init_adagrad_state(state: ModelState, initial_accumulator_value=0.1):
+    t = state.user_table.dtype.type
+    state.user_accum = np.full_like(state.user_table, t(initial_accumulator_value))
+    state.item_accum = np.full_like(state.item_table, t(initial_accumulator_value))
+    for tw in (state.user_tower, state.item_tower):
+        tw.w_accum = [np.full_like(w, t(initial_accumulator_value)) for w in tw.weights]
+        tw.b_accum = [np.full_like(b, t(initial_accumulator_value)) for b in tw.biases]
+
+
+def forward_backward(state: ModelState, user_ids, item_ids, temperature=0.1,
+                     l2=0.0, sample_weight=None, candidate_sampling_probability=None,
+                     candidate_ids=None, remove_accidental_hits=False):
+    """One forward+backward.  total_loss = retrieval loss (SUM) + l2 * sum(W**2)
+    over Dense kernels (Keras ``kernel_regularizer=l2``; biases unregularised)."""
+    ue = embedding_gather(state.user_table, user_ids)
+    ie = embedding_gather(state.item_table, item_ids)
+    ua = tower_fwd(ue, state.user_tower.weights, state.user_tower.biases)
+    ia = tower_fwd(ie, state.item_tower.weights, state.item_tower.biases)
+    q, c = ua[-1], ia[-1]
+    dt = q.dtype
+    kw = dict(temperature=temperature, sample_weight=sample_weight,
+              candidate_sampling_probability=candidate_sampling_probability,
+              candidate_ids=candidate_ids, remove_accidental_hits=remove_accidental_hits,
+              dtype=dt)
+    loss, per_row, lse = retrieval_loss(q, c, **kw)
+    dq, dc = retrieval_grad(q, c, **kw)
+    due, udw, udb = tower_bwd(ua, state.user_tower.weights, dq)
+    die, idw, idb = tower_bwd(ia, state.item_tower.weights, dc)
+    reg = dt.type(0)
+    if l2:
+        for tw, dws in ((state.user_tower, udw), (state.item_tower, idw)):
+            for l, w in enumerate(tw.weights):
+                reg = reg + dt.type(l2) * (w * w).sum()
+                dws[l] = dws[l] + dt.type(2 * l2) * w
+    return dict(loss=loss, reg=reg, total=loss + reg, per_row=per_row, lse=lse, q=q, c=c,
+                dq=dq, dc=dc, due=due, die=die, udw=udw, udb=udb, idw=idw, idb=idb,
+                user_acts=ua, item_acts=ia)
+
+
+def train_step(state: ModelState, user_ids, item_ids, lr, optimizer="sgd",
+               temperature=0.1, l2=0.0, eps=1e-7, **loss_kw):
+    """In-place train step; returns forward_backward's dict."""
+    r = forward_backward(state, user_ids, item_ids, temperature=temperature, l2=l2, **loss_kw)
+    if optimizer == "sgd":
+        sparse_sgd(state.user_table, user_ids, r["due"], lr)
+        sparse_sgd(state.item_table, item_ids, r["die"], lr)
+        for tw, dws, dbs in ((state.user_tower, r["udw"], r["udb"]),
+                             (state.item_tower, r["idw"], r["idb"])):
+            for l in range(len(tw.weights)):
+                dense_sgd(tw.weights[l], dws[l], lr)
+                dense_sgd(tw.biases[l], dbs[l], lr)
+    elif optimizer == "adagrad":
+        sparse_adagrad(state.user_table, state.user_accum, user_ids, r["due"], lr, eps)
+        sparse_adagrad(state.item_table, state.item_accum, item_ids, r["die"], lr, eps)
+        for tw, dws, dbs in ((state.user_tower, r["udw"], r["udb"]),
+                             (state.item_tower, r["idw"], r["idb"])):
+            for l in range(len(tw.weights)):
+                dense_adagrad(tw.weights[l], tw.w_accum[l], dws[l], lr, eps)
+                dense_adagrad(tw.biases[l], tw.b_accum[l], dbs[l], lr, eps)
+    else:
+        raise ValueError(f"unknown optimizer {optimizer!r}")
+    return r
+
+
+def synthetic_state(seed, n_users, n_items, emb_dim, tower_dims, dtype=np.float64,
+                    optimizer="sgd") -> ModelState:
+    """Deterministic init shared with the product's ``synthetic`` initialiser
+    (oracle.synth tensor-id convention).  ``tower_dims`` = output dims of each
+    Dense layer, e.g. [256, 128]; both towers share the shape."""
+    from . import synth
+    ut = synth.embedding_table(seed, synth.TID_USER_TABLE, n_users, emb_dim).astype(dtype)
+    it = synth.embedding_table(seed, synth.TID_ITEM_TABLE, n_items, emb_dim).astype(dtype)
+    towers = []
+    for t in (0, 1):
+        ws, bs, fan_in = [], [], emb_dim
+        for l, fan_out in enumerate(tower_dims):
+            ws.append(synth.dense_kernel(seed, synth.dense_tid(t, l), fan_in, fan_out).astype(dtype))
+            bs.append(np.zeros(fan_out, dtype=dtype))
+            fan_in = fan_out
+        towers.append(TowerParams(ws, bs))
+    st = ModelState(ut, it, towers[0], towers[1])
+    if optimizer == "adagrad":
+        init_adagrad_state(st)
+    return st

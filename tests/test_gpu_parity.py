@@ -1,0 +1,324 @@
+"""GPU parity tests: every HIP kernel, called through the C ABI (ctypes), against the CPU oracle
+on the same seeded inputs.  Bars (SURVEY.md §8d "Parity checks"):
+  generator, gather, sparse SGD rows .......... bit-exact
+  sparse Adagrad rows ......................... <= 2 ulp (observed: bit-exact)
+  loss ........................................ |d|/B <= 1e-4 and relative <= 1e-4 vs the f64 oracle
+  gradients / dense layers .................... max-abs error <= 1e-4 * max|reference|
+Parity is UNPINNED by the reference for all of these (the reference has no implementation and no
+fixtures for this path); the oracle is this repo's restatement (oracle/__init__.py).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import synth, two_tower as tt
+from two_tower_amazon_recommender_amd import _lib, ops
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def rel_err(got, ref):
+    return float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30))
+
+
+# ----------------------------------------------------------------------------------- generator
+@pytest.mark.parametrize("n,start", [(1, 0), (4099, 0), (1 << 16, 12345), (3, 7)])
+def test_fill_uniform_bit_exact(dev, n, start):
+    out = torch.empty(n, dtype=torch.float32, device=dev)
+    ops.fill_uniform_(out, seed=1003, tensor_id=2, lo=-0.05, scale=0.1, start=start)
+    ref = synth.uniform_f32(1003, 2, n, -0.05, 0.1, start=start)
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("variant,rows", [("U", 10_000_000), ("Z", 10_000_000), ("U", 7), ("Z", 100_000_000)])
+def test_fill_ids_bit_exact(dev, variant, rows):
+    out = torch.empty(70001, dtype=torch.int64, device=dev)
+    ops.fill_ids_(out, seed=1003, tensor_id=4, num_rows=rows, variant=variant, start=8192 * 3)
+    gen = synth.ids_uniform if variant == "U" else synth.ids_powerlaw
+    ref = gen(1003, 4, 70001, rows, start=8192 * 3)
+    assert np.array_equal(out.cpu().numpy(), ref)
+
+
+# ----------------------------------------------------------------------------------- a1 gather
+@pytest.mark.parametrize("rows,dim,n", [(10_000, 32, 256), (100_000, 64, 4096), (200_000, 128, 8192),
+                                        (5000, 256, 1000), (300, 1024 + 64, 77), (50, 4, 1), (64, 8, 0)])
+def test_gather_bit_exact(dev, rows, dim, n):
+    table = synth.embedding_table(5, 1, rows, dim)
+    ids = synth.ids_powerlaw(5, 3, n, rows) if n else np.zeros(0, dtype=np.int64)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    out = ops.embedding_gather(T(table, dev), T(ids, dev), oob_flag=flag)
+    assert out.shape == (n, dim)
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), tt.embedding_gather(table, ids).view(np.uint32))
+    assert flag.item() == 0
+
+
+def test_gather_out_of_range_sets_flag_like_tf_raises(dev):
+    table = synth.embedding_table(5, 1, 100, 32)
+    ids = np.array([3, 100, 5, -1], dtype=np.int64)
+    with pytest.raises(IndexError):
+        tt.embedding_gather(table, ids)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    out = ops.embedding_gather(T(table, dev), T(ids, dev), oob_flag=flag).cpu().numpy()
+    assert flag.item() == 1
+    assert np.array_equal(out[0], table[3]) and np.array_equal(out[2], table[5])
+    assert not out[1].any() and not out[3].any()
+
+
+def test_gather2_matches_two_gathers(dev):
+    ta, tb = synth.embedding_table(9, 1, 5000, 128), synth.embedding_table(9, 2, 7000, 128)
+    ia, ib = synth.ids_uniform(9, 3, 4096, 5000), synth.ids_powerlaw(9, 4, 4096, 7000)
+    oa = torch.empty(4096, 128, device=dev); ob = torch.empty(4096, 128, device=dev)
+    ops.embedding_gather2(T(ta, dev), T(ia, dev), oa, T(tb, dev), T(ib, dev), ob)
+    assert np.array_equal(oa.cpu().numpy(), ta[ia]) and np.array_equal(ob.cpu().numpy(), tb[ib])
+
+
+def test_ops_reject_cpu_tensors():
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.embedding_gather(torch.zeros(4, 4), torch.zeros(2, dtype=torch.int64))
+
+
+# ----------------------------------------------------------------------------------- a5 sparse optimizer
+@pytest.mark.parametrize("rows,dim,n,variant", [(10_000, 32, 256, "U"), (1_000_000, 64, 4096, "Z"),
+                                                (2_000_000, 128, 8192, "U"), (2_000_000, 128, 8192, "Z"),
+                                                (50, 128, 4096, "U"), (1000, 256, 1, "U")])
+def test_sparse_sgd_bit_exact(dev, rows, dim, n, variant):
+    table = synth.embedding_table(21, 1, rows, dim)
+    ids = synth.batch_ids(21, 3, 0, n, rows, variant)
+    grads = synth.uniform_f32(21, 9, n * dim, -1.0, 2.0).reshape(n, dim)
+    d_table = T(table, dev)
+    plan = ops.SparsePlan(n, dev).run(T(ids, dev), rows)
+    # the plan itself: a stable sort by id
+    o = np.argsort(ids, kind="stable")
+    assert np.array_equal(plan.sorted_ids.cpu().numpy(), ids[o])
+    assert np.array_equal(plan.order.cpu().numpy(), o.astype(np.int32))
+    ops.sparse_sgd_(d_table, T(grads, dev), plan, lr=0.001)
+    ref = tt.sparse_sgd(table.copy(), ids, grads, 0.001)
+    touched = np.unique(ids)
+    assert np.array_equal(d_table.cpu().numpy()[touched].view(np.uint32), ref[touched].view(np.uint32))
+    if rows <= 1_000_000:
+        assert np.array_equal(d_table.cpu().numpy(), ref)     # untouched rows unchanged
+
+
+@pytest.mark.parametrize("variant", ["U", "Z"])
+def test_sparse_adagrad_within_2ulp(dev, variant):
+    rows, dim, n = 500_000, 128, 8192
+    table = synth.embedding_table(22, 1, rows, dim)
+    accum = np.full_like(table, np.float32(0.1))
+    ids = synth.batch_ids(22, 3, 0, n, rows, variant)
+    grads = synth.uniform_f32(22, 9, n * dim, -1.0, 2.0).reshape(n, dim)
+    d_table, d_acc = T(table, dev), T(accum, dev)
+    plan = ops.SparsePlan(n, dev).run(T(ids, dev), rows)
+    ops.sparse_adagrad_(d_table, d_acc, T(grads, dev), plan, lr=0.001, eps=1e-7)
+    rt, ra = tt.sparse_adagrad(table.copy(), accum.copy(), ids, grads, 0.001, 1e-7)
+    assert np.array_equal(d_acc.cpu().numpy(), ra)
+    ulp = np.abs(d_table.cpu().numpy().view(np.int32).astype(np.int64) - rt.view(np.int32).astype(np.int64))
+    assert ulp.max() <= 2
+
+
+def test_sparse_update2_both_tables_one_launch(dev):
+    dim, n = 64, 2048
+    ta, tb = synth.embedding_table(23, 1, 3000, dim), synth.embedding_table(23, 2, 100, dim)
+    ia, ib = synth.ids_uniform(23, 3, n, 3000), synth.ids_powerlaw(23, 4, n, 100)
+    ga = synth.uniform_f32(23, 9, n * dim, -1.0, 2.0).reshape(n, dim)
+    gb = synth.uniform_f32(23, 10, n * dim, -1.0, 2.0).reshape(n, dim)
+    for opt in ("sgd", "adagrad"):
+        da, db = T(ta, dev), T(tb, dev)
+        aa, ab = torch.full_like(da, 0.1), torch.full_like(db, 0.1)
+        pa = ops.SparsePlan(n, dev).run(T(ia, dev), 3000)
+        pb = ops.SparsePlan(n, dev).run(T(ib, dev), 100)
+        ops.sparse_update2_(opt, da, aa, T(ga, dev), pa, db, ab, T(gb, dev), pb, lr=0.01)
+        if opt == "sgd":
+            assert np.array_equal(da.cpu().numpy(), tt.sparse_sgd(ta.copy(), ia, ga, 0.01))
+            assert np.array_equal(db.cpu().numpy(), tt.sparse_sgd(tb.copy(), ib, gb, 0.01))
+        else:
+            ra, _ = tt.sparse_adagrad(ta.copy(), np.full_like(ta, np.float32(0.1)), ia, ga, 0.01)
+            rb, _ = tt.sparse_adagrad(tb.copy(), np.full_like(tb, np.float32(0.1)), ib, gb, 0.01)
+            assert np.allclose(da.cpu().numpy(), ra, rtol=3e-7, atol=0) and np.allclose(db.cpu().numpy(), rb, rtol=3e-7, atol=0)
+
+
+def test_sparse_update_is_run_to_run_deterministic(dev):
+    rows, dim, n = 1000, 128, 8192                     # heavy duplication
+    table = synth.embedding_table(24, 1, rows, dim)
+    ids = synth.ids_powerlaw(24, 3, n, rows)
+    grads = T(synth.uniform_f32(24, 9, n * dim, -1.0, 2.0).reshape(n, dim), dev)
+    outs = []
+    for _ in range(3):
+        d = T(table, dev)
+        plan = ops.SparsePlan(n, dev).run(T(ids, dev), rows)
+        ops.sparse_sgd_(d, grads, plan, lr=0.01)
+        outs.append(d.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
+# ----------------------------------------------------------------------------------- a2 dense layers
+@pytest.mark.parametrize("m,k,n,relu", [(256, 32, 32, False), (4096, 64, 64, True), (8192, 128, 256, True),
+                                        (8192, 256, 128, False), (1000, 128, 512, True), (77, 36, 20, True),
+                                        (8192, 512, 256, True)])
+def test_dense_fwd(dev, m, k, n, relu):
+    x = synth.uniform_f32(31, 1, m * k, -1.0, 2.0).reshape(m, k)
+    w = synth.dense_kernel(31, 2, k, n)
+    b = synth.uniform_f32(31, 3, n, -0.1, 0.2)
+    y = ops.dense_fwd(T(x, dev), T(w, dev), T(b, dev), relu).cpu().numpy()
+    ref = tt.dense_fwd(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64), relu)
+    assert rel_err(y, ref) <= 1e-5
+    if relu:
+        assert (y >= 0).all()
+
+
+@pytest.mark.parametrize("m,k,n,mask", [(256, 32, 32, False), (4096, 64, 64, True), (8192, 128, 256, False),
+                                        (8192, 256, 128, True), (1000, 128, 512, True), (77, 36, 20, True)])
+def test_dense_bwd(dev, m, k, n, mask):
+    x = synth.uniform_f32(32, 1, m * k, -1.0, 2.0).reshape(m, k)      # ~half the entries <= 0
+    w = synth.dense_kernel(32, 2, k, n)
+    dz = synth.uniform_f32(32, 3, m * n, -1.0, 2.0).reshape(m, n)
+    ns = ops.dense_bwd_num_slabs(m)
+    dw_s = torch.full((ns, k, n), float("nan"), device=dev)
+    db_s = torch.full((ns, n), float("nan"), device=dev)
+    dx = torch.full((m, k), float("nan"), device=dev)
+    dx_src = T(x, dev) if mask else None
+    assert ops.dense_bwd(T(x, dev), T(w, dev), T(dz, dev), dx, dx_src, dw_s, db_s) == ns
+    x64, w64, dz64 = x.astype(np.float64), w.astype(np.float64), dz.astype(np.float64)
+    rdx = dz64 @ w64.T
+    if mask:
+        rdx = rdx * (x64 > 0)
+    assert rel_err(dx.cpu().numpy(), rdx) <= 1e-5
+    assert rel_err(dw_s.sum(0).cpu().numpy(), x64.T @ dz64) <= 1e-5
+    assert rel_err(db_s.sum(0).cpu().numpy(), dz64.sum(0)) <= 1e-5
+
+
+@pytest.mark.parametrize("opt", ["sgd", "adagrad"])
+def test_dense_update_segments(dev, opt):
+    rng = np.random.default_rng(5)
+    shapes = [(128, 256), (256,), (256, 128), (128,)]
+    l2s = [1e-6, 0.0, 1e-6, 0.0]
+    ns = 7
+    params = [rng.normal(size=s).astype(np.float32) for s in shapes]
+    slabs = [rng.normal(size=(ns,) + s).astype(np.float32) for s in shapes]
+    d_params = [T(p, dev) for p in params]
+    d_acc = [torch.full_like(p, 0.1) for p in d_params]
+    d_slabs = [T(s, dev) for s in slabs]
+    d_gout = [torch.empty_like(p) for p in d_params]
+    segs = [ops.make_dense_seg(p, a, s, ns, l2, g) for p, a, s, l2, g in zip(d_params, d_acc, d_slabs, l2s, d_gout)]
+    ops.dense_update_(segs, opt, lr=0.01, eps=1e-7)
+    for p, s, l2, dp, dg in zip(params, slabs, l2s, d_params, d_gout):
+        g = s[0].copy()
+        for k in range(1, ns):
+            g += s[k]
+        assert np.array_equal(dg.cpu().numpy(), g)
+        g = g + np.float32(2 * l2) * p
+        if opt == "sgd":
+            ref = p - np.float32(0.01) * g
+        else:
+            acc = np.float32(0.1) + g * g
+            ref = p - (np.float32(0.01) * g) / np.sqrt(acc + np.float32(1e-7))
+        assert np.allclose(dp.cpu().numpy(), ref, rtol=3e-7, atol=1e-9)
+
+
+# ----------------------------------------------------------------------------------- a3+a4 retrieval
+def run_retrieval(dev, q, c, temperature, w=None, p=None, ids=None, off=0, grad_scale=1.0):
+    nq, nc, d = q.shape[0], c.shape[0], q.shape[1]
+    ws = torch.empty(ops.retrieval_workspace_bytes(nq, nc, d), dtype=torch.uint8, device=dev)
+    lse = torch.empty(nq, device=dev); per_row = torch.empty(nq, device=dev); loss = torch.empty(1, device=dev)
+    dq, dc = torch.full((nq, d), float("nan"), device=dev), torch.full((nc, d), float("nan"), device=dev)
+    dq_, dc_ = T(q, dev), T(c, dev)
+    kw = dict(sample_weight=None if w is None else T(w.astype(np.float32), dev),
+              cand_prob=None if p is None else T(p.astype(np.float32), dev),
+              cand_ids=None if ids is None else T(ids.astype(np.int64), dev), diag_offset=off)
+    ops.retrieval_fwd(dq_, dc_, 1.0 / temperature, ws, lse, per_row, loss, **kw)
+    ops.retrieval_bwd(dq_, dc_, 1.0 / temperature, ws, lse, dq, dc, grad_scale=grad_scale, **kw)
+    return loss.item(), per_row.cpu().numpy(), lse.cpu().numpy(), dq.cpu().numpy(), dc.cpu().numpy()
+
+
+def check_retrieval(dev, nq, nc, d, temperature=0.1, scale=0.3, use_w=False, use_p=False, use_ids=False, off=0, seed=41):
+    q = synth.uniform_f32(seed, 1, nq * d, -scale, 2 * scale).reshape(nq, d)
+    c = synth.uniform_f32(seed, 2, nc * d, -scale, 2 * scale).reshape(nc, d)
+    w = synth.uniform_f32(seed, 3, nq, 0.5, 1.5) if use_w else None
+    p = synth.uniform_f32(seed, 4, nc, 0.0, 0.3) if use_p else None      # includes values < 1e-6 (clip)
+    ids = synth.ids_powerlaw(seed, 5, nc, max(nc // 4, 2)) if use_ids else None
+    loss, per_row, lse, dq, dc = run_retrieval(dev, q, c, temperature, w, p, ids, off)
+    kw = dict(temperature=temperature, sample_weight=w, candidate_sampling_probability=p, candidate_ids=ids,
+              remove_accidental_hits=use_ids, diag_offset=off)
+    rl, rper, rlse = tt.retrieval_loss(q, c, **kw)
+    rdq, rdc = tt.retrieval_grad(q, c, **kw)
+    assert abs(loss - rl) / nq <= 1e-4 and abs(loss - rl) <= 1e-4 * abs(rl), (loss, rl)
+    assert np.abs(lse - rlse).max() <= 1e-4 * max(1.0, np.abs(rlse).max())
+    assert np.abs(per_row - rper).max() <= 1e-4 * max(1.0, np.abs(rper).max())
+    assert rel_err(dq, rdq) <= 1e-4 and rel_err(dc, rdc) <= 1e-4, (rel_err(dq, rdq), rel_err(dc, rdc))
+
+
+@pytest.mark.parametrize("b,d", [(256, 32), (4096, 64), (8192, 128), (1024, 256)])
+def test_retrieval_baseline_configs(dev, b, d):
+    """cfg1 / cfg2 / cfg3 batch x dim shapes (BASELINE.json configs) + dim 256 (cfg5's dim)."""
+    check_retrieval(dev, b, b, d)
+
+
+@pytest.mark.parametrize("nq,nc,d,off", [(1, 1, 32, 0), (33, 33, 32, 0), (100, 131, 64, 0), (100, 131, 64, 31),
+                                         (129, 1000, 128, 700), (1000, 1000, 128, 0), (2048, 16384, 128, 6144),
+                                         (257, 300, 256, 5)])
+def test_retrieval_ragged_and_offset_slabs(dev, nq, nc, d, off):
+    check_retrieval(dev, nq, nc, d, off=off)
+
+
+@pytest.mark.parametrize("opts", [dict(use_w=True), dict(use_p=True), dict(use_ids=True),
+                                  dict(use_w=True, use_p=True, use_ids=True),
+                                  dict(use_w=True, use_p=True, use_ids=True, off=17)])
+def test_retrieval_options(dev, opts):
+    off = opts.pop("off", 0)
+    check_retrieval(dev, 777, 777 + off + 3, 128, off=off, **opts)
+    check_retrieval(dev, 300, 300 + off, 64, off=off, **opts)
+
+
+def test_retrieval_temperature_and_large_logits(dev):
+    check_retrieval(dev, 512, 512, 128, temperature=0.05, scale=1.0)    # |logit| up to ~ 1000: online max must hold
+    check_retrieval(dev, 512, 512, 128, temperature=1.0, scale=0.05)
+
+
+def test_retrieval_grad_scale_linearity(dev):
+    q = synth.uniform_f32(43, 1, 512 * 64, -0.3, 0.6).reshape(512, 64)
+    c = synth.uniform_f32(43, 2, 512 * 64, -0.3, 0.6).reshape(512, 64)
+    _, _, _, dq1, dc1 = run_retrieval(dev, q, c, 0.1)
+    _, _, _, dq2, dc2 = run_retrieval(dev, q, c, 0.1, grad_scale=2.0)
+    assert np.allclose(dq2, 2 * dq1, rtol=1e-6, atol=1e-9) and np.allclose(dc2, 2 * dc1, rtol=1e-6, atol=1e-9)
+
+
+def test_retrieval_is_deterministic(dev):
+    q = synth.uniform_f32(44, 1, 2048 * 128, -0.3, 0.6).reshape(2048, 128)
+    a = run_retrieval(dev, q, q[::-1].copy(), 0.1)
+    b = run_retrieval(dev, q, q[::-1].copy(), 0.1)
+    assert a[0] == b[0] and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+
+
+def test_retrieval_rejects_bad_shapes(dev):
+    q = torch.zeros(8, 48, device=dev)
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device=dev)
+    o = torch.empty(8, device=dev)
+    with pytest.raises(ValueError, match="dim 48"):
+        ops.retrieval_fwd(q, q, 10.0, ws, o, o, o)
+    q = torch.zeros(8, 64, device=dev)
+    with pytest.raises(ValueError, match="diag_offset"):
+        ops.retrieval_fwd(q, q, 10.0, ws, o, o, o, diag_offset=1)
+    with pytest.raises(_lib.TwoTowerHipError, match="workspace"):
+        ops.retrieval_fwd(q, q, 10.0, ws[:256], o, o, o)
+
+
+# ----------------------------------------------------------------------------------- full-size properties
+def test_full_size_properties_cfg3(dev):
+    """BASELINE cfg3 sizes, size-independent properties (no O(B^2) host work):
+    every row's gradient sums: sum_j dS_ij = 0  =>  for c == const, dq == 0; loss == B*log(B) for zero q."""
+    b, d = 8192, 128
+    q = torch.zeros(b, d, device=dev)
+    c = T(synth.uniform_f32(45, 2, b * d, -0.3, 0.6).reshape(b, d), dev)
+    ws = torch.empty(ops.retrieval_workspace_bytes(b, b, d), dtype=torch.uint8, device=dev)
+    lse = torch.empty(b, device=dev); per_row = torch.empty(b, device=dev); loss = torch.empty(1, device=dev)
+    ops.retrieval_fwd(q, c, 10.0, ws, lse, per_row, loss)
+    assert abs(loss.item() / b - np.log(b)) < 1e-5
+    dq, dc = torch.empty(b, d, device=dev), torch.empty(b, d, device=dev)
+    ops.retrieval_bwd(q, c, 10.0, ws, lse, dq, dc)
+    # q == 0: softmax is uniform, dq_i = 10*(mean(c) - c_i), dc == 0
+    ref = 10.0 * (c.double().mean(0, keepdim=True) - c.double())
+    assert (dq.double() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+    assert dc.abs().max().item() <= 1e-6

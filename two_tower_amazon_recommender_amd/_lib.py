@@ -1,0 +1,107 @@
+"""ctypes binding of ``libtwotower_hip.so`` (the C ABI declared in ``include/twotower_hip.h``).
+
+The product has NO CPU fallback: if the shared library is missing or a symbol is
+absent, importing an op raises.  ``build()`` (re)builds the library in-tree with hipcc
+(``csrc/Makefile``); it cross-compiles for gfx950 without a GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import pathlib
+import subprocess
+import threading
+
+_PKG = pathlib.Path(__file__).resolve().parent
+LIB_PATH = _PKG / "libtwotower_hip.so"
+ABI_VERSION = 1
+
+TT_OK, TT_ERR_INVALID_ARG, TT_ERR_LAUNCH, TT_ERR_UNSUPPORTED, TT_ERR_WORKSPACE = range(5)
+TT_OPT_SGD, TT_OPT_ADAGRAD = 0, 1
+TT_IDS_UNIFORM, TT_IDS_POWERLAW = 0, 1
+TT_MAX_DENSE_SEGS = 16
+
+
+class DenseSeg(C.Structure):
+    """Mirror of ``tt_dense_seg`` (include/twotower_hip.h)."""
+    _fields_ = [
+        ("param", C.c_void_p), ("accum", C.c_void_p), ("grad_slabs", C.c_void_p), ("grad_out", C.c_void_p),
+        ("count", C.c_int64), ("slab_stride", C.c_int64), ("n_slabs", C.c_int32), ("l2", C.c_float),
+    ]
+
+
+_p, _i64, _i32, _u64, _f = C.c_void_p, C.c_int64, C.c_int32, C.c_uint64, C.c_float
+
+# name -> (restype, argtypes); exactly the declarations of include/twotower_hip.h
+SIGNATURES = {
+    "tt_abi_version": (C.c_int, []),
+    "tt_last_error": (C.c_char_p, []),
+    "tt_fill_uniform_f32": (C.c_int, [_p, _i64, _u64, _u64, _i64, _f, _f, _p]),
+    "tt_fill_ids_i64": (C.c_int, [_p, _i64, _u64, _u64, _i64, _i64, _i32, _p]),
+    "tt_embedding_gather_f32": (C.c_int, [_p, _i64, _i32, _p, _i64, _p, _p, _p]),
+    "tt_embedding_gather2_f32": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _p, _p, _i32, _i64, _p, _p]),
+    "tt_sparse_plan_workspace_bytes": (_i64, [_i64]),
+    "tt_sparse_plan": (C.c_int, [_p, _i64, _i64, _p, _i64, _p, _p, _p]),
+    "tt_sparse_sgd_f32": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _i64, _f, _p]),
+    "tt_sparse_adagrad_f32": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _i64, _f, _f, _p]),
+    "tt_sparse_update2_f32": (C.c_int, [_i32, _p, _p, _i64, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _i32, _i64, _f, _f, _p]),
+    "tt_dense_fwd_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _i32, _p]),
+    "tt_dense_bwd_num_slabs": (_i32, [_i64]),
+    "tt_dense_bwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
+    "tt_dense_update_f32": (C.c_int, [C.POINTER(DenseSeg), _i32, _i32, _i32, _f, _f, _p]),
+    "tt_retrieval_workspace_bytes": (_i64, [_i64, _i64, _i32]),
+    "tt_retrieval_fwd_f32": (C.c_int, [_p, _p, _i64, _i64, _i32, _i64, _f, _p, _p, _p, _p, _i64, _p, _p, _p, _p]),
+    "tt_retrieval_bwd_f32": (C.c_int, [_p, _p, _i64, _i64, _i32, _i64, _f, _p, _p, _p, _p, _f, _p, _i64, _p, _p, _p]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+class TwoTowerHipError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> pathlib.Path:
+    """Compile every HIP source for gfx950 into ``libtwotower_hip.so`` (in-tree)."""
+    cmd = ["make", "-C", str(_PKG / "csrc"), f"-j{min(8, os.cpu_count() or 1)}"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+        print(res.stderr)
+    if res.returncode != 0:
+        raise TwoTowerHipError(f"building libtwotower_hip.so failed (exit {res.returncode})")
+    return LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Load the library and bind every declared symbol.  Raises if anything is missing."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not LIB_PATH.exists():
+            raise TwoTowerHipError(
+                f"{LIB_PATH} not found: the HIP extension is not built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+                "There is no CPU fallback.")
+        lib = C.CDLL(str(LIB_PATH))
+        for name, (restype, argtypes) in SIGNATURES.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError as e:
+                raise TwoTowerHipError(f"{LIB_PATH} does not export {name}") from e
+            fn.restype = restype
+            fn.argtypes = argtypes
+        got = lib.tt_abi_version()
+        if got != ABI_VERSION:
+            raise TwoTowerHipError(f"ABI version mismatch: library {got}, binding {ABI_VERSION}")
+        _lib = lib
+        return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != TT_OK:
+        msg = load().tt_last_error().decode("utf-8", "replace")
+        exc = {TT_ERR_INVALID_ARG: ValueError, TT_ERR_UNSUPPORTED: NotImplementedError}.get(rc, TwoTowerHipError)
+        raise exc(f"{what} failed (code {rc}): {msg}")

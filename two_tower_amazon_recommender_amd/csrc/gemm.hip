@@ -1,0 +1,222 @@
+// K3 — MLP tower layers: y = act(x@w+b), dx = dz@w^T (* relu mask),
+// dw = x^T@dz (split-K slabs), db = colsum(dz).  f32-input MFMA (v_mfma_f32_32x32x2_f32, exact f32
+// products, peak 157.3 TF).  One tiled kernel, three operand-orientation instantiations:
+//
+//   fwd  NN : A = x  [m][k] k-contiguous      B = w  [k][n] n-contiguous
+//   dx   NT : A = dz [m][k=n_out] k-contig.   B = w  [n=k_in][k=n_out] k-contiguous
+//   dw   TN : A = x  [k=batch][m=k_in]        B = dz [k=batch][n] (both "m-contiguous"), split over batch
+//
+// Block tile 64x64x32, 4 waves (2x2), one 32x32 accumulator per wave: the tower GEMMs are skinny
+// (n = 128..512) so small tiles keep >= 256 workgroups in flight.  Tiles go global -> registers ->
+// LDS one k-step ahead (double-buffered).  MFMA k order inside a 32-deep step is permuted
+// (k = 8g + 4*lanehalf + s) so a k-contiguous operand is read with one ds_read_b128 per 4 MFMAs
+// from rows padded to 36 floats (conflict-free); an m-contiguous operand is read with ds_read_b32.
+#include "common.h"
+
+namespace {
+
+using tt::f32x4;
+using tt::f32x16;
+
+constexpr int BM = 64, BN = 64, BK = 32;
+constexpr int LS_KC = BK + 4;    // [row][k] stride
+constexpr int LS_MC = BM + 4;    // [k][row] stride
+constexpr int TILE_F = (BM * LS_KC > BK * LS_MC) ? BM * LS_KC : BK * LS_MC;   // floats per operand tile
+
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  int64_t M;            // rows of C
+  int64_t N;            // cols of C
+  int64_t K;            // reduction length
+  int64_t lda, ldb, ldc;
+  const float* bias;    // [N] or null
+  int relu;
+  const float* mask_src;   // [M][ldc] or null: C *= (mask_src > 0)
+  int64_t k_per_split;     // multiple of BK
+  int64_t slab_stride;     // C offset per blockIdx.z
+  float* db_slabs;         // TN only: [splits][N] column sums of B
+};
+
+// stage one operand tile into registers.  KC: rows x 32 k, float4 along k.  MC: 32 k x rows, float4 along rows.
+template <bool KC>
+__device__ __forceinline__ void load_operand(f32x4 (&st)[2], const float* __restrict__ base, int64_t ld, int64_t row0,
+                                             int64_t nrows, int64_t k0, int64_t kend, int tid) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int f = tid + 256 * j;
+    if constexpr (KC) {
+      const int row = f >> 3, k4 = f & 7;
+      const int64_t r = row0 + row, k = k0 + 4 * k4;
+      st[j] = (r < nrows && k < kend) ? *reinterpret_cast<const f32x4*>(base + r * ld + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+      const int kk = f >> 4, m4 = f & 15;
+      const int64_t k = k0 + kk, r = row0 + 4 * m4;
+      st[j] = (k < kend && r < nrows) ? *reinterpret_cast<const f32x4*>(base + k * ld + r) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+}
+
+template <bool KC>
+__device__ __forceinline__ void store_operand(const f32x4 (&st)[2], float* T, int tid) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int f = tid + 256 * j;
+    if constexpr (KC) {
+      const int row = f >> 3, k4 = f & 7;
+      *reinterpret_cast<f32x4*>(T + row * LS_KC + 4 * k4) = st[j];
+    } else {
+      const int kk = f >> 4, m4 = f & 15;
+      *reinterpret_cast<f32x4*>(T + kk * LS_MC + 4 * m4) = st[j];
+    }
+  }
+}
+
+// the 4 operand values of k-group g (k = 8g + 4h + s, s = 0..3) for tile row `row`
+template <bool KC>
+__device__ __forceinline__ f32x4 read_operand(const float* T, int row, int g, int h) {
+  if constexpr (KC) {
+    return *reinterpret_cast<const f32x4*>(T + row * LS_KC + 8 * g + 4 * h);
+  } else {
+    const float* p = T + (8 * g + 4 * h) * LS_MC + row;
+    return f32x4{p[0], p[LS_MC], p[2 * LS_MC], p[3 * LS_MC]};
+  }
+}
+
+template <bool A_KC, bool B_KC, bool COLSUM>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * 2 * TILE_F];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, ln = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const int64_t n0 = (int64_t)blockIdx.y * BN;
+  const int64_t kbeg = (int64_t)blockIdx.z * p.k_per_split;
+  int64_t kend = kbeg + p.k_per_split;
+  if (kend > p.K) kend = p.K;
+  const int nk = kend > kbeg ? (int)((kend - kbeg + BK - 1) / BK) : 0;
+
+  f32x4 sa[2], sb[2];
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  float colsum = 0.f;
+
+  if (nk > 0) {
+    load_operand<A_KC>(sa, p.A, p.lda, m0, p.M, kbeg, kend, tid);
+    load_operand<B_KC>(sb, p.B, p.ldb, n0, p.N, kbeg, kend, tid);
+    store_operand<A_KC>(sa, smem, tid);
+    store_operand<B_KC>(sb, smem + TILE_F, tid);
+  }
+  __syncthreads();
+
+  for (int t = 0; t < nk; ++t) {
+    const float* TA = smem + (t & 1) * 2 * TILE_F;
+    const float* TB = TA + TILE_F;
+    if (t + 1 < nk) {
+      load_operand<A_KC>(sa, p.A, p.lda, m0, p.M, kbeg + (int64_t)(t + 1) * BK, kend, tid);
+      load_operand<B_KC>(sb, p.B, p.ldb, n0, p.N, kbeg + (int64_t)(t + 1) * BK, kend, tid);
+    }
+#pragma unroll
+    for (int g = 0; g < BK / 8; ++g) {
+      const f32x4 a4 = read_operand<A_KC>(TA, wm * 32 + ln, g, h);
+      const f32x4 b4 = read_operand<B_KC>(TB, wn * 32 + ln, g, h);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s], b4[s], acc, 0, 0, 0);
+    }
+    if constexpr (COLSUM) {
+      // db: column sums of the dz tile, once per n-tile (m-tile 0 only); rows beyond kend are zero-filled
+      if (blockIdx.x == 0 && tid < BN) {
+#pragma unroll 8
+        for (int kk = 0; kk < BK; ++kk) colsum += TB[kk * LS_MC + tid];
+      }
+    }
+    if (t + 1 < nk) {
+      float* NA = smem + ((t + 1) & 1) * 2 * TILE_F;
+      store_operand<A_KC>(sa, NA, tid);
+      store_operand<B_KC>(sb, NA + TILE_F, tid);
+    }
+    __syncthreads();
+  }
+
+  float* C = p.C + (int64_t)blockIdx.z * p.slab_stride;
+  const int64_t n = n0 + wn * 32 + ln;
+  if (n < p.N) {
+    const float bias = p.bias != nullptr ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int64_t m = m0 + wm * 32 + tt::acc_row(reg, h);
+      if (m < p.M) {
+        float v = acc[reg] + bias;
+        if (p.relu) v = fmaxf(v, 0.f);
+        if (p.mask_src != nullptr) v = p.mask_src[m * p.ldc + n] > 0.f ? v : 0.f;
+        C[m * p.ldc + n] = v;
+      }
+    }
+  }
+  if constexpr (COLSUM) {
+    if (blockIdx.x == 0 && tid < BN && n0 + tid < p.N) p.db_slabs[(int64_t)blockIdx.z * p.N + n0 + tid] = colsum;
+  }
+}
+
+template <bool A_KC, bool B_KC, bool COLSUM>
+int launch(const GemmArgs& a, int splits, hipStream_t stream, const char* what) {
+  const int64_t gm = (a.M + BM - 1) / BM, gn = (a.N + BN - 1) / BN;
+  TT_REQUIRE(gm <= 0x7fffffff && gn <= 65535 && splits <= 65535, "%s: grid too large", what);
+  hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, COLSUM>), dim3((unsigned)gm, (unsigned)gn, (unsigned)splits), dim3(256), 0,
+                     stream, a);
+  return tt::check_launch(what);
+}
+
+}  // namespace
+
+extern "C" int tt_dense_fwd_f32(const float* x, const float* w, const float* b, float* y, int64_t m, int32_t k,
+                                int32_t n, int32_t relu, tt_stream_t stream) {
+  TT_REQUIRE(x && w && y, "tt_dense_fwd_f32: null pointer");
+  TT_REQUIRE(m > 0 && k > 0 && n > 0 && k % 4 == 0 && n % 4 == 0, "tt_dense_fwd_f32: need m>0, k%%4==0, n%%4==0 (m=%lld k=%d n=%d)",
+             (long long)m, k, n);
+  TT_REQUIRE(tt::aligned16(x) && tt::aligned16(w) && tt::aligned16(y), "tt_dense_fwd_f32: pointers must be 16-byte aligned");
+  GemmArgs a{};
+  a.A = x; a.B = w; a.C = y; a.M = m; a.N = n; a.K = k; a.lda = k; a.ldb = n; a.ldc = n;
+  a.bias = b; a.relu = relu; a.k_per_split = (k + BK - 1) / BK * BK;
+  return launch<true, false, false>(a, 1, tt::as_stream(stream), "tt_dense_fwd_f32");
+}
+
+extern "C" int32_t tt_dense_bwd_num_slabs(int64_t m) {
+  int64_t s = (m + 255) / 256;
+  if (s < 1) s = 1;
+  if (s > 32) s = 32;
+  return (int32_t)s;
+}
+
+extern "C" int tt_dense_bwd_f32(const float* x, const float* w, const float* dz, float* dx, const float* dx_relu_src,
+                                float* dw_slabs, float* db_slabs, int64_t m, int32_t k, int32_t n, tt_stream_t stream_) {
+  TT_REQUIRE(x && w && dz && dw_slabs && db_slabs, "tt_dense_bwd_f32: null pointer");
+  TT_REQUIRE(m > 0 && k > 0 && n > 0 && k % 4 == 0 && n % 4 == 0, "tt_dense_bwd_f32: need m>0, k%%4==0, n%%4==0 (m=%lld k=%d n=%d)",
+             (long long)m, k, n);
+  TT_REQUIRE(tt::aligned16(x) && tt::aligned16(w) && tt::aligned16(dz) && tt::aligned16(dw_slabs) &&
+                 (dx == nullptr || tt::aligned16(dx)),
+             "tt_dense_bwd_f32: pointers must be 16-byte aligned");
+  hipStream_t stream = tt::as_stream(stream_);
+  int rc;
+  if (dx != nullptr) {
+    // dx[m][k] = sum_n dz[m][n] * w[k][n]
+    GemmArgs a{};
+    a.A = dz; a.B = w; a.C = dx; a.M = m; a.N = k; a.K = n; a.lda = n; a.ldb = n; a.ldc = k;
+    a.mask_src = dx_relu_src; a.k_per_split = (n + BK - 1) / BK * BK;
+    if ((rc = launch<true, true, false>(a, 1, stream, "tt_dense_bwd_f32(dx)")) != TT_OK) return rc;
+  }
+  {
+    // dw[k][n] = sum_b x[b][k] * dz[b][n], split over the batch into slabs; db rides along
+    const int splits = tt_dense_bwd_num_slabs(m);
+    GemmArgs a{};
+    a.A = x; a.B = dz; a.C = dw_slabs; a.M = k; a.N = n; a.K = m; a.lda = k; a.ldb = n; a.ldc = n;
+    a.k_per_split = ((m + splits - 1) / splits + BK - 1) / BK * BK;
+    a.slab_stride = (int64_t)k * n;
+    a.db_slabs = db_slabs;
+    if ((rc = launch<false, false, true>(a, splits, stream, "tt_dense_bwd_f32(dw)")) != TT_OK) return rc;
+  }
+  return TT_OK;
+}

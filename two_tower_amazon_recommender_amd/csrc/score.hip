@@ -1,0 +1,575 @@
+// K4 / K5 — batched dot-product scorer fused with the in-batch sampled-softmax loss and its
+// gradient (SURVEY.md §2.2 K4/K5, §8a a3+a4; tfrs.tasks.Retrieval semantics, Appendix A).
+// The [nq, nc] logit matrix never reaches HBM.
+//
+// One kernel serves the forward statistics pass and both gradient passes.  It sees a STATIONARY
+// matrix R [n_r, D] (one 32-row fragment per wave, held in registers for the whole launch) and a
+// STREAMED matrix K [n_c, D] (32-row tiles, double-buffered in LDS, shared by the 4 waves):
+//
+//   GEMM1   X[c][r]  = sum_d K[c][d] * R[r][d]          v_mfma_f32_32x32x2_f32, D/2 per tile
+//           (c on accumulator registers, r on lanes: every softmax reduction over c is lane-local)
+//   FWD     online (max, sum-exp2) over c per lane; positive logit captured in-tile
+//   BWD     coef[c][r] = exp2(X*c1 + a_c + a_r) * s_c*s_r  - [c == r+diag] s_c*s_r
+//   GEMM2   G^T[d][r] += sum_c K[c][d] * coef[c][r]      the accumulator IS the B operand (no LDS
+//           transpose): lane half h of register `reg` holds row acc_row(reg,h) = k of that step.
+//
+//   pass        R        K        a_r          s_r        a_c          s_c        diag
+//   FWD  (lse)  q        c        -            -          -log2 p_c    -          +off
+//   BWD dq      q        c        -lse2        w/T*g      -log2 p_c    1          +off
+//   BWD dc      c        q        -log2 p_r    1          -lse2        w/T*g      -off
+//
+// f32-input MFMA: exact f32 products (guide §3 'FP32-input MFMA'); peak 157.3 TF on MI355X.
+// Per (32 r x 32 c) tile and wave: D/2 + D/2 MFMAs (BWD), 16 v_exp_f32 per lane, 16+16(+8) LDS reads.
+// The c range is split over the grid (blockIdx % nsplit; blocks b and b+8 share an XCD, so one
+// XCD's L2 keeps re-serving the same K range); partial results go to per-split slabs that a small
+// kernel sums in split order (bitwise reproducible; no float atomics).
+#include "common.h"
+
+namespace {
+
+using tt::f32x4;
+using tt::f32x16;
+
+constexpr float kLog2e = 1.44269504088896340736f;
+constexpr float kLn2 = 0.69314718055994530942f;
+constexpr float kNegBig = -1.0e30f;   // log2-domain stand-in for -inf (tfrs uses finfo.min/100)
+
+enum { MODE_FWD = 0, MODE_BWD = 1 };
+
+struct ScoreArgs {
+  const float* R;
+  const float* K;
+  int64_t n_r, n_c;
+  int64_t diag;             // positive pair: c == r + diag
+  float c1;                 // log2(e) / temperature
+  const float* a_r;         // [n_r] additive, log2 domain (nullable = 0)
+  const float* s_r;         // [n_r] multiplicative (nullable = 1)
+  const float* a_c;         // [n_c]
+  const float* s_c;         // [n_c]
+  const int64_t* id_r;      // accidental-hit ids (HAS_IDS only)
+  const int64_t* id_c;
+  int nsplit;
+  int64_t c_per_split;      // multiple of 32
+  float* part_m;            // FWD [nsplit][n_r]
+  float* part_l;            // FWD [nsplit][n_r]
+  float* pos2;              // FWD [n_r] positive logit (log2 domain)
+  float* slab;              // BWD [nsplit][n_r][D]
+};
+
+template <int D>
+struct Geo {
+  static constexpr int LS = D + 4;             // LDS row stride (floats): bank-conflict-free b128 reads
+  static constexpr int NG = D / 8;             // GEMM1 k-groups of 8 (4 per lane half)
+  static constexpr int NB = D / 32;            // GEMM2 d-blocks (d = NB*lane_row + b)
+  static constexpr int TILE_F = 32 * LS;
+  static constexpr int BUF_F = TILE_F + 128;   // + a_c[32] + s_c[32] + id_c[32] (int64)
+  static constexpr int NV = (32 * D / 4) / 256 > 0 ? (32 * D / 4) / 256 : 1;   // staged float4 per thread
+  static constexpr int LDS_BYTES = 2 * BUF_F * 4;
+};
+
+template <int D, int MODE, bool HAS_IDS>
+__global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void score_kernel(ScoreArgs p) {
+  using G_ = Geo<D>;
+  constexpr int LS = G_::LS, NG = G_::NG, NB = G_::NB, TILE_F = G_::TILE_F, BUF_F = G_::BUF_F, NV = G_::NV;
+  constexpr int ROW4 = D / 4;                       // float4 per K row
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int h = lane >> 5;
+  const int ln = lane & 31;
+
+  const int split = blockIdx.x % p.nsplit;
+  const int64_t rblk = blockIdx.x / p.nsplit;
+  const int64_t r0w = rblk * 128 + wave * 32;       // first row of this wave
+  const int64_t r = r0w + ln;                       // this lane's row (both halves)
+  const bool r_ok = r < p.n_r;
+  const int64_t c_begin = (int64_t)split * p.c_per_split;
+  int64_t c_end = c_begin + p.c_per_split;
+  if (c_end > p.n_c) c_end = p.n_c;
+  const int ntiles = c_end > c_begin ? (int)((c_end - c_begin + 31) >> 5) : 0;
+
+  // ---- stationary fragment: rf[g][s] = R[r][8g + 4h + s]  (B operand of GEMM1) ----
+  f32x4 rf[NG];
+  {
+    const f32x4* R4 = reinterpret_cast<const f32x4*>(p.R + (r_ok ? r : 0) * D) + h;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) rf[g] = r_ok ? R4[2 * g] : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const float ar = (MODE == MODE_BWD && p.a_r != nullptr && r_ok) ? p.a_r[r] : 0.f;
+  const float sr = (MODE == MODE_BWD && p.s_r != nullptr && r_ok) ? p.s_r[r] : 1.f;
+  int64_t idr = 0;
+  if constexpr (HAS_IDS) idr = r_ok ? p.id_r[r] : (int64_t)-1;
+  const int64_t cpos = r + p.diag;                  // this lane's positive column
+
+  // ---- staging (global -> regs -> LDS, one tile ahead).  Thread `tid` moves float4 number
+  // tid + 256*j of the tile (row = f / ROW4, col4 = f % ROW4): 32-bit offsets from one running pointer.
+  f32x4 st[NV];
+  float st_a = 0.f, st_s = 0.f;
+  int64_t st_id = -2;
+  constexpr int RPJ = 256 / ROW4;                   // tile rows between a thread's consecutive float4s
+  const int st_row = tid / ROW4, st_col4 = tid % ROW4;
+  const f32x4* kp = reinterpret_cast<const f32x4*>(p.K) + c_begin * ROW4 + tid;   // tile 0
+  const float* acp = p.a_c != nullptr ? p.a_c + c_begin + tid : nullptr;
+  const float* scp = p.s_c != nullptr ? p.s_c + c_begin + tid : nullptr;
+  const int64_t* idp = nullptr;
+  if constexpr (HAS_IDS) idp = p.id_c + c_begin + tid;
+  const int ncols = (int)(c_end - c_begin);         // columns of this split (<= c_per_split)
+
+  auto load_tile = [&](int t) {
+    const int nvalid = ncols - 32 * t;              // valid rows of tile t (may exceed 32)
+    const f32x4* src = kp + (int64_t)t * (32 * ROW4);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int row = st_row + j * RPJ;
+      st[j] = (row < 32 && row < nvalid) ? src[256 * j] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (tid < 32) {
+      const bool ok = tid < nvalid;
+      st_a = ok ? (acp != nullptr ? acp[32 * t] : 0.f) : kNegBig;
+      st_s = ok ? (scp != nullptr ? scp[32 * t] : 1.f) : 0.f;
+      if constexpr (HAS_IDS) st_id = ok ? idp[32 * t] : (int64_t)-2;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    float* T = smem + buf * BUF_F;
+    float* dst = T + st_row * LS + st_col4 * 4;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+      if (st_row + j * RPJ < 32) *reinterpret_cast<f32x4*>(dst + j * RPJ * LS) = st[j];
+    if (tid < 32) {
+      T[TILE_F + tid] = st_a;
+      T[TILE_F + 32 + tid] = st_s;
+      if constexpr (HAS_IDS) reinterpret_cast<int64_t*>(T + TILE_F + 64)[tid] = st_id;
+    }
+  };
+
+  // ---- per-lane state ----
+  float run_m = kNegBig, run_l = 0.f, pos = 0.f;
+  bool have_pos = false;
+  f32x16 G[NB];
+  if constexpr (MODE == MODE_BWD) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) G[b][i] = 0.f;
+  }
+
+  if (ntiles > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    // FWD: prefetch the next tile at the top.  BWD: registers are tight (rf + G + X + coef), so the
+    // prefetch is issued just before GEMM2, whose 16*NB MFMAs (>= 1.7 us at D=128) cover its latency.
+    if constexpr (MODE == MODE_FWD) { if (t + 1 < ntiles) load_tile(t + 1); }
+    const float* T = smem + (t & 1) * BUF_F;
+    const int64_t c0 = c_begin + 32 * (int64_t)t;
+
+    // ---- GEMM1: X[c][r] ----
+    f32x16 X;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) X[i] = 0.f;
+    {
+      const float* arow = T + ln * LS + 4 * h;
+      // one ds_read_b128 ahead of the MFMAs that use it; sched_barrier keeps hipcc from hoisting all
+      // NG reads (4*NG VGPRs) to the loop top
+      f32x4 a_cur = *reinterpret_cast<const f32x4*>(arow);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        f32x4 a_nxt = a_cur;
+        if (g + 1 < NG) a_nxt = *reinterpret_cast<const f32x4*>(arow + 8 * (g + 1));
+        X = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0], rf[g][0], X, 0, 0, 0);
+        X = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[1], rf[g][1], X, 0, 0, 0);
+        X = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[2], rf[g][2], X, 0, 0, 0);
+        X = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[3], rf[g][3], X, 0, 0, 0);
+        a_cur = a_nxt;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+
+    // ---- per-column terms of this lane's 16 accumulator rows: c = c0 + 8*q + 4*h + i ----
+    float ac[16], sc[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 va = *reinterpret_cast<const f32x4*>(T + TILE_F + 8 * q + 4 * h);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ac[4 * q + i] = va[i];
+      if constexpr (MODE == MODE_BWD) {
+        const f32x4 vs = *reinterpret_cast<const f32x4*>(T + TILE_F + 32 + 8 * q + 4 * h);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sc[4 * q + i] = vs[i];
+      }
+    }
+    // wave-uniform: does this tile hold the positive of any row of this wave?
+    const bool diag_tile = (c0 < r0w + p.diag + 32) && (c0 + 32 > r0w + p.diag);
+    // tile-local row (minus the lane half's +4h) of this lane's positive, or a value no row matches
+    int dloc = -100;
+    if (diag_tile) {
+      const int64_t dd = cpos - c0;
+      dloc = (dd >= 0 && dd < 32) ? (int)dd - 4 * h : -100;
+    }
+    bool dup[16];
+    if constexpr (HAS_IDS) {
+      const int64_t* idc = reinterpret_cast<const int64_t*>(T + TILE_F + 64) + 4 * h;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg)
+        dup[reg] = (idc[tt::acc_row(reg, 0)] == idr) && (tt::acc_row(reg, 0) != dloc);
+    }
+
+    if constexpr (MODE == MODE_FWD) {
+      float t2[16];
+      float mx = kNegBig;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        float v = __builtin_fmaf(X[reg], p.c1, ac[reg]);
+        if constexpr (HAS_IDS) v = dup[reg] ? kNegBig : v;
+        t2[reg] = v;
+        mx = fmaxf(mx, v);
+      }
+      if (diag_tile) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+          if (tt::acc_row(reg, 0) == dloc) { pos = t2[reg]; have_pos = true; }
+      }
+      const float m_new = fmaxf(run_m, mx);
+      float sum = 0.f;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) sum += __builtin_amdgcn_exp2f(t2[reg] - m_new);
+      run_l = run_l * __builtin_amdgcn_exp2f(run_m - m_new) + sum;
+      run_m = m_new;
+    } else {
+      float coef[16];
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const float w = sc[reg] * sr;
+        float e = __builtin_amdgcn_exp2f(__builtin_fmaf(X[reg], p.c1, ac[reg]) + ar) * w;
+        if constexpr (HAS_IDS) e = dup[reg] ? 0.f : e;
+        coef[reg] = e;
+      }
+      if (diag_tile) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+          if (tt::acc_row(reg, 0) == dloc) coef[reg] -= sc[reg] * sr;
+      }
+      if (t + 1 < ntiles) load_tile(t + 1);
+      // ---- GEMM2: G^T[d = NB*i + b][r] += K[c(reg,h)][d] * coef[reg] ----
+      const float* kbase = T + 4 * h * LS + NB * ln;
+      f32x4 kc0, kc1;
+      auto read_k = [&](int reg, f32x4& k0, f32x4& k1) {
+        const float* krow = kbase + tt::acc_row(reg, 0) * LS;
+        if constexpr (NB == 8) {
+          k0 = *reinterpret_cast<const f32x4*>(krow);
+          k1 = *reinterpret_cast<const f32x4*>(krow + 4);
+        } else if constexpr (NB == 4) {
+          k0 = *reinterpret_cast<const f32x4*>(krow);
+        } else if constexpr (NB == 2) {
+          const float2 k2 = *reinterpret_cast<const float2*>(krow);
+          k0[0] = k2.x; k0[1] = k2.y;
+        } else {
+          k0[0] = krow[0];
+        }
+      };
+      read_k(0, kc0, kc1);
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        f32x4 kn0 = kc0, kn1 = kc1;
+        if (reg + 1 < 16) read_k(reg + 1, kn0, kn1);
+#pragma unroll
+        for (int b = 0; b < (NB < 4 ? NB : 4); ++b)
+          G[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(kc0[b], coef[reg], G[b], 0, 0, 0);
+        if constexpr (NB == 8) {
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            G[4 + b] = __builtin_amdgcn_mfma_f32_32x32x2f32(kc1[b], coef[reg], G[4 + b], 0, 0, 0);
+        }
+        kc0 = kn0; kc1 = kn1;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+
+    if (t + 1 < ntiles) store_tile((t + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+  if constexpr (MODE == MODE_FWD) {
+    const float om = __shfl_xor(run_m, 32);
+    const float ol = __shfl_xor(run_l, 32);
+    const float M = fmaxf(run_m, om);
+    const float L = run_l * __builtin_amdgcn_exp2f(run_m - M) + ol * __builtin_amdgcn_exp2f(om - M);
+    if (r_ok) {
+      if (h == 0) {
+        p.part_m[(int64_t)split * p.n_r + r] = M;
+        p.part_l[(int64_t)split * p.n_r + r] = L;
+      }
+      if (have_pos) p.pos2[r] = pos;
+    }
+  } else {
+    if (r_ok) {
+      float* out = p.slab + ((int64_t)split * p.n_r + r) * D;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int i = tt::acc_row(reg, 0) + 4 * h;
+        if constexpr (NB == 8) {
+          *reinterpret_cast<f32x4*>(out + 8 * i) = f32x4{G[0][reg], G[1][reg], G[2][reg], G[3][reg]};
+          *reinterpret_cast<f32x4*>(out + 8 * i + 4) = f32x4{G[4][reg], G[5][reg], G[6][reg], G[7][reg]};
+        } else if constexpr (NB == 4) {
+          *reinterpret_cast<f32x4*>(out + 4 * i) = f32x4{G[0][reg], G[1][reg], G[2][reg], G[3][reg]};
+        } else if constexpr (NB == 2) {
+          *reinterpret_cast<float2*>(out + 2 * i) = float2{G[0][reg], G[1][reg]};
+        } else {
+          out[i] = G[0][reg];
+        }
+      }
+    }
+  }
+}
+
+// ---- small kernels around the main pass -------------------------------------------------------
+
+// -log2(clip(p, 1e-6, 1))  (tfrs SamplingProbablityCorrection, log2 domain)
+__global__ __launch_bounds__(256) void prob_bias_kernel(const float* __restrict__ prob, float* __restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = -__log2f(fminf(fmaxf(prob[i], 1e-6f), 1.0f));
+}
+
+// a = -lse*log2e ; s = w * inv_t * gscale
+__global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__ lse, const float* __restrict__ w,
+                                                       float* __restrict__ a, float* __restrict__ s, int64_t n,
+                                                       float scale) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    a[i] = -lse[i] * kLog2e;
+    s[i] = (w != nullptr ? w[i] : 1.0f) * scale;
+  }
+}
+
+// lse / per-row loss / total loss from the per-split (max, sum) pairs.  One workgroup: the total is
+// a fixed-order sum (bitwise reproducible).
+__global__ __launch_bounds__(1024) void fwd_combine_kernel(const float* __restrict__ part_m, const float* __restrict__ part_l,
+                                                           const float* __restrict__ pos2, const float* __restrict__ w,
+                                                           int64_t n_r, int nsplit, float* __restrict__ lse,
+                                                           float* __restrict__ per_row, float* __restrict__ loss) {
+  __shared__ float red[1024];
+  float acc = 0.f;
+  for (int64_t r = threadIdx.x; r < n_r; r += 1024) {
+    float M = kNegBig;
+    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, part_m[(int64_t)s * n_r + r]);
+    float L = 0.f;
+    for (int s = 0; s < nsplit; ++s)
+      L += part_l[(int64_t)s * n_r + r] * __builtin_amdgcn_exp2f(part_m[(int64_t)s * n_r + r] - M);
+    const float lse2 = M + __log2f(L);
+    const float row = (lse2 - pos2[r]) * kLn2 * (w != nullptr ? w[r] : 1.0f);
+    lse[r] = lse2 * kLn2;
+    per_row[r] = row;
+    acc += row;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = red[0];
+}
+
+// out[i] = sum_s slab[s][i], s ascending (float4)
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const f32x4* __restrict__ slab, f32x4* __restrict__ out,
+                                                           int64_t n4, int nsplit) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    f32x4 a = slab[i];
+    for (int s = 1; s < nsplit; ++s) a += slab[(int64_t)s * n4 + i];
+    out[i] = a;
+  }
+}
+
+// ---- host side --------------------------------------------------------------------------------
+
+int choose_nsplit(int64_t n_r, int64_t n_c) {
+  const int64_t nrb = (n_r + 127) / 128;
+  int ns = 1;
+  while (nrb * ns < 512 && (int64_t)ns * 2 * 64 <= n_c && ns < 64) ns *= 2;
+  return ns;
+}
+
+int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+struct WsLayout {
+  int ns_q, ns_c;           // splits for the passes whose stationary side is q / c
+  int64_t off_bias, off_aq, off_sq, off_pm, off_pl, off_pos, off_slab, total;
+};
+
+WsLayout ws_layout(int64_t nq, int64_t nc, int32_t dim) {
+  WsLayout w{};
+  w.ns_q = choose_nsplit(nq, nc);
+  w.ns_c = choose_nsplit(nc, nq);
+  int64_t o = 0;
+  w.off_bias = o; o = align_up(o + nc * 4, 256);
+  w.off_aq = o;   o = align_up(o + nq * 4, 256);
+  w.off_sq = o;   o = align_up(o + nq * 4, 256);
+  w.off_pm = o;   o = align_up(o + (int64_t)w.ns_q * nq * 4, 256);
+  w.off_pl = o;   o = align_up(o + (int64_t)w.ns_q * nq * 4, 256);
+  w.off_pos = o;  o = align_up(o + nq * 4, 256);
+  w.off_slab = o;
+  const int64_t slab_q = (int64_t)w.ns_q * nq * dim * 4, slab_c = (int64_t)w.ns_c * nc * dim * 4;
+  o = align_up(o + (slab_q > slab_c ? slab_q : slab_c), 256);
+  w.total = o;
+  return w;
+}
+
+template <int D, int MODE>
+int launch_score(const ScoreArgs& a, bool has_ids, hipStream_t stream) {
+  const int64_t nrb = (a.n_r + 127) / 128;
+  const int64_t blocks = nrb * a.nsplit;
+  const int lds = Geo<D>::LDS_BYTES;
+  if constexpr (Geo<D>::LDS_BYTES > 64 * 1024) {   // above the 64 KiB default the limit must be raised once
+    static bool raised = false;
+    if (!raised) {
+      hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&score_kernel<D, MODE, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&score_kernel<D, MODE, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e1 != hipSuccess || e2 != hipSuccess) return tt::fail(TT_ERR_LAUNCH, "hipFuncSetAttribute(LDS %d) failed", lds);
+      raised = true;
+    }
+  }
+  if (has_ids)
+    hipLaunchKernelGGL((score_kernel<D, MODE, true>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+  else
+    hipLaunchKernelGGL((score_kernel<D, MODE, false>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+  return tt::check_launch(MODE == MODE_FWD ? "score_fwd" : "score_bwd");
+}
+
+template <int MODE>
+int dispatch_score(int32_t dim, const ScoreArgs& a, bool has_ids, hipStream_t stream) {
+  switch (dim) {
+    case 32: return launch_score<32, MODE>(a, has_ids, stream);
+    case 64: return launch_score<64, MODE>(a, has_ids, stream);
+    case 128: return launch_score<128, MODE>(a, has_ids, stream);
+    case 256: return launch_score<256, MODE>(a, has_ids, stream);
+    default: return tt::fail(TT_ERR_UNSUPPORTED, "retrieval: dim %d not in {32,64,128,256}", dim);
+  }
+}
+
+int check_common(const char* fn, const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
+                 int64_t diag_offset, const void* ws, int64_t ws_bytes) {
+  TT_REQUIRE(q && c && ws, "%s: null pointer", fn);
+  TT_REQUIRE(nq > 0 && nc > 0, "%s: nq and nc must be positive", fn);
+  TT_REQUIRE(diag_offset >= 0 && nq + diag_offset <= nc, "%s: need 0 <= diag_offset and nq + diag_offset <= nc", fn);
+  TT_REQUIRE(dim == 32 || dim == 64 || dim == 128 || dim == 256, "%s: dim %d not in {32,64,128,256}", fn, dim);
+  TT_REQUIRE(tt::aligned16(q) && tt::aligned16(c), "%s: q/c must be 16-byte aligned", fn);
+  TT_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255u) == 0, "%s: workspace must be 256-byte aligned", fn);
+  if (ws_bytes < ws_layout(nq, nc, dim).total)
+    return tt::fail(TT_ERR_WORKSPACE, "%s: workspace %lld < %lld bytes", fn, (long long)ws_bytes,
+                    (long long)ws_layout(nq, nc, dim).total);
+  return TT_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t tt_retrieval_workspace_bytes(int64_t nq, int64_t nc, int32_t dim) {
+  if (nq <= 0 || nc <= 0 || dim <= 0) return 0;
+  return ws_layout(nq, nc, dim).total;
+}
+
+extern "C" int tt_retrieval_fwd_f32(const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
+                                    int64_t diag_offset, float inv_temperature, const float* sample_weight,
+                                    const float* cand_prob, const int64_t* cand_ids, void* workspace,
+                                    int64_t workspace_bytes, float* lse, float* per_row, float* loss,
+                                    tt_stream_t stream_) {
+  int rc = check_common("tt_retrieval_fwd_f32", q, c, nq, nc, dim, diag_offset, workspace, workspace_bytes);
+  if (rc != TT_OK) return rc;
+  TT_REQUIRE(lse && per_row && loss, "tt_retrieval_fwd_f32: null output pointer");
+  hipStream_t stream = tt::as_stream(stream_);
+  const WsLayout w = ws_layout(nq, nc, dim);
+  char* ws = static_cast<char*>(workspace);
+  float* bias = reinterpret_cast<float*>(ws + w.off_bias);
+  if (cand_prob != nullptr) {
+    hipLaunchKernelGGL(prob_bias_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, stream, cand_prob, bias, nc);
+    if ((rc = tt::check_launch("prob_bias")) != TT_OK) return rc;
+  }
+  ScoreArgs a{};
+  a.R = q; a.K = c; a.n_r = nq; a.n_c = nc; a.diag = diag_offset;
+  a.c1 = kLog2e * inv_temperature;
+  a.a_c = cand_prob != nullptr ? bias : nullptr;
+  a.id_r = cand_ids != nullptr ? cand_ids + diag_offset : nullptr;
+  a.id_c = cand_ids;
+  a.nsplit = w.ns_q;
+  a.c_per_split = align_up((nc + a.nsplit - 1) / a.nsplit, 32);
+  a.part_m = reinterpret_cast<float*>(ws + w.off_pm);
+  a.part_l = reinterpret_cast<float*>(ws + w.off_pl);
+  a.pos2 = reinterpret_cast<float*>(ws + w.off_pos);
+  if ((rc = dispatch_score<MODE_FWD>(dim, a, cand_ids != nullptr, stream)) != TT_OK) return rc;
+  hipLaunchKernelGGL(fwd_combine_kernel, dim3(1), dim3(1024), 0, stream, a.part_m, a.part_l, a.pos2, sample_weight, nq,
+                     a.nsplit, lse, per_row, loss);
+  return tt::check_launch("fwd_combine");
+}
+
+extern "C" int tt_retrieval_bwd_f32(const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
+                                    int64_t diag_offset, float inv_temperature, const float* sample_weight,
+                                    const float* cand_prob, const int64_t* cand_ids, const float* lse,
+                                    float grad_scale, void* workspace, int64_t workspace_bytes, float* dq, float* dc,
+                                    tt_stream_t stream_) {
+  int rc = check_common("tt_retrieval_bwd_f32", q, c, nq, nc, dim, diag_offset, workspace, workspace_bytes);
+  if (rc != TT_OK) return rc;
+  TT_REQUIRE(lse && dq && dc, "tt_retrieval_bwd_f32: null lse/dq/dc");
+  TT_REQUIRE(tt::aligned16(dq) && tt::aligned16(dc), "tt_retrieval_bwd_f32: dq/dc must be 16-byte aligned");
+  hipStream_t stream = tt::as_stream(stream_);
+  const WsLayout w = ws_layout(nq, nc, dim);
+  char* ws = static_cast<char*>(workspace);
+  float* bias = reinterpret_cast<float*>(ws + w.off_bias);
+  float* aq = reinterpret_cast<float*>(ws + w.off_aq);
+  float* sq = reinterpret_cast<float*>(ws + w.off_sq);
+  float* slab = reinterpret_cast<float*>(ws + w.off_slab);
+  if (cand_prob != nullptr) {
+    hipLaunchKernelGGL(prob_bias_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, stream, cand_prob, bias, nc);
+    if ((rc = tt::check_launch("prob_bias")) != TT_OK) return rc;
+  }
+  hipLaunchKernelGGL(bwd_prep_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, lse, sample_weight, aq,
+                     sq, nq, inv_temperature * grad_scale);
+  if ((rc = tt::check_launch("bwd_prep")) != TT_OK) return rc;
+  const float* biasp = cand_prob != nullptr ? bias : nullptr;
+
+  // dq: stationary q, stream c
+  {
+    ScoreArgs a{};
+    a.R = q; a.K = c; a.n_r = nq; a.n_c = nc; a.diag = diag_offset;
+    a.c1 = kLog2e * inv_temperature;
+    a.a_r = aq; a.s_r = sq; a.a_c = biasp; a.s_c = nullptr;
+    a.id_r = cand_ids != nullptr ? cand_ids + diag_offset : nullptr;
+    a.id_c = cand_ids;
+    a.nsplit = w.ns_q;
+    a.c_per_split = align_up((nc + a.nsplit - 1) / a.nsplit, 32);
+    a.slab = slab;
+    if ((rc = dispatch_score<MODE_BWD>(dim, a, cand_ids != nullptr, stream)) != TT_OK) return rc;
+    const int64_t n4 = nq * dim / 4;
+    const int64_t blocks = (n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
+                       reinterpret_cast<const f32x4*>(slab), reinterpret_cast<f32x4*>(dq), n4, a.nsplit);
+    if ((rc = tt::check_launch("reduce_slabs(dq)")) != TT_OK) return rc;
+  }
+  // dc: stationary c, stream q.  Candidates beyond nq + diag_offset have no positive: diag never matches.
+  {
+    ScoreArgs a{};
+    a.R = c; a.K = q; a.n_r = nc; a.n_c = nq; a.diag = -diag_offset;
+    a.c1 = kLog2e * inv_temperature;
+    a.a_r = biasp; a.s_r = nullptr; a.a_c = aq; a.s_c = sq;
+    a.id_r = cand_ids;
+    a.id_c = cand_ids != nullptr ? cand_ids + diag_offset : nullptr;
+    a.nsplit = w.ns_c;
+    a.c_per_split = align_up((nq + a.nsplit - 1) / a.nsplit, 32);
+    a.slab = slab;
+    if ((rc = dispatch_score<MODE_BWD>(dim, a, cand_ids != nullptr, stream)) != TT_OK) return rc;
+    const int64_t n4 = nc * dim / 4;
+    const int64_t blocks = (n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
+                       reinterpret_cast<const f32x4*>(slab), reinterpret_cast<f32x4*>(dc), n4, a.nsplit);
+    if ((rc = tt::check_launch("reduce_slabs(dc)")) != TT_OK) return rc;
+  }
+  return TT_OK;
+}

@@ -1,0 +1,189 @@
+// K2 — fused sparse optimizer on embedding rows.
+//
+// plan  : stable LSD radix sort of (id, position) by id (rocPRIM device radix sort — integer index
+//         plumbing; only the ids are needed, so it runs before / beside the forward pass).
+// apply : one group of dim/4 lanes per sorted slot.  A slot that starts a run of equal ids walks the
+//         run, summing the gradient rows in ascending position order (sequential f32 adds: the
+//         IndexedSlices de-duplication Keras performs before the update; bitwise reproducible and
+//         bit-equal to the oracle's np.add.at), then read-modify-writes the table row (and the
+//         Adagrad accumulator row) once.  Other slots exit.  No float atomics: Adagrad is
+//         non-linear in g, so duplicates MUST be summed first.
+// HBM-bound.  Algorithmic bytes per distinct row: 4*dim (grad) + 4*dim (row read) + 4*dim (row write)
+// [+ 8*dim accumulator read/write for Adagrad] + 12 (sorted id + position).
+#include "common.h"
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+
+namespace {
+
+using tt::f32x4;
+
+int id_bits(int64_t num_rows) {
+  int bits = 1;
+  while (bits < 63 && ((int64_t)1 << bits) < num_rows) ++bits;
+  return bits;
+}
+
+struct ApplyArgs {
+  float* table[2];
+  float* accum[2];
+  const float* grads[2];
+  const int64_t* sorted_ids[2];
+  const int32_t* order[2];
+  int64_t rows[2];
+};
+
+template <int OPT>
+__global__ __launch_bounds__(256) void sparse_apply_kernel(ApplyArgs a, int dim4, int lpr_log2, int64_t n_ids, float lr,
+                                                           float eps) {
+  const int t = blockIdx.y;
+  f32x4* __restrict__ table = reinterpret_cast<f32x4*>(a.table[t]);
+  f32x4* __restrict__ accum = reinterpret_cast<f32x4*>(a.accum[t]);
+  const f32x4* __restrict__ grads = reinterpret_cast<const f32x4*>(a.grads[t]);
+  const int64_t* __restrict__ sid = a.sorted_ids[t];
+  const int32_t* __restrict__ order = a.order[t];
+  const int64_t rows = a.rows[t];
+
+  const int lpr = 1 << lpr_log2;
+  const int groups = 256 >> lpr_log2;
+  const int64_t k = (int64_t)blockIdx.x * groups + (threadIdx.x >> lpr_log2);   // sorted slot
+  const int l = threadIdx.x & (lpr - 1);
+  if (k >= n_ids) return;
+  const int64_t id = sid[k];
+  if (k > 0 && sid[k - 1] == id) return;          // not the head of its run
+  if (id < 0 || id >= rows) return;               // out-of-range ids are skipped (flagged by the gather)
+
+  for (int c = l; c < dim4; c += lpr) {
+    f32x4 g = grads[(int64_t)order[k] * dim4 + c];
+    // walk the run; two rows in flight
+    int64_t j = k + 1;
+    while (j < n_ids && sid[j] == id) {
+      const bool two = (j + 1 < n_ids) && (sid[j + 1] == id);
+      const f32x4 g1 = grads[(int64_t)order[j] * dim4 + c];
+      f32x4 g2 = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (two) g2 = grads[(int64_t)order[j + 1] * dim4 + c];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] = __fadd_rn(g[e], g1[e]);
+      if (two) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = __fadd_rn(g[e], g2[e]);
+      }
+      j += two ? 2 : 1;
+    }
+    f32x4 w = table[id * dim4 + c];
+    if constexpr (OPT == TT_OPT_SGD) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[e] = __fsub_rn(w[e], __fmul_rn(lr, g[e]));
+    } else {
+      f32x4 acc = accum[id * dim4 + c];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[e] = __fadd_rn(acc[e], __fmul_rn(g[e], g[e]));
+        const float den = __fsqrt_rn(__fadd_rn(acc[e], eps));
+        w[e] = __fsub_rn(w[e], __fdiv_rn(__fmul_rn(lr, g[e]), den));
+      }
+      accum[id * dim4 + c] = acc;
+    }
+    table[id * dim4 + c] = w;
+  }
+}
+
+int launch_apply(int opt, const ApplyArgs& a, int n_tables, int32_t dim, int64_t n_ids, float lr, float eps,
+                 hipStream_t stream, const char* what) {
+  if (n_ids == 0) return TT_OK;
+  const int dim4 = dim / 4;
+  int lpr_log2 = 0;
+  while ((1 << lpr_log2) < dim4 && lpr_log2 < 6) ++lpr_log2;
+  const int groups = 256 >> lpr_log2;
+  const int64_t blocks = (n_ids + groups - 1) / groups;
+  TT_REQUIRE(blocks <= 0x7fffffff, "%s: n_ids too large", what);
+  if (opt == TT_OPT_SGD)
+    hipLaunchKernelGGL(sparse_apply_kernel<TT_OPT_SGD>, dim3((unsigned)blocks, n_tables), dim3(256), 0, stream, a, dim4,
+                       lpr_log2, n_ids, lr, eps);
+  else
+    hipLaunchKernelGGL(sparse_apply_kernel<TT_OPT_ADAGRAD>, dim3((unsigned)blocks, n_tables), dim3(256), 0, stream, a,
+                       dim4, lpr_log2, n_ids, lr, eps);
+  return tt::check_launch(what);
+}
+
+int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+size_t sort_temp_bytes(int64_t n_ids) {
+  size_t bytes = 0;
+  const int64_t* kin = nullptr;
+  int64_t* kout = nullptr;
+  int32_t* vout = nullptr;
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, rocprim::counting_iterator<int32_t>(0), vout, (size_t)n_ids, 0u,
+                            64u, (hipStream_t) nullptr, false);
+  return bytes;
+}
+
+}  // namespace
+
+extern "C" int64_t tt_sparse_plan_workspace_bytes(int64_t n_ids) {
+  if (n_ids <= 0) return 256;
+  return align_up((int64_t)sort_temp_bytes(n_ids), 256) + 256;
+}
+
+extern "C" int tt_sparse_plan(const int64_t* ids, int64_t n_ids, int64_t num_rows, void* workspace, int64_t workspace_bytes,
+                              int64_t* sorted_ids, int32_t* order, tt_stream_t stream) {
+  TT_REQUIRE(n_ids >= 0 && num_rows > 0, "tt_sparse_plan: bad n_ids/num_rows");
+  TT_REQUIRE(n_ids <= 0x7fffffff, "tt_sparse_plan: n_ids must fit in int32");
+  if (n_ids == 0) return TT_OK;
+  TT_REQUIRE(ids && workspace && sorted_ids && order, "tt_sparse_plan: null pointer");
+  size_t temp = sort_temp_bytes(n_ids);
+  if ((int64_t)temp > workspace_bytes)
+    return tt::fail(TT_ERR_WORKSPACE, "tt_sparse_plan: workspace %lld < %lld bytes", (long long)workspace_bytes,
+                    (long long)temp);
+  // Only the low bits that an id < num_rows can set are sorted.  Ids outside [0,num_rows) then land
+  // somewhere in the order, possibly splitting into several runs — harmless, because the apply kernel
+  // skips every out-of-range id (the gather has already flagged them).
+  const int bits = id_bits(num_rows);
+  hipError_t e = rocprim::radix_sort_pairs(workspace, temp, ids, sorted_ids, rocprim::counting_iterator<int32_t>(0), order,
+                                           (size_t)n_ids, 0u, (unsigned)bits, tt::as_stream(stream), false);
+  if (e != hipSuccess) return tt::fail(TT_ERR_LAUNCH, "tt_sparse_plan: rocprim radix sort: %s", hipGetErrorString(e));
+  return TT_OK;
+}
+
+extern "C" int tt_sparse_sgd_f32(float* table, int64_t num_rows, int32_t dim, const float* grads, const int64_t* sorted_ids,
+                                 const int32_t* order, int64_t n_ids, float lr, tt_stream_t stream) {
+  TT_REQUIRE(n_ids >= 0 && num_rows > 0 && dim > 0 && dim % 4 == 0, "tt_sparse_sgd_f32: bad n_ids/num_rows/dim");
+  TT_REQUIRE(n_ids == 0 || (table && grads && sorted_ids && order), "tt_sparse_sgd_f32: null pointer");
+  TT_REQUIRE(tt::aligned16(table) && tt::aligned16(grads), "tt_sparse_sgd_f32: table/grads must be 16-byte aligned");
+  ApplyArgs a{};
+  a.table[0] = table; a.grads[0] = grads; a.sorted_ids[0] = sorted_ids; a.order[0] = order; a.rows[0] = num_rows;
+  return launch_apply(TT_OPT_SGD, a, 1, dim, n_ids, lr, 0.f, tt::as_stream(stream), "tt_sparse_sgd_f32");
+}
+
+extern "C" int tt_sparse_adagrad_f32(float* table, float* accum, int64_t num_rows, int32_t dim, const float* grads,
+                                     const int64_t* sorted_ids, const int32_t* order, int64_t n_ids, float lr, float eps,
+                                     tt_stream_t stream) {
+  TT_REQUIRE(n_ids >= 0 && num_rows > 0 && dim > 0 && dim % 4 == 0, "tt_sparse_adagrad_f32: bad n_ids/num_rows/dim");
+  TT_REQUIRE(n_ids == 0 || (table && accum && grads && sorted_ids && order), "tt_sparse_adagrad_f32: null pointer");
+  TT_REQUIRE(tt::aligned16(table) && tt::aligned16(accum) && tt::aligned16(grads),
+             "tt_sparse_adagrad_f32: table/accum/grads must be 16-byte aligned");
+  ApplyArgs a{};
+  a.table[0] = table; a.accum[0] = accum; a.grads[0] = grads; a.sorted_ids[0] = sorted_ids; a.order[0] = order;
+  a.rows[0] = num_rows;
+  return launch_apply(TT_OPT_ADAGRAD, a, 1, dim, n_ids, lr, eps, tt::as_stream(stream), "tt_sparse_adagrad_f32");
+}
+
+extern "C" int tt_sparse_update2_f32(int32_t opt, float* table_a, float* accum_a, int64_t rows_a, const float* grads_a,
+                                     const int64_t* sorted_ids_a, const int32_t* order_a, float* table_b, float* accum_b,
+                                     int64_t rows_b, const float* grads_b, const int64_t* sorted_ids_b,
+                                     const int32_t* order_b, int32_t dim, int64_t n_ids, float lr, float eps,
+                                     tt_stream_t stream) {
+  TT_REQUIRE(opt == TT_OPT_SGD || opt == TT_OPT_ADAGRAD, "tt_sparse_update2_f32: unknown optimizer %d", opt);
+  TT_REQUIRE(n_ids >= 0 && rows_a > 0 && rows_b > 0 && dim > 0 && dim % 4 == 0, "tt_sparse_update2_f32: bad sizes");
+  TT_REQUIRE(n_ids == 0 || (table_a && grads_a && sorted_ids_a && order_a && table_b && grads_b && sorted_ids_b && order_b),
+             "tt_sparse_update2_f32: null pointer");
+  TT_REQUIRE(opt == TT_OPT_SGD || (accum_a && accum_b), "tt_sparse_update2_f32: Adagrad needs accumulators");
+  TT_REQUIRE(tt::aligned16(table_a) && tt::aligned16(table_b) && tt::aligned16(grads_a) && tt::aligned16(grads_b) &&
+                 tt::aligned16(accum_a) && tt::aligned16(accum_b),
+             "tt_sparse_update2_f32: pointers must be 16-byte aligned");
+  ApplyArgs a{};
+  a.table[0] = table_a; a.accum[0] = accum_a; a.grads[0] = grads_a; a.sorted_ids[0] = sorted_ids_a; a.order[0] = order_a; a.rows[0] = rows_a;
+  a.table[1] = table_b; a.accum[1] = accum_b; a.grads[1] = grads_b; a.sorted_ids[1] = sorted_ids_b; a.order[1] = order_b; a.rows[1] = rows_b;
+  return launch_apply(opt, a, 2, dim, n_ids, lr, eps, tt::as_stream(stream), "tt_sparse_update2_f32");
+}

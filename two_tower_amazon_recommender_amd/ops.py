@@ -1,0 +1,238 @@
+"""Tensor-level wrappers over the C ABI (``include/twotower_hip.h``).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every op below
+hands raw device pointers and the current stream to ``libtwotower_hip.so``.  There is
+no eager/PyTorch fallback — a missing library or a CPU tensor raises.
+
+Reference anchors: the ops are what ``src/models`` / ``src/training`` of the reference
+(docstring stubs, ``src/models/__init__.py:1``) would have run through TensorFlow /
+TFRS for the config in ``configs/data_config.yaml:54-71``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import DenseSeg, TT_OPT_ADAGRAD, TT_OPT_SGD
+
+_OPT = {"sgd": TT_OPT_SGD, "adagrad": TT_OPT_ADAGRAD}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, dtype, name: str, ndim: int | None = None) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a CUDA/HIP tensor (there is no CPU fallback), got device {t.device}")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name}: expected a contiguous tensor")
+    if ndim is not None and t.dim() != ndim:
+        raise RuntimeError(f"{name}: expected {ndim} dims, got shape {tuple(t.shape)}")
+    return t
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+# ----------------------------------------------------------------------------- synthetic
+def fill_uniform_(dst: torch.Tensor, seed: int, tensor_id: int, lo: float, scale: float, start: int = 0):
+    """dst.flat[i] = fl32(fl32(u(start+i)*scale)+lo); bit-identical to oracle.synth.uniform_f32."""
+    _chk(dst, torch.float32, "dst")
+    lib = _lib.load()
+    _lib.check(lib.tt_fill_uniform_f32(_p(dst), dst.numel(), seed, tensor_id, start, lo, scale, _stream()),
+               "tt_fill_uniform_f32")
+    return dst
+
+
+def fill_ids_(dst: torch.Tensor, seed: int, tensor_id: int, num_rows: int, variant: str = "U", start: int = 0):
+    _chk(dst, torch.int64, "dst")
+    v = {"U": _lib.TT_IDS_UNIFORM, "Z": _lib.TT_IDS_POWERLAW}[variant]
+    lib = _lib.load()
+    _lib.check(lib.tt_fill_ids_i64(_p(dst), dst.numel(), seed, tensor_id, start, num_rows, v, _stream()),
+               "tt_fill_ids_i64")
+    return dst
+
+
+# ----------------------------------------------------------------------------- a1 gather
+def embedding_gather(table: torch.Tensor, ids: torch.Tensor, out: torch.Tensor | None = None,
+                     oob_flag: torch.Tensor | None = None) -> torch.Tensor:
+    """out[b,:] = table[ids[b],:].  ``oob_flag`` (int32[1]) is set to 1 on any out-of-range id."""
+    _chk(table, torch.float32, "table", 2)
+    _chk(ids, torch.int64, "ids", 1)
+    n, d = ids.numel(), table.shape[1]
+    if out is None:
+        out = torch.empty((n, d), dtype=torch.float32, device=table.device)
+    _chk(out, torch.float32, "out", 2)
+    if oob_flag is not None:
+        _chk(oob_flag, torch.int32, "oob_flag")
+    lib = _lib.load()
+    _lib.check(lib.tt_embedding_gather_f32(_p(table), table.shape[0], d, _p(ids), n, _p(out), _p(oob_flag), _stream()),
+               "tt_embedding_gather_f32")
+    return out
+
+
+def embedding_gather2(table_a, ids_a, out_a, table_b, ids_b, out_b, oob_flag=None):
+    """Both towers' lookups in one launch."""
+    for t, nme in ((table_a, "table_a"), (table_b, "table_b"), (out_a, "out_a"), (out_b, "out_b")):
+        _chk(t, torch.float32, nme, 2)
+    _chk(ids_a, torch.int64, "ids_a", 1)
+    _chk(ids_b, torch.int64, "ids_b", 1)
+    if ids_a.numel() != ids_b.numel() or table_a.shape[1] != table_b.shape[1]:
+        raise RuntimeError("embedding_gather2: both lookups must share n_ids and dim")
+    lib = _lib.load()
+    _lib.check(lib.tt_embedding_gather2_f32(_p(table_a), table_a.shape[0], _p(ids_a), _p(out_a),
+                                            _p(table_b), table_b.shape[0], _p(ids_b), _p(out_b),
+                                            table_a.shape[1], ids_a.numel(), _p(oob_flag), _stream()),
+               "tt_embedding_gather2_f32")
+    return out_a, out_b
+
+
+# ----------------------------------------------------------------------------- a5 sparse optimizer
+class SparsePlan:
+    """Sorted (id, position) list of one id batch; reusable buffers."""
+
+    def __init__(self, n_ids: int, device):
+        lib = _lib.load()
+        self.n_ids = n_ids
+        self.ws_bytes = int(lib.tt_sparse_plan_workspace_bytes(n_ids))
+        self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
+        self.sorted_ids = torch.empty(n_ids, dtype=torch.int64, device=device)
+        self.order = torch.empty(n_ids, dtype=torch.int32, device=device)
+
+    def run(self, ids: torch.Tensor, num_rows: int) -> "SparsePlan":
+        _chk(ids, torch.int64, "ids", 1)
+        if ids.numel() != self.n_ids:
+            raise RuntimeError(f"SparsePlan: built for {self.n_ids} ids, got {ids.numel()}")
+        lib = _lib.load()
+        _lib.check(lib.tt_sparse_plan(_p(ids), self.n_ids, num_rows, _p(self.workspace), self.ws_bytes,
+                                      _p(self.sorted_ids), _p(self.order), _stream()), "tt_sparse_plan")
+        return self
+
+
+def sparse_sgd_(table, grads, plan: SparsePlan, lr: float):
+    _chk(table, torch.float32, "table", 2)
+    _chk(grads, torch.float32, "grads", 2)
+    lib = _lib.load()
+    _lib.check(lib.tt_sparse_sgd_f32(_p(table), table.shape[0], table.shape[1], _p(grads), _p(plan.sorted_ids),
+                                     _p(plan.order), plan.n_ids, lr, _stream()), "tt_sparse_sgd_f32")
+    return table
+
+
+def sparse_adagrad_(table, accum, grads, plan: SparsePlan, lr: float, eps: float = 1e-7):
+    _chk(table, torch.float32, "table", 2)
+    _chk(accum, torch.float32, "accum", 2)
+    _chk(grads, torch.float32, "grads", 2)
+    lib = _lib.load()
+    _lib.check(lib.tt_sparse_adagrad_f32(_p(table), _p(accum), table.shape[0], table.shape[1], _p(grads),
+                                         _p(plan.sorted_ids), _p(plan.order), plan.n_ids, lr, eps, _stream()),
+               "tt_sparse_adagrad_f32")
+    return table
+
+
+def sparse_update2_(opt: str, table_a, accum_a, grads_a, plan_a: SparsePlan,
+                    table_b, accum_b, grads_b, plan_b: SparsePlan, lr: float, eps: float = 1e-7):
+    """User and item table updates in one launch."""
+    lib = _lib.load()
+    _lib.check(lib.tt_sparse_update2_f32(_OPT[opt], _p(table_a), _p(accum_a), table_a.shape[0], _p(grads_a),
+                                         _p(plan_a.sorted_ids), _p(plan_a.order),
+                                         _p(table_b), _p(accum_b), table_b.shape[0], _p(grads_b),
+                                         _p(plan_b.sorted_ids), _p(plan_b.order),
+                                         table_a.shape[1], plan_a.n_ids, lr, eps, _stream()),
+               "tt_sparse_update2_f32")
+
+
+# ----------------------------------------------------------------------------- a2 dense layers
+def dense_fwd(x, w, b, relu: bool, out=None):
+    _chk(x, torch.float32, "x", 2)
+    _chk(w, torch.float32, "w", 2)
+    if b is not None:
+        _chk(b, torch.float32, "b", 1)
+    m, k = x.shape
+    n = w.shape[1]
+    if w.shape[0] != k:
+        raise RuntimeError(f"dense_fwd: x is [{m},{k}] but w is {tuple(w.shape)}")
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=x.device)
+    _chk(out, torch.float32, "out", 2)
+    lib = _lib.load()
+    _lib.check(lib.tt_dense_fwd_f32(_p(x), _p(w), _p(b), _p(out), m, k, n, int(relu), _stream()), "tt_dense_fwd_f32")
+    return out
+
+
+def dense_bwd_num_slabs(m: int) -> int:
+    return int(_lib.load().tt_dense_bwd_num_slabs(m))
+
+
+def dense_bwd(x, w, dz, dx, dx_relu_src, dw_slabs, db_slabs):
+    """dx = dz@w^T (* (dx_relu_src>0)); dw_slabs/db_slabs get the split-K partials."""
+    _chk(x, torch.float32, "x", 2)
+    _chk(w, torch.float32, "w", 2)
+    _chk(dz, torch.float32, "dz", 2)
+    m, k = x.shape
+    n = w.shape[1]
+    if dx is not None:
+        _chk(dx, torch.float32, "dx", 2)
+    if dx_relu_src is not None:
+        _chk(dx_relu_src, torch.float32, "dx_relu_src", 2)
+    ns = dense_bwd_num_slabs(m)
+    _chk(dw_slabs, torch.float32, "dw_slabs")
+    _chk(db_slabs, torch.float32, "db_slabs")
+    if dw_slabs.numel() < ns * k * n or db_slabs.numel() < ns * n:
+        raise RuntimeError("dense_bwd: slab buffers too small")
+    lib = _lib.load()
+    _lib.check(lib.tt_dense_bwd_f32(_p(x), _p(w), _p(dz), _p(dx), _p(dx_relu_src), _p(dw_slabs), _p(db_slabs),
+                                    m, k, n, _stream()), "tt_dense_bwd_f32")
+    return ns
+
+
+def dense_update_(segs: list[DenseSeg], opt: str, lr: float, eps: float = 1e-7, apply: bool = True):
+    arr = (DenseSeg * len(segs))(*segs)
+    lib = _lib.load()
+    _lib.check(lib.tt_dense_update_f32(arr, len(segs), _OPT[opt], int(apply), lr, eps, _stream()), "tt_dense_update_f32")
+
+
+def make_dense_seg(param, accum, grad_slabs, n_slabs: int, l2: float, grad_out=None) -> DenseSeg:
+    count = param.numel()
+    return DenseSeg(_p(param), _p(accum), _p(grad_slabs), _p(grad_out), count, count, n_slabs, l2)
+
+
+# ----------------------------------------------------------------------------- a3+a4 retrieval
+def retrieval_workspace_bytes(nq: int, nc: int, dim: int) -> int:
+    return int(_lib.load().tt_retrieval_workspace_bytes(nq, nc, dim))
+
+
+def retrieval_fwd(q, c, inv_temperature: float, workspace, lse, per_row, loss, sample_weight=None,
+                  cand_prob=None, cand_ids=None, diag_offset: int = 0):
+    _chk(q, torch.float32, "query_embeddings", 2)
+    _chk(c, torch.float32, "candidate_embeddings", 2)
+    if q.shape[1] != c.shape[1]:
+        raise RuntimeError(f"retrieval: embedding dims differ: {q.shape[1]} vs {c.shape[1]}")
+    if sample_weight is not None:
+        _chk(sample_weight, torch.float32, "sample_weight", 1)
+    if cand_prob is not None:
+        _chk(cand_prob, torch.float32, "candidate_sampling_probability", 1)
+    if cand_ids is not None:
+        _chk(cand_ids, torch.int64, "candidate_ids", 1)
+    lib = _lib.load()
+    _lib.check(lib.tt_retrieval_fwd_f32(_p(q), _p(c), q.shape[0], c.shape[0], q.shape[1], diag_offset, inv_temperature,
+                                        _p(sample_weight), _p(cand_prob), _p(cand_ids), _p(workspace), workspace.numel(),
+                                        _p(lse), _p(per_row), _p(loss), _stream()), "tt_retrieval_fwd_f32")
+    return loss
+
+
+def retrieval_bwd(q, c, inv_temperature: float, workspace, lse, dq, dc, sample_weight=None, cand_prob=None,
+                  cand_ids=None, diag_offset: int = 0, grad_scale: float = 1.0):
+    lib = _lib.load()
+    _lib.check(lib.tt_retrieval_bwd_f32(_p(q), _p(c), q.shape[0], c.shape[0], q.shape[1], diag_offset, inv_temperature,
+                                        _p(sample_weight), _p(cand_prob), _p(cand_ids), _p(lse), grad_scale,
+                                        _p(workspace), workspace.numel(), _p(dq), _p(dc), _stream()),
+               "tt_retrieval_bwd_f32")
+    return dq, dc
