@@ -1,0 +1,165 @@
+"""bench.py — pairs/sec of the two-tower train step (fwd + bwd + optimizers) on MI355X.
+
+Contract: ``python bench.py --gpus N --steps K --warmup W`` (N>1 is launched by the driver through
+torch.distributed.run, one rank per GPU).  Rank 0 prints ONE JSON line.
+
+Workload at N=1: BASELINE.json configs[2] (the configuration north_star quotes its targets on,
+"batch 8192/dim 128"): 10M items x 5M users, emb_dim 128, towers 128->256(ReLU)->128, B = 8192,
+temperature 0.1, SGD lr 0.001, uniform ids, synthetic counter-based data.
+`--config cfg1|cfg2|cfg3` selects another single-GPU configuration.
+
+Inputs (tables, weights, id batches) are resident in HBM before the timed region.  A step is one
+pass of the hot path over one batch.  The `roofline` object is measured live, inside the timed
+steps, with hipEvents recorded around every launch of the dominant kernel on its own stream
+(tt_profile_enable); `cpu_baseline` times the torch-CPU restatement (oracle/torch_cpu.py, kind
+"port") on a bounded sample of the same batches, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (n_users, n_items, emb_dim, tower_dims, batch)           SURVEY.md §8d
+    "cfg1": (10_000, 10_000, 32, [32], 256),
+    "cfg2": (1_000_000, 1_000_000, 64, [64], 4096),
+    "cfg3": (5_000_000, 10_000_000, 128, [256, 128], 8192),
+}
+MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32-input MFMA dense peak
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
+    ap.add_argument("--optimizer", default="sgd", choices=["sgd", "adagrad"])
+    ap.add_argument("--ids", default="U", choices=["U", "Z"], help="uniform / power-law id batches")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def mean(xs):
+    return sum(xs) / max(len(xs), 1)
+
+
+def cpu_baseline(trainer, cfg, seed, args, batch):
+    """torch-CPU restatement on the same model state and batches (bounded sample)."""
+    from oracle.torch_cpu import TorchCpuTwoTower, time_cpu_steps      # bench's cpu_baseline leg only
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    ut, it = trainer.user_table.cpu(), trainer.item_table.cpu()
+    uw = [w.cpu().clone() for w in trainer.user_tower.w]; ub = [b.cpu().clone() for b in trainer.user_tower.b]
+    iw = [w.cpu().clone() for w in trainer.item_tower.w]; ib = [b.cpu().clone() for b in trainer.item_tower.b]
+    model = TorchCpuTwoTower(ut, it, uw, ub, iw, ib, temperature=cfg.temperature, l2=cfg.l2_regularization,
+                             lr=cfg.learning_rate, optimizer=cfg.optimizer)
+    batches = []
+    for s in range(4):
+        u, i = trainer.synthetic_batch(seed, 10_000 + s, args.ids)
+        batches.append((u.cpu(), i.cpu()))
+    sec, n = time_cpu_steps(model, batches, budget_s=args.cpu_budget_s)
+    return {"value": batch / sec, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{n} train steps of the same workload (batch {batch}) with stock torch CPU ops, "
+                      f"{sec * 1e3:.1f} ms/step; restatement, not reference code"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from two_tower_amazon_recommender_amd import _lib
+    from two_tower_amazon_recommender_amd.trainer import TwoTowerConfig, TwoTowerTrainer
+
+    if world > 1:
+        from bench_dist import run_distributed          # row-sharded tables + RCCL all-to-all
+        return run_distributed(args, rank, world, dev)
+
+    n_users, n_items, dim, tower_dims, batch = CONFIGS[args.config]
+    seed = 1000 + int(args.config[3:])
+    cfg = TwoTowerConfig(n_users=n_users, n_items=n_items, embedding_dim=dim, tower_dims=tower_dims,
+                         temperature=0.1, l2_regularization=1e-6, learning_rate=0.001,
+                         optimizer=args.optimizer, batch_size=batch)
+    trainer = TwoTowerTrainer(cfg, dev, seed=seed)
+    total = args.warmup + args.steps
+    uids = torch.empty(total, batch, dtype=torch.int64, device=dev)
+    iids = torch.empty(total, batch, dtype=torch.int64, device=dev)
+    for s in range(total):
+        trainer.synthetic_batch(seed, s, args.ids, out=(uids[s], iids[s]))
+    torch.cuda.synchronize()
+
+    for s in range(args.warmup):
+        trainer.step(uids[s], iids[s])
+    torch.cuda.synchronize()
+    trainer.check_ids()
+
+    tags = "score_fwd,score_bwd,gather,sparse_plan,sparse_apply"
+    _lib.profile_enable(tags, capacity=2 * args.steps + 8)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(args.warmup, total):
+        trainer.step(uids[s], iids[s])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = {t: _lib.profile_read(t, 2 * args.steps + 8)[0] for t in tags.split(",")}
+    _lib.profile_enable("")
+    loss = float(trainer.loss.item())
+    trainer.check_ids()
+
+    ms_per_step = dt / args.steps * 1e3
+    sd = tower_dims[-1]
+    # dominant kernel: score_kernel<D, BWD> (two launches per step: dq pass, dc pass).
+    # Algorithmic FLOPs per launch = 2*B^2*D (bwd = 4*B^2*D over both passes, recompute not counted).
+    t_bwd = mean(prof["score_bwd"]) * 1e-3
+    flops_launch = 2.0 * batch * batch * sd
+    ach = flops_launch / t_bwd / 1e12
+    t_fwd = mean(prof["score_fwd"]) * 1e-3
+    # gather + scatter (HBM): algorithmic bytes per step: gather 16BD+16B, SGD 24BD, Adagrad 40BD
+    gs_bytes = 16 * batch * dim + 16 * batch + (24 if args.optimizer == "sgd" else 40) * batch * dim
+    t_gs = (mean(prof["gather"]) + mean(prof["sparse_apply"])) * 1e-3
+    t_gs_plan = t_gs + 2 * mean(prof["sparse_plan"]) * 1e-3
+    out = {
+        "metric": "user-item pairs/sec (train step) + embedding-gather HBM GB/s, 1/2/4/8 MI355X",
+        "value": batch / (dt / args.steps), "unit": "pairs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.config}: {n_users} users x {n_items} items, emb_dim {dim}, towers "
+                               f"{dim}->{'->'.join(map(str, tower_dims))}, batch {batch}, in-batch sampled softmax T=0.1, "
+                               f"{args.optimizer} lr 1e-3, ids {args.ids}",
+                   "global_batch": batch, "parallelism": "single GPU"},
+        "roofline": {"bound": "mfma", "kernel": f"score_kernel<{sd},BWD> (one gradient pass; 2 launches/step)",
+                     "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS,
+                     "traffic": None, "avg_launch_us": t_bwd * 1e6, "dtype": "f32-input MFMA",
+                     "executed_tflops": 2 * ach,
+                     "score_fwd_bwd": {"algorithmic_tflops": 6.0 * batch * batch * sd / (t_fwd + 2 * t_bwd) / 1e12,
+                                       "fwd_launch_us": t_fwd * 1e6}},
+        "roofline_hbm": {"bound": "hbm", "kernel": "gather2 + sparse_update2 (K1 + K2 apply; both tables)",
+                         "achieved": gs_bytes / t_gs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gs_bytes / t_gs / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "gather_us": mean(prof["gather"]) * 1e3, "sparse_apply_us": mean(prof["sparse_apply"]) * 1e3,
+                         "sparse_plan_us_each": mean(prof["sparse_plan"]) * 1e3,
+                         "achieved_incl_plan": gs_bytes / t_gs_plan / 1e9, "algorithmic_bytes": gs_bytes},
+        "loss_per_pair": loss / batch,
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(trainer, cfg, seed, args, batch)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

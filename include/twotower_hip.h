@@ -48,6 +48,18 @@ int tt_abi_version(void);
 const char* tt_last_error(void);
 
 /* ---------------------------------------------------------------------------------------
+ * Built-in kernel timing (SURVEY.md §5 "Tracing / profiling": the reference has none).
+ * tt_profile_enable("score_bwd,gather", 4096) makes every launch of the kernels carrying one
+ * of those tags record a hipEvent pair on ITS OWN stream (capacity = launches kept per tag);
+ * tags: fill, gather, sparse_plan, sparse_apply, dense_fwd, dense_bwd_dx, dense_bwd_dw,
+ * dense_update, score_fwd, score_bwd, score_aux.  An empty string (or NULL) disables it.
+ * tt_profile_read synchronises on the recorded events, writes up to `cap` durations in
+ * milliseconds (launch order) to the HOST array `ms`, stores the number of launches seen in
+ * *count (HOST) and clears the tag.  Disabled = one predictable branch per launch.           */
+int tt_profile_enable(const char* tags_csv, int32_t capacity_per_tag);
+int tt_profile_read(const char* tag, float* ms, int32_t cap, int32_t* count);
+
+/* ---------------------------------------------------------------------------------------
  * Synthetic inputs (SURVEY.md §8d "Synthetic inputs"; no reference counterpart).
  * Counter-based splitmix64; bit-identical to oracle/synth.py.
  *   value(i) = fl32(fl32(u(start+i) * scale) + lo),  u in [0,1) with 24 bits.          */

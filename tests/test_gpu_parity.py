@@ -115,8 +115,10 @@ def test_sparse_adagrad_within_2ulp(dev, variant):
     ops.sparse_adagrad_(d_table, d_acc, T(grads, dev), plan, lr=0.001, eps=1e-7)
     rt, ra = tt.sparse_adagrad(table.copy(), accum.copy(), ids, grads, 0.001, 1e-7)
     assert np.array_equal(d_acc.cpu().numpy(), ra)
-    ulp = np.abs(d_table.cpu().numpy().view(np.int32).astype(np.int64) - rt.view(np.int32).astype(np.int64))
-    assert ulp.max() <= 2
+    # the applied update  table_before - table_after  is what the optimizer computes: <= 2 ulp of it
+    # (observed: rows bit-exact — f32 sqrt and divide are correctly rounded on both sides)
+    got = d_table.cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), rt.view(np.uint32))
 
 
 def test_sparse_update2_both_tables_one_launch(dev):
@@ -247,7 +249,11 @@ def check_retrieval(dev, nq, nc, d, temperature=0.1, scale=0.3, use_w=False, use
     assert abs(loss - rl) / nq <= 1e-4 and abs(loss - rl) <= 1e-4 * abs(rl), (loss, rl)
     assert np.abs(lse - rlse).max() <= 1e-4 * max(1.0, np.abs(rlse).max())
     assert np.abs(per_row - rper).max() <= 1e-4 * max(1.0, np.abs(rper).max())
-    assert rel_err(dq, rdq) <= 1e-4 and rel_err(dc, rdc) <= 1e-4, (rel_err(dq, rdq), rel_err(dc, rdc))
+    # max-abs error <= 1e-4 * max|reference|, with a floor for degenerate all-zero gradients (nc == 1):
+    # each gradient row is a sum of terms of size (w/T)*|embedding|, the floor is 1e-6 of that
+    floor = 1e-6 * (1.5 / temperature) * scale
+    for got, ref in ((dq, rdq), (dc, rdc)):
+        assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max() + floor, (np.abs(got - ref).max(), np.abs(ref).max())
 
 
 @pytest.mark.parametrize("b,d", [(256, 32), (4096, 64), (8192, 128), (1024, 256)])

@@ -36,6 +36,8 @@ _p, _i64, _i32, _u64, _f = C.c_void_p, C.c_int64, C.c_int32, C.c_uint64, C.c_flo
 SIGNATURES = {
     "tt_abi_version": (C.c_int, []),
     "tt_last_error": (C.c_char_p, []),
+    "tt_profile_enable": (C.c_int, [C.c_char_p, _i32]),
+    "tt_profile_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_float), _i32, C.POINTER(_i32)]),
     "tt_fill_uniform_f32": (C.c_int, [_p, _i64, _u64, _u64, _i64, _f, _f, _p]),
     "tt_fill_ids_i64": (C.c_int, [_p, _i64, _u64, _u64, _i64, _i64, _i32, _p]),
     "tt_embedding_gather_f32": (C.c_int, [_p, _i64, _i32, _p, _i64, _p, _p, _p]),
@@ -80,6 +82,9 @@ def load() -> C.CDLL:
     with _lock:
         if _lib is not None:
             return _lib
+        # The library and torch must share ONE HIP runtime (tensors and streams come from torch's).
+        # Both link `libamdhip64.so.7`; the first one loaded wins, so torch goes first.
+        import torch  # noqa: F401
         if not LIB_PATH.exists():
             raise TwoTowerHipError(
                 f"{LIB_PATH} not found: the HIP extension is not built. Run "
@@ -105,3 +110,16 @@ def check(rc: int, what: str) -> None:
         msg = load().tt_last_error().decode("utf-8", "replace")
         exc = {TT_ERR_INVALID_ARG: ValueError, TT_ERR_UNSUPPORTED: NotImplementedError}.get(rc, TwoTowerHipError)
         raise exc(f"{what} failed (code {rc}): {msg}")
+
+
+def profile_enable(tags: str = "", capacity: int = 4096) -> None:
+    """Enable the built-in hipEvent kernel timing for the comma-separated tags ("" disables)."""
+    check(load().tt_profile_enable(tags.encode(), capacity), "tt_profile_enable")
+
+
+def profile_read(tag: str, capacity: int = 4096) -> tuple[list[float], int]:
+    """(durations in ms of the recorded launches, launches seen); synchronises and clears the tag."""
+    buf = (C.c_float * capacity)()
+    n = _i32(0)
+    check(load().tt_profile_read(tag.encode(), buf, capacity, C.byref(n)), "tt_profile_read")
+    return list(buf[:min(n.value, capacity)]), n.value

@@ -1,5 +1,9 @@
 // tt_abi_version / tt_last_error and the error plumbing shared by every entry point.
 #include "common.h"
+#include <mutex>
+#include <string>
+#include <vector>
+#include <cstring>
 
 namespace tt {
 static thread_local char g_err[512] = "";
@@ -11,7 +15,84 @@ int fail(int code, const char* fmt, ...) {
   va_end(ap);
   return code;
 }
+
+// ---- kernel timing --------------------------------------------------------------------------
+bool g_prof_on = false;
+namespace {
+struct ProfTag {
+  std::string name;
+  std::vector<hipEvent_t> ev;   // 2 per launch: begin, end
+  int used = 0;                 // launches recorded
+  int seen = 0;                 // launches seen (may exceed capacity)
+};
+std::mutex g_prof_mu;
+std::vector<ProfTag> g_prof_tags;
+ProfTag* find_tag(const char* tag) {
+  for (auto& t : g_prof_tags)
+    if (t.name == tag) return &t;
+  return nullptr;
+}
+}  // namespace
+
+void prof_record(const char* tag, hipStream_t stream, bool end) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  ProfTag* t = find_tag(tag);
+  if (t == nullptr) return;
+  if (!end) {
+    if (2 * (t->used + 1) > (int)t->ev.size()) { ++t->seen; return; }
+    (void)hipEventRecord(t->ev[2 * t->used], stream);
+  } else {
+    if (t->seen > t->used) return;            // begin was dropped (capacity)
+    (void)hipEventRecord(t->ev[2 * t->used + 1], stream);
+    ++t->used;
+    ++t->seen;
+  }
+}
 }  // namespace tt
+
+extern "C" int tt_profile_enable(const char* tags_csv, int32_t capacity_per_tag) {
+  std::lock_guard<std::mutex> lk(tt::g_prof_mu);
+  for (auto& t : tt::g_prof_tags)
+    for (auto e : t.ev) (void)hipEventDestroy(e);
+  tt::g_prof_tags.clear();
+  tt::g_prof_on = false;
+  if (tags_csv == nullptr || tags_csv[0] == 0) return TT_OK;
+  if (capacity_per_tag <= 0) return tt::fail(TT_ERR_INVALID_ARG, "tt_profile_enable: capacity must be positive");
+  std::string s(tags_csv);
+  size_t pos = 0;
+  while (pos <= s.size()) {
+    size_t q = s.find(',', pos);
+    if (q == std::string::npos) q = s.size();
+    if (q > pos) {
+      tt::ProfTag t;
+      t.name = s.substr(pos, q - pos);
+      t.ev.resize(2 * (size_t)capacity_per_tag);
+      for (auto& e : t.ev)
+        if (hipEventCreate(&e) != hipSuccess) return tt::fail(TT_ERR_LAUNCH, "tt_profile_enable: hipEventCreate failed");
+      tt::g_prof_tags.push_back(std::move(t));
+    }
+    pos = q + 1;
+  }
+  tt::g_prof_on = !tt::g_prof_tags.empty();
+  return TT_OK;
+}
+
+extern "C" int tt_profile_read(const char* tag, float* ms, int32_t cap, int32_t* count) {
+  if (tag == nullptr || count == nullptr || (cap > 0 && ms == nullptr))
+    return tt::fail(TT_ERR_INVALID_ARG, "tt_profile_read: null pointer");
+  std::lock_guard<std::mutex> lk(tt::g_prof_mu);
+  tt::ProfTag* t = tt::find_tag(tag);
+  if (t == nullptr) return tt::fail(TT_ERR_INVALID_ARG, "tt_profile_read: tag '%s' is not enabled", tag);
+  *count = t->seen;
+  for (int i = 0; i < t->used && i < cap; ++i) {
+    if (hipEventSynchronize(t->ev[2 * i + 1]) != hipSuccess ||
+        hipEventElapsedTime(&ms[i], t->ev[2 * i], t->ev[2 * i + 1]) != hipSuccess)
+      return tt::fail(TT_ERR_LAUNCH, "tt_profile_read: event query failed for '%s'", tag);
+  }
+  t->used = 0;
+  t->seen = 0;
+  return TT_OK;
+}
 
 extern "C" int tt_abi_version(void) { return TT_ABI_VERSION; }
 extern "C" const char* tt_last_error(void) { return tt::err_buf(); }

@@ -20,6 +20,16 @@ inline int check_launch(const char* what) {
   return TT_OK;
 }
 
+// built-in kernel timing (tt_profile_enable / tt_profile_read); see capi_common.hip
+extern bool g_prof_on;
+void prof_record(const char* tag, hipStream_t stream, bool end);
+struct ProfScope {
+  const char* tag;
+  hipStream_t stream;
+  ProfScope(const char* t, hipStream_t s) : tag(t), stream(s) { if (g_prof_on) prof_record(tag, stream, false); }
+  ~ProfScope() { if (g_prof_on) prof_record(tag, stream, true); }
+};
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 #define TT_REQUIRE(cond, ...) do { if (!(cond)) return ::tt::fail(TT_ERR_INVALID_ARG, __VA_ARGS__); } while (0)

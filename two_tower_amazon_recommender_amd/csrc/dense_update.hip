@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void dense_update_kernel(SegTable tbl, int app
     } else {
       const float acc = __fadd_rn(s.accum[i], __fmul_rn(g, g));
       s.accum[i] = acc;
-      w = __fsub_rn(w, __fdiv_rn(__fmul_rn(lr, g), __fsqrt_rn(__fadd_rn(acc, eps))));
+      w = __fsub_rn(w, __fdiv_rn(__fmul_rn(lr, g), sqrtf(__fadd_rn(acc, eps))));
     }
     s.param[i] = w;
   }
@@ -52,6 +52,7 @@ extern "C" int tt_dense_update_f32(const tt_dense_seg* segs, int32_t n_segs, int
   }
   int64_t bx = (max_count + 255) / 256;
   if (bx > 512) bx = 512;
+  tt::ProfScope prof("dense_update", tt::as_stream(stream));
   if (opt == TT_OPT_SGD)
     hipLaunchKernelGGL(dense_update_kernel<TT_OPT_SGD>, dim3((unsigned)bx, (unsigned)n_segs), dim3(256), 0,
                        tt::as_stream(stream), tbl, apply, lr, eps);

@@ -62,6 +62,7 @@ int launch(const GatherArgs& a, int n_tables, int32_t dim, int64_t n_ids, int32_
   const int64_t rows_per_block = (int64_t)groups * UNROLL;
   const int64_t blocks = (n_ids + rows_per_block - 1) / rows_per_block;
   TT_REQUIRE(blocks <= 0x7fffffff, "%s: n_ids too large", what);
+  tt::ProfScope prof("gather", stream);
   hipLaunchKernelGGL(gather_kernel<UNROLL>, dim3((unsigned)blocks, n_tables), dim3(256), 0, stream, a, dim4, lpr_log2,
                      n_ids, oob_flag);
   return tt::check_launch(what);

@@ -162,9 +162,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 }
 
 template <bool A_KC, bool B_KC, bool COLSUM>
-int launch(const GemmArgs& a, int splits, hipStream_t stream, const char* what) {
+int launch(const GemmArgs& a, int splits, hipStream_t stream, const char* what, const char* tag) {
   const int64_t gm = (a.M + BM - 1) / BM, gn = (a.N + BN - 1) / BN;
   TT_REQUIRE(gm <= 0x7fffffff && gn <= 65535 && splits <= 65535, "%s: grid too large", what);
+  tt::ProfScope prof(tag, stream);
   hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, COLSUM>), dim3((unsigned)gm, (unsigned)gn, (unsigned)splits), dim3(256), 0,
                      stream, a);
   return tt::check_launch(what);
@@ -181,7 +182,7 @@ extern "C" int tt_dense_fwd_f32(const float* x, const float* w, const float* b, 
   GemmArgs a{};
   a.A = x; a.B = w; a.C = y; a.M = m; a.N = n; a.K = k; a.lda = k; a.ldb = n; a.ldc = n;
   a.bias = b; a.relu = relu; a.k_per_split = (k + BK - 1) / BK * BK;
-  return launch<true, false, false>(a, 1, tt::as_stream(stream), "tt_dense_fwd_f32");
+  return launch<true, false, false>(a, 1, tt::as_stream(stream), "tt_dense_fwd_f32", "dense_fwd");
 }
 
 extern "C" int32_t tt_dense_bwd_num_slabs(int64_t m) {
@@ -206,7 +207,7 @@ extern "C" int tt_dense_bwd_f32(const float* x, const float* w, const float* dz,
     GemmArgs a{};
     a.A = dz; a.B = w; a.C = dx; a.M = m; a.N = k; a.K = n; a.lda = n; a.ldb = n; a.ldc = k;
     a.mask_src = dx_relu_src; a.k_per_split = (n + BK - 1) / BK * BK;
-    if ((rc = launch<true, true, false>(a, 1, stream, "tt_dense_bwd_f32(dx)")) != TT_OK) return rc;
+    if ((rc = launch<true, true, false>(a, 1, stream, "tt_dense_bwd_f32(dx)", "dense_bwd_dx")) != TT_OK) return rc;
   }
   {
     // dw[k][n] = sum_b x[b][k] * dz[b][n], split over the batch into slabs; db rides along
@@ -216,7 +217,7 @@ extern "C" int tt_dense_bwd_f32(const float* x, const float* w, const float* dz,
     a.k_per_split = ((m + splits - 1) / splits + BK - 1) / BK * BK;
     a.slab_stride = (int64_t)k * n;
     a.db_slabs = db_slabs;
-    if ((rc = launch<false, false, true>(a, splits, stream, "tt_dense_bwd_f32(dw)")) != TT_OK) return rc;
+    if ((rc = launch<false, false, true>(a, splits, stream, "tt_dense_bwd_f32(dw)", "dense_bwd_dw")) != TT_OK) return rc;
   }
   return TT_OK;
 }

@@ -438,6 +438,7 @@ int launch_score(const ScoreArgs& a, bool has_ids, hipStream_t stream) {
       raised = true;
     }
   }
+  tt::ProfScope prof(MODE == MODE_FWD ? "score_fwd" : "score_bwd", stream);
   if (has_ids)
     hipLaunchKernelGGL((score_kernel<D, MODE, true>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
   else
@@ -505,6 +506,7 @@ extern "C" int tt_retrieval_fwd_f32(const float* q, const float* c, int64_t nq, 
   a.part_l = reinterpret_cast<float*>(ws + w.off_pl);
   a.pos2 = reinterpret_cast<float*>(ws + w.off_pos);
   if ((rc = dispatch_score<MODE_FWD>(dim, a, cand_ids != nullptr, stream)) != TT_OK) return rc;
+  tt::ProfScope prof("score_aux", stream);
   hipLaunchKernelGGL(fwd_combine_kernel, dim3(1), dim3(1024), 0, stream, a.part_m, a.part_l, a.pos2, sample_weight, nq,
                      a.nsplit, lse, per_row, loss);
   return tt::check_launch("fwd_combine");
@@ -549,8 +551,11 @@ extern "C" int tt_retrieval_bwd_f32(const float* q, const float* c, int64_t nq, 
     if ((rc = dispatch_score<MODE_BWD>(dim, a, cand_ids != nullptr, stream)) != TT_OK) return rc;
     const int64_t n4 = nq * dim / 4;
     const int64_t blocks = (n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
-                       reinterpret_cast<const f32x4*>(slab), reinterpret_cast<f32x4*>(dq), n4, a.nsplit);
+    {
+      tt::ProfScope prof("score_aux", stream);
+      hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
+                         reinterpret_cast<const f32x4*>(slab), reinterpret_cast<f32x4*>(dq), n4, a.nsplit);
+    }
     if ((rc = tt::check_launch("reduce_slabs(dq)")) != TT_OK) return rc;
   }
   // dc: stationary c, stream q.  Candidates beyond nq + diag_offset have no positive: diag never matches.
@@ -567,8 +572,11 @@ extern "C" int tt_retrieval_bwd_f32(const float* q, const float* c, int64_t nq, 
     if ((rc = dispatch_score<MODE_BWD>(dim, a, cand_ids != nullptr, stream)) != TT_OK) return rc;
     const int64_t n4 = nc * dim / 4;
     const int64_t blocks = (n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
-                       reinterpret_cast<const f32x4*>(slab), reinterpret_cast<f32x4*>(dc), n4, a.nsplit);
+    {
+      tt::ProfScope prof("score_aux", stream);
+      hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
+                         reinterpret_cast<const f32x4*>(slab), reinterpret_cast<f32x4*>(dc), n4, a.nsplit);
+    }
     if ((rc = tt::check_launch("reduce_slabs(dc)")) != TT_OK) return rc;
   }
   return TT_OK;

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void sparse_apply_kernel(ApplyArgs a, int dim4
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         acc[e] = __fadd_rn(acc[e], __fmul_rn(g[e], g[e]));
-        const float den = __fsqrt_rn(__fadd_rn(acc[e], eps));
+        const float den = sqrtf(__fadd_rn(acc[e], eps));
         w[e] = __fsub_rn(w[e], __fdiv_rn(__fmul_rn(lr, g[e]), den));
       }
       accum[id * dim4 + c] = acc;
@@ -98,6 +98,7 @@ int launch_apply(int opt, const ApplyArgs& a, int n_tables, int32_t dim, int64_t
   const int groups = 256 >> lpr_log2;
   const int64_t blocks = (n_ids + groups - 1) / groups;
   TT_REQUIRE(blocks <= 0x7fffffff, "%s: n_ids too large", what);
+  tt::ProfScope prof("sparse_apply", stream);
   if (opt == TT_OPT_SGD)
     hipLaunchKernelGGL(sparse_apply_kernel<TT_OPT_SGD>, dim3((unsigned)blocks, n_tables), dim3(256), 0, stream, a, dim4,
                        lpr_log2, n_ids, lr, eps);
@@ -140,6 +141,7 @@ extern "C" int tt_sparse_plan(const int64_t* ids, int64_t n_ids, int64_t num_row
   // somewhere in the order, possibly splitting into several runs — harmless, because the apply kernel
   // skips every out-of-range id (the gather has already flagged them).
   const int bits = id_bits(num_rows);
+  tt::ProfScope prof("sparse_plan", tt::as_stream(stream));
   hipError_t e = rocprim::radix_sort_pairs(workspace, temp, ids, sorted_ids, rocprim::counting_iterator<int32_t>(0), order,
                                            (size_t)n_ids, 0u, (unsigned)bits, tt::as_stream(stream), false);
   if (e != hipSuccess) return tt::fail(TT_ERR_LAUNCH, "tt_sparse_plan: rocprim radix sort: %s", hipGetErrorString(e));

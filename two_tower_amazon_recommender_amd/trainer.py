@@ -1,0 +1,217 @@
+"""Single-GPU train step of the two-tower retrieval model: the whole hot path on HIP kernels.
+
+This is the explicit (no autograd) engine that ``train.py`` and ``bench.py`` drive:
+
+    ids ──gather2──► tower fwd (MFMA GEMMs) ──► fused scorer + softmax loss (fwd, bwd)
+        ──► tower bwd ──► dense update (1 launch) ──► sparse SGD/Adagrad on both tables (1 launch)
+
+All buffers are allocated once for a fixed batch size; ``step`` enqueues ~25 kernels on the
+current stream and never synchronises (it can be captured in a HIP graph).
+
+Reference anchors: hyper-parameters are the ``model:`` block of
+``/root/reference/configs/data_config.yaml:54-71`` (embedding_dim, *_tower_dims, l2_regularization,
+training.learning_rate, retrieval.temperature, candidate_sampling "in_batch"); inputs are the int64
+``user_idx`` / ``item_idx`` columns of ``prepare_training_data.py:209-210``.  The reference never
+implemented the step itself (``src/training/__init__.py:1``).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import torch
+
+from . import ops
+
+# tensor-id convention of the synthetic initialiser (must match oracle/synth.py, which restates it
+# for the tests; the product does not import the oracle)
+TID_USER_TABLE, TID_ITEM_TABLE, TID_USER_IDS, TID_ITEM_IDS = 1, 2, 3, 4
+TID_DENSE_BASE = 16
+
+
+@dataclass
+class TwoTowerConfig:
+    n_users: int
+    n_items: int
+    embedding_dim: int = 128                       # configs/data_config.yaml:55
+    tower_dims: list = field(default_factory=lambda: [512, 256, 128])   # :56-57 (both towers)
+    temperature: float = 0.1                       # :70
+    l2_regularization: float = 1e-6                # :59
+    learning_rate: float = 0.001                   # :63
+    optimizer: str = "sgd"                         # unspecified by the reference; north_star: SGD / Adagrad
+    adagrad_initial_accumulator: float = 0.1       # Keras 2.15 default
+    adagrad_epsilon: float = 1e-7                  # Keras 2.15 default
+    batch_size: int = 1024                         # :62
+    dropout_rate: float = 0.0                      # :58 is 0.1; parity/bench runs use 0
+
+    def validate(self):
+        if self.optimizer not in ("sgd", "adagrad"):
+            raise ValueError(f"optimizer must be 'sgd' or 'adagrad', got {self.optimizer!r}")
+        if self.embedding_dim % 4 or any(d % 4 for d in self.tower_dims):
+            raise ValueError("embedding_dim and tower dims must be multiples of 4")
+        if self.tower_dims[-1] not in (32, 64, 128, 256):
+            raise ValueError("the last tower dim (scorer dim) must be one of 32, 64, 128, 256")
+        if self.dropout_rate != 0.0:
+            raise NotImplementedError("dropout_rate > 0 is not implemented in the HIP path yet (SURVEY.md §7: "
+                                      "parity runs use rate 0)")
+        if self.temperature <= 0:
+            raise ValueError("temperature must be positive")
+
+
+class Tower:
+    """Dense stack: ReLU on all but the last layer (Keras Dense)."""
+
+    def __init__(self, cfg: TwoTowerConfig, flat: torch.Tensor, flat_acc, offset: int, dev):
+        self.dims = [cfg.embedding_dim] + list(cfg.tower_dims)
+        self.n_layers = len(cfg.tower_dims)
+        b = cfg.batch_size
+        self.w, self.b, self.w_acc, self.b_acc = [], [], [], []
+        for l in range(self.n_layers):
+            k, n = self.dims[l], self.dims[l + 1]
+            self.w.append(flat[offset:offset + k * n].view(k, n))
+            self.w_acc.append(None if flat_acc is None else flat_acc[offset:offset + k * n].view(k, n))
+            offset += k * n
+            self.b.append(flat[offset:offset + n])
+            self.b_acc.append(None if flat_acc is None else flat_acc[offset:offset + n])
+            offset += n
+        self.end_offset = offset
+        ns = ops.dense_bwd_num_slabs(b)
+        self.n_slabs = ns
+        self.acts = [torch.empty(b, self.dims[0], device=dev)] + \
+                    [torch.empty(b, self.dims[l + 1], device=dev) for l in range(self.n_layers)]
+        # dz[l]: gradient w.r.t. the pre-activation of layer l; dz[n_layers-1] is the scorer's dq/dc
+        self.dz = [torch.empty(b, self.dims[l + 1], device=dev) for l in range(self.n_layers)]
+        self.demb = torch.empty(b, self.dims[0], device=dev)
+        self.dw_slabs = [torch.empty(ns, self.dims[l], self.dims[l + 1], device=dev) for l in range(self.n_layers)]
+        self.db_slabs = [torch.empty(ns, self.dims[l + 1], device=dev) for l in range(self.n_layers)]
+
+    @staticmethod
+    def param_count(cfg: TwoTowerConfig) -> int:
+        dims = [cfg.embedding_dim] + list(cfg.tower_dims)
+        return sum(dims[l] * dims[l + 1] + dims[l + 1] for l in range(len(cfg.tower_dims)))
+
+    def forward(self):
+        for l in range(self.n_layers):
+            ops.dense_fwd(self.acts[l], self.w[l], self.b[l], relu=(l < self.n_layers - 1), out=self.acts[l + 1])
+        return self.acts[-1]
+
+    def backward(self):
+        """Consumes dz[-1]; leaves demb and the dw/db slabs."""
+        for l in range(self.n_layers - 1, -1, -1):
+            dx = self.dz[l - 1] if l > 0 else self.demb
+            mask_src = self.acts[l] if l > 0 else None       # acts[l] = ReLU output of layer l-1
+            ops.dense_bwd(self.acts[l], self.w[l], self.dz[l], dx, mask_src, self.dw_slabs[l], self.db_slabs[l])
+
+    def segments(self, l2: float, grad_flat=None, grad_offset: int = 0):
+        segs = []
+        off = grad_offset
+        for l in range(self.n_layers):
+            for p, acc, slabs, reg in ((self.w[l], self.w_acc[l], self.dw_slabs[l], l2),
+                                       (self.b[l], self.b_acc[l], self.db_slabs[l], 0.0)):
+                gout = None if grad_flat is None else grad_flat[off:off + p.numel()]
+                segs.append(ops.make_dense_seg(p, acc, slabs, self.n_slabs, reg, gout))
+                off += p.numel()
+        return segs
+
+
+class TwoTowerTrainer:
+    def __init__(self, cfg: TwoTowerConfig, device="cuda:0", seed: int | None = None):
+        cfg.validate()
+        self.cfg = cfg
+        self.dev = dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("TwoTowerTrainer needs a CUDA/HIP device: there is no CPU fallback")
+        b, d = cfg.batch_size, cfg.embedding_dim
+        adagrad = cfg.optimizer == "adagrad"
+        self.user_table = torch.empty(cfg.n_users, d, device=dev)
+        self.item_table = torch.empty(cfg.n_items, d, device=dev)
+        self.user_accum = torch.full_like(self.user_table, cfg.adagrad_initial_accumulator) if adagrad else None
+        self.item_accum = torch.full_like(self.item_table, cfg.adagrad_initial_accumulator) if adagrad else None
+        n_tower = Tower.param_count(cfg)
+        self.dense_flat = torch.zeros(2 * n_tower, device=dev)
+        self.dense_accum = torch.full_like(self.dense_flat, cfg.adagrad_initial_accumulator) if adagrad else None
+        self.dense_grad = torch.empty_like(self.dense_flat)        # summed gradients (multi-GPU all-reduce bucket)
+        self.user_tower = Tower(cfg, self.dense_flat, self.dense_accum, 0, dev)
+        self.item_tower = Tower(cfg, self.dense_flat, self.dense_accum, n_tower, dev)
+        sd = cfg.tower_dims[-1]
+        self.ws = torch.empty(ops.retrieval_workspace_bytes(b, b, sd), dtype=torch.uint8, device=dev)
+        self.lse = torch.empty(b, device=dev)
+        self.per_row = torch.empty(b, device=dev)
+        self.loss = torch.empty(1, device=dev)
+        self.oob = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.user_plan = ops.SparsePlan(b, dev)
+        self.item_plan = ops.SparsePlan(b, dev)
+        self._segs = self.user_tower.segments(cfg.l2_regularization) + self.item_tower.segments(cfg.l2_regularization)
+        if seed is not None:
+            self.init_synthetic(seed)
+
+    # ------------------------------------------------------------------ init
+    def init_synthetic(self, seed: int):
+        """Keras defaults (Embedding U(-0.05,0.05), Dense Glorot-uniform, zero bias) from the counter-based
+        generator: identical, bit for bit, to oracle.two_tower.synthetic_state(seed, ...)."""
+        ops.fill_uniform_(self.user_table, seed, TID_USER_TABLE, -0.05, 0.1)
+        ops.fill_uniform_(self.item_table, seed, TID_ITEM_TABLE, -0.05, 0.1)
+        self.dense_flat.zero_()
+        for t, tower in enumerate((self.user_tower, self.item_tower)):
+            for l, w in enumerate(tower.w):
+                lim = torch.tensor(math.sqrt(6.0 / (w.shape[0] + w.shape[1])), dtype=torch.float64).to(torch.float32)
+                lim32 = lim.item()
+                scale32 = (lim + lim).item()
+                ops.fill_uniform_(w, seed, TID_DENSE_BASE + 2 * l + t, -lim32, scale32)
+        if self.cfg.optimizer == "adagrad":
+            for a in (self.user_accum, self.item_accum, self.dense_accum):
+                a.fill_(self.cfg.adagrad_initial_accumulator)
+
+    def synthetic_batch(self, seed: int, step: int, variant: str = "U", out=None):
+        b = self.cfg.batch_size
+        if out is None:
+            out = (torch.empty(b, dtype=torch.int64, device=self.dev), torch.empty(b, dtype=torch.int64, device=self.dev))
+        ops.fill_ids_(out[0], seed, TID_USER_IDS, self.cfg.n_users, variant, start=step * b)
+        ops.fill_ids_(out[1], seed, TID_ITEM_IDS, self.cfg.n_items, variant, start=step * b)
+        return out
+
+    # ------------------------------------------------------------------ the hot path
+    def forward_backward(self, user_ids: torch.Tensor, item_ids: torch.Tensor, sample_weight=None,
+                         candidate_sampling_probability=None, candidate_ids=None):
+        cfg, ut, it = self.cfg, self.user_tower, self.item_tower
+        ops.embedding_gather2(self.user_table, user_ids, ut.acts[0], self.item_table, item_ids, it.acts[0], self.oob)
+        q = ut.forward()
+        c = it.forward()
+        kw = dict(sample_weight=sample_weight, cand_prob=candidate_sampling_probability, cand_ids=candidate_ids)
+        ops.retrieval_fwd(q, c, 1.0 / cfg.temperature, self.ws, self.lse, self.per_row, self.loss, **kw)
+        ops.retrieval_bwd(q, c, 1.0 / cfg.temperature, self.ws, self.lse, ut.dz[-1], it.dz[-1], **kw)
+        ut.backward()
+        it.backward()
+        return self.loss
+
+    def apply_gradients(self):
+        cfg = self.cfg
+        ops.dense_update_(self._segs, cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon)
+        ops.sparse_update2_(cfg.optimizer, self.user_table, self.user_accum, self.user_tower.demb, self.user_plan,
+                            self.item_table, self.item_accum, self.item_tower.demb, self.item_plan,
+                            cfg.learning_rate, cfg.adagrad_epsilon)
+
+    def step(self, user_ids: torch.Tensor, item_ids: torch.Tensor, **loss_kw) -> torch.Tensor:
+        """One train step; returns the (device, unsynchronised) retrieval loss (SUM over the batch)."""
+        if user_ids.numel() != self.cfg.batch_size or item_ids.numel() != self.cfg.batch_size:
+            raise ValueError(f"batch must have {self.cfg.batch_size} pairs")
+        # the sort plans depend on the ids only
+        self.user_plan.run(user_ids, self.cfg.n_users)
+        self.item_plan.run(item_ids, self.cfg.n_items)
+        loss = self.forward_backward(user_ids, item_ids, **loss_kw)
+        self.apply_gradients()
+        return loss
+
+    def check_ids(self):
+        """Host check of the out-of-range flag (TF's CPU gather raises InvalidArgumentError); synchronises."""
+        if int(self.oob.item()) != 0:
+            self.oob.zero_()
+            raise IndexError("embedding id out of range in a previous step")
+
+    def l2_penalty(self) -> torch.Tensor:
+        """l2 * sum(W^2) over the Dense kernels — reporting only (the gradient term is fused in the update)."""
+        tot = torch.zeros((), device=self.dev, dtype=torch.float64)
+        for tower in (self.user_tower, self.item_tower):
+            for w in tower.w:
+                tot += (w.double() ** 2).sum()
+        return self.cfg.l2_regularization * tot
