@@ -48,6 +48,19 @@ def parse():
     return ap.parse_args()
 
 
+def cpu_share() -> int:
+    """Host threads this job may use: affinity, capped by the cgroup quota and by the GPU box's per-GPU
+    CPU share (16)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
 def mean(xs):
     return sum(xs) / max(len(xs), 1)
 
@@ -55,7 +68,7 @@ def mean(xs):
 def cpu_baseline(trainer, cfg, seed, args, batch):
     """torch-CPU restatement on the same model state and batches (bounded sample)."""
     from oracle.torch_cpu import TorchCpuTwoTower, time_cpu_steps      # bench's cpu_baseline leg only
-    cores = os.cpu_count() or 1
+    cores = cpu_share()
     torch.set_num_threads(cores)
     ut, it = trainer.user_table.cpu(), trainer.item_table.cpu()
     uw = [w.cpu().clone() for w in trainer.user_tower.w]; ub = [b.cpu().clone() for b in trainer.user_tower.b]

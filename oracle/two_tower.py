@@ -42,10 +42,12 @@ def dense_fwd(x, w, b, relu: bool):
     return np.maximum(y, 0) if relu else y
 
 
-def dense_bwd(x, w, y, dy, relu: bool):
-    """Returns dx, dw, db for y = act(x@w+b)."""
+def dense_bwd(x, w, y, dy, relu: bool, mask=None):
+    """Returns dx, dw, db for y = act(x@w+b).  ``mask`` overrides the ReLU derivative (y > 0): the
+    derivative is discontinuous at 0, so a test that compares gradients element-wise passes the mask
+    the device actually used (pre-activations within rounding of 0 may differ in sign between f32 and f64)."""
     if relu:
-        dy = dy * (y > 0)
+        dy = dy * ((y > 0) if mask is None else mask)
     return dy @ w.T, x.T @ dy, dy.sum(axis=0)
 
 
@@ -58,11 +60,13 @@ def tower_fwd(x, weights, biases):
     return acts
 
 
-def tower_bwd(acts, weights, dy):
+def tower_bwd(acts, weights, dy, masks=None):
+    """masks: optional list (one per hidden layer) of boolean arrays replacing (acts[l+1] > 0)."""
     n = len(weights)
     dws, dbs = [None] * n, [None] * n
     for l in range(n - 1, -1, -1):
-        dy, dws[l], dbs[l] = dense_bwd(acts[l], weights[l], acts[l + 1], dy, relu=(l < n - 1))
+        m = None if (masks is None or l >= n - 1) else masks[l]
+        dy, dws[l], dbs[l] = dense_bwd(acts[l], weights[l], acts[l + 1], dy, relu=(l < n - 1), mask=m)
     return dy, dws, dbs
 
 
@@ -201,7 +205,7 @@ def init_adagrad_state(state: ModelState, initial_accumulator_value=0.1):
 
 def forward_backward(state: ModelState, user_ids, item_ids, temperature=0.1,
                      l2=0.0, sample_weight=None, candidate_sampling_probability=None,
-                     candidate_ids=None, remove_accidental_hits=False):
+                     candidate_ids=None, remove_accidental_hits=False, relu_masks=None):
     """One forward+backward.  total_loss = retrieval loss (SUM) + l2 * sum(W**2)
     over Dense kernels (Keras ``kernel_regularizer=l2``; biases unregularised)."""
     ue = embedding_gather(state.user_table, user_ids)
@@ -216,8 +220,9 @@ def forward_backward(state: ModelState, user_ids, item_ids, temperature=0.1,
               dtype=dt)
     loss, per_row, lse = retrieval_loss(q, c, **kw)
     dq, dc = retrieval_grad(q, c, **kw)
-    due, udw, udb = tower_bwd(ua, state.user_tower.weights, dq)
-    die, idw, idb = tower_bwd(ia, state.item_tower.weights, dc)
+    um, im = (None, None) if relu_masks is None else relu_masks
+    due, udw, udb = tower_bwd(ua, state.user_tower.weights, dq, um)
+    die, idw, idb = tower_bwd(ia, state.item_tower.weights, dc, im)
     reg = dt.type(0)
     if l2:
         for tw, dws in ((state.user_tower, udw), (state.item_tower, idw)):

@@ -47,7 +47,11 @@ def test_train_steps_match_oracle(dev, name, shape, opt, variant):
         du, di = tr.synthetic_batch(seed, step, variant)
         assert np.array_equal(du.cpu().numpy(), uid) and np.array_equal(di.cpu().numpy(), iid)   # bit-exact indices
         loss = tr.step(du, di).item()
-        r = tt.train_step(ref, uid, iid, lr=0.001, optimizer=opt, temperature=0.1, l2=1e-6)
+        # ReLU's derivative is discontinuous at 0: hand the oracle the masks the device used (a hidden
+        # pre-activation within f32 rounding of 0 may have the other sign in f64); everything else is f64.
+        masks = tuple([(t.acts[l + 1] > 0).cpu().numpy() for l in range(len(tower_dims) - 1)]
+                      for t in (tr.user_tower, tr.item_tower))
+        r = tt.train_step(ref, uid, iid, lr=0.001, optimizer=opt, temperature=0.1, l2=1e-6, relu_masks=masks)
         tr.check_ids()
         # loss: |d|/B <= 1e-4 and relative <= 1e-4
         assert abs(loss - r["loss"]) / batch <= 1e-4 and abs(loss - r["loss"]) <= 1e-4 * abs(r["loss"]), (step, loss, r["loss"])
@@ -61,8 +65,10 @@ def test_train_steps_match_oracle(dev, name, shape, opt, variant):
         assert np.abs(g - want).max() <= 2e-6, np.abs(g - want).max()
     for tower, rt in ((tr.user_tower, ref.user_tower), (tr.item_tower, ref.item_tower)):
         for l in range(len(tower_dims)):
-            assert np.abs(tower.w[l].cpu().numpy() - rt.weights[l]).max() <= 2e-6
-            assert np.abs(tower.b[l].cpu().numpy() - rt.biases[l]).max() <= 2e-6
+            # 3 updates of size lr*|g| ~ 1e-3 * O(1..30): a wrong gradient shows as >= 1e-4; f32 sums over
+            # 8192 rows leave ~3e-6 (measured)
+            assert np.abs(tower.w[l].cpu().numpy() - rt.weights[l]).max() <= 1e-5
+            assert np.abs(tower.b[l].cpu().numpy() - rt.biases[l]).max() <= 1e-5
     if opt == "adagrad":
         assert np.abs(tr.user_accum.cpu().numpy() - ref.user_accum).max() <= 1e-4 * ref.user_accum.max()
 
