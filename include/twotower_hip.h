@@ -65,6 +65,10 @@ int tt_profile_read(const char* tag, float* ms, int32_t cap, int32_t* count);
  *   value(i) = fl32(fl32(u(start+i) * scale) + lo),  u in [0,1) with 24 bits.          */
 int tt_fill_uniform_f32(float* dst, int64_t n, uint64_t seed, uint64_t tensor_id,
                         int64_t start, float lo, float scale, tt_stream_t stream);
+/* Rows row_start, row_start+row_stride, ... of a [*, dim] tensor whose flat element (r, d) uses counter
+ * r*dim + d: the shard of a row-sharded table (owner = row % world) without materialising the whole. */
+int tt_fill_uniform_rows_f32(float* dst, int64_t n_rows, int32_t dim, int64_t row_start, int64_t row_stride,
+                             uint64_t seed, uint64_t tensor_id, float lo, float scale, tt_stream_t stream);
 /* ids in [0,num_rows): variant TT_IDS_UNIFORM or TT_IDS_POWERLAW (floor(N*u^4)).        */
 int tt_fill_ids_i64(int64_t* dst, int64_t n, uint64_t seed, uint64_t tensor_id,
                     int64_t start, int64_t num_rows, int32_t variant, tt_stream_t stream);
@@ -73,7 +77,8 @@ int tt_fill_ids_i64(int64_t* dst, int64_t n, uint64_t seed, uint64_t tensor_id,
  * a1 — embedding lookup (Keras Embedding / tf.gather; configs/data_config.yaml:55).
  *   out[b, :] = table[ids[b], :]          table [num_rows, dim] f32 row-major, dim % 4 == 0
  * Ids outside [0,num_rows) produce a zero row and set *oob_flag (device int32, may be
- * NULL) to 1 — the caller turns that into the error TF's CPU gather raises.
+ * NULL) to 1 — the caller turns that into the error TF's CPU gather raises.  The id -1 is a
+ * PADDING slot (fixed-capacity all-to-all buffers of the row-sharded path): zero row, no flag.
  * The `2` form gathers the user and the item table in ONE launch.                        */
 int tt_embedding_gather_f32(const float* table, int64_t num_rows, int32_t dim,
                             const int64_t* ids, int64_t n_ids, float* out,

@@ -1,0 +1,167 @@
+"""world_size-2 (and 3) gloo tests of the row-sharded embedding exchange on CPU (the N>1 path of
+SURVEY.md §8e).  The exchange code under test is the product's (device-agnostic torch +
+torch.distributed); the three row kernels are replaced by a NumPy-oracle backend DEFINED HERE (the
+product's only backend is HIP).  Checks: looked-up rows, post-step shards (SGD and Adagrad, duplicates
+inside and across ranks), padding, capacity overflow and out-of-range reporting."""
+import os
+import socket
+import sys
+import pathlib
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = pathlib.Path(__file__).resolve().parents[1]
+
+
+class OracleRowBackend:
+    """Test-only stand-in for HipRowBackend built from the oracle's row functions."""
+
+    def gather(self, table, ids, out, oob_flag):
+        t, i = table.numpy(), ids.numpy()
+        ok = (i >= 0) & (i < t.shape[0])
+        res = np.zeros((len(i), t.shape[1]), dtype=np.float32)
+        res[ok] = t[i[ok]]
+        out.copy_(torch.from_numpy(res))
+        if oob_flag is not None and ((~ok) & (i != -1)).any():
+            oob_flag.fill_(1)
+
+    def segment_sum(self, out_zeroed, grads, sorted_flat, order):
+        o = out_zeroed.numpy()
+        g = grads.numpy()
+        for f, p in zip(sorted_flat.numpy(), order.numpy()):      # sorted: ascending position inside a run
+            o[f] = o[f] + g[p]
+
+    def apply(self, opt, table, accum, ids, grads, lr, eps):
+        from oracle import two_tower as tt
+        i = ids.numpy()
+        keep = i >= 0
+        if opt == "sgd":
+            tt.sparse_sgd(table.numpy(), i[keep], grads.numpy()[keep], lr)
+        else:
+            tt.sparse_adagrad(table.numpy(), accum.numpy(), i[keep], grads.numpy()[keep], lr, eps)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, case, ret):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import synth, two_tower as tt
+        from two_tower_amazon_recommender_amd.sharded import ShardedEmbedding, shard_rows
+        rows, dim, batch, opt, variant, capf = case
+        full = synth.embedding_table(3, 1, rows, dim)                       # the global table (oracle side)
+        n_local = shard_rows(rows, world, rank)
+        shard = torch.from_numpy(full[rank::world].copy())
+        assert shard.shape[0] == n_local
+        accum = torch.full_like(shard, 0.1) if opt == "adagrad" else None
+        emb = ShardedEmbedding(rows, dim, batch, torch.device("cpu"), capacity_factor=capf, backend=OracleRowBackend(),
+                               table=shard, accum=accum)
+        ref_table = full.copy()
+        ref_acc = np.full_like(full, np.float32(0.1))
+        for step in range(2):
+            all_ids = synth.batch_ids(3, 3, step, world * batch, rows, variant)
+            all_g = synth.uniform_f32(3, 9 + step, world * batch * dim, -1.0, 2.0).reshape(world * batch, dim)
+            ids = all_ids[rank * batch:(rank + 1) * batch]
+            g = all_g[rank * batch:(rank + 1) * batch]
+            out = torch.empty(batch, dim)
+            emb.lookup(torch.from_numpy(ids), out)
+            assert np.array_equal(out.numpy(), ref_table[ids]), "looked-up rows differ"
+            emb.apply_gradients(torch.from_numpy(g), opt, 0.01, 1e-7)
+            emb.check()
+            # oracle on the GLOBAL batch; summation order differs (per-rank partial sums first), so compare with a
+            # tolerance of a few f32 ulps of the gradient sum
+            if opt == "sgd":
+                tt.sparse_sgd(ref_table, all_ids, all_g, 0.01)
+            else:
+                tt.sparse_adagrad(ref_table, ref_acc, all_ids, all_g, 0.01, 1e-7)
+            got = emb.table.numpy()[:n_local]
+            assert np.allclose(got, ref_table[rank::world], rtol=0, atol=2e-6), np.abs(got - ref_table[rank::world]).max()
+            # after the comparison re-sync the oracle to the sharded state so errors do not compound
+            gathered = [None] * world
+            dist.all_gather_object(gathered, got.copy())
+            for r in range(world):
+                ref_table[r::world] = gathered[r]
+            if opt == "adagrad":
+                gacc = [None] * world
+                dist.all_gather_object(gacc, emb.accum.numpy()[:n_local].copy())
+                for r in range(world):
+                    ref_acc[r::world] = gacc[r]
+        ret[rank] = "ok"
+    except Exception as e:                                                    # noqa: BLE001
+        import traceback
+        ret[rank] = traceback.format_exc()
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(world, case):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), case, ret), nprocs=world, join=True)
+    for r in range(world):
+        assert ret.get(r) == "ok", f"rank {r}: {ret.get(r)}"
+
+
+@pytest.mark.parametrize("case", [
+    (1000, 32, 256, "sgd", "U", 2.0),
+    (1000, 32, 256, "adagrad", "Z", 2.0),       # heavy duplicates inside and across ranks
+    (37, 8, 64, "sgd", "U", 4.0),               # tiny table: every id duplicated many times; ragged shards
+])
+def test_sharded_embedding_world2(case):
+    _run(2, case)
+
+
+def test_sharded_embedding_world3_ragged():
+    _run(3, (1001, 16, 96, "adagrad", "Z", 3.0))
+
+
+def _worker_flags(rank, world, port, ret):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from two_tower_amazon_recommender_amd.sharded import ShardedEmbedding
+        emb = ShardedEmbedding(1000, 8, 128, torch.device("cpu"), capacity_factor=1.0, backend=OracleRowBackend(),
+                               table=torch.zeros(500, 8))
+        assert emb.cap == 64
+        out = torch.empty(128, 8)
+        ids = torch.arange(128, dtype=torch.int64) * 2            # all even: 128 distinct ids for owner 0 > cap 64
+        emb.lookup(ids, out)
+        try:
+            emb.check()
+            ret[rank] = "no overflow error"
+        except RuntimeError as e:
+            ret[rank] = "ok" if "overflow" in str(e) else str(e)
+        ids = torch.arange(128, dtype=torch.int64)
+        ids[5] = 1000                                             # out of range
+        emb.lookup(ids, out)
+        try:
+            emb.check()
+            ret[rank] = "no oob error"
+        except IndexError:
+            assert not out[5].any()
+    except Exception:                                             # noqa: BLE001
+        import traceback
+        ret[rank] = traceback.format_exc()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overflow_and_out_of_range_are_reported():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_flags, args=(2, _free_port(), ret), nprocs=2, join=True)
+    for r in range(2):
+        assert ret.get(r) == "ok", f"rank {r}: {ret.get(r)}"

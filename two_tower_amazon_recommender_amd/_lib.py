@@ -39,6 +39,7 @@ SIGNATURES = {
     "tt_profile_enable": (C.c_int, [C.c_char_p, _i32]),
     "tt_profile_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_float), _i32, C.POINTER(_i32)]),
     "tt_fill_uniform_f32": (C.c_int, [_p, _i64, _u64, _u64, _i64, _f, _f, _p]),
+    "tt_fill_uniform_rows_f32": (C.c_int, [_p, _i64, _i32, _i64, _i64, _u64, _u64, _f, _f, _p]),
     "tt_fill_ids_i64": (C.c_int, [_p, _i64, _u64, _u64, _i64, _i64, _i32, _p]),
     "tt_embedding_gather_f32": (C.c_int, [_p, _i64, _i32, _p, _i64, _p, _p, _p]),
     "tt_embedding_gather2_f32": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _p, _p, _i32, _i64, _p, _p]),

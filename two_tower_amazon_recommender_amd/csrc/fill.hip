@@ -27,6 +27,23 @@ __global__ __launch_bounds__(256) void fill_uniform_kernel(float* __restrict__ d
   if (t < n) dst[t] = u24_to_f32(tt::splitmix(key + (uint64_t)(start + t)), lo, scale);
 }
 
+__global__ __launch_bounds__(256) void fill_rows_kernel(float* __restrict__ dst, int64_t n_rows, int dim4, int64_t row_start,
+                                                        int64_t row_stride, uint64_t key, float lo, float scale) {
+  const int64_t nvec = n_rows * dim4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
+    const int64_t lr = v / dim4;
+    const int c = (int)(v - lr * dim4);
+    const uint64_t base = key + (uint64_t)((row_start + lr * row_stride) * (4 * (int64_t)dim4) + 4 * c);
+    tt::f32x4 o;
+    o[0] = u24_to_f32(tt::splitmix(base + 0), lo, scale);
+    o[1] = u24_to_f32(tt::splitmix(base + 1), lo, scale);
+    o[2] = u24_to_f32(tt::splitmix(base + 2), lo, scale);
+    o[3] = u24_to_f32(tt::splitmix(base + 3), lo, scale);
+    *reinterpret_cast<tt::f32x4*>(dst + 4 * v) = o;
+  }
+}
+
 __global__ __launch_bounds__(256) void fill_ids_kernel(int64_t* __restrict__ dst, int64_t n, uint64_t key,
                                                        int64_t start, int64_t num_rows, int variant) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -67,6 +84,16 @@ extern "C" int tt_fill_uniform_f32(float* dst, int64_t n, uint64_t seed, uint64_
   hipLaunchKernelGGL(fill_uniform_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, tt::as_stream(stream), dst, n,
                      stream_key(seed, tensor_id), start, lo, scale);
   return tt::check_launch("tt_fill_uniform_f32");
+}
+
+extern "C" int tt_fill_uniform_rows_f32(float* dst, int64_t n_rows, int32_t dim, int64_t row_start, int64_t row_stride,
+                                        uint64_t seed, uint64_t tensor_id, float lo, float scale, tt_stream_t stream) {
+  TT_REQUIRE(dst != nullptr && n_rows >= 0 && row_start >= 0 && row_stride > 0, "tt_fill_uniform_rows_f32: bad arguments");
+  TT_REQUIRE(dim > 0 && dim % 4 == 0 && tt::aligned16(dst), "tt_fill_uniform_rows_f32: dim %% 4 == 0 and 16-byte alignment required");
+  if (n_rows == 0) return TT_OK;
+  hipLaunchKernelGGL(fill_rows_kernel, dim3(grid_for(n_rows * (dim / 4))), dim3(256), 0, tt::as_stream(stream), dst, n_rows,
+                     dim / 4, row_start, row_stride, stream_key(seed, tensor_id), lo, scale);
+  return tt::check_launch("tt_fill_uniform_rows_f32");
 }
 
 extern "C" int tt_fill_ids_i64(int64_t* dst, int64_t n, uint64_t seed, uint64_t tensor_id, int64_t start,

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a, int dim4 /* d
         const int64_t id = ids[b[u]];
         if (id >= 0 && id < rows) {
           v[u] = table[id * dim4 + c];
-        } else if (oob_flag != nullptr && c == 0) {
+        } else if (oob_flag != nullptr && c == 0 && id != -1) {   // -1 = padding slot (sharded exchange): zero row, no flag
           atomicOr(oob_flag, 1);
         }
       }

@@ -140,7 +140,9 @@ extern "C" int tt_sparse_plan(const int64_t* ids, int64_t n_ids, int64_t num_row
   // Only the low bits that an id < num_rows can set are sorted.  Ids outside [0,num_rows) then land
   // somewhere in the order, possibly splitting into several runs — harmless, because the apply kernel
   // skips every out-of-range id (the gather has already flagged them).
-  const int bits = id_bits(num_rows);
+  // +1: 2^bits - 1 (the low bits of the padding id -1) is then never a valid id, so padding slots cannot
+  // interleave with (and split) a run of equal valid ids.
+  const int bits = id_bits(num_rows + 1);
   tt::ProfScope prof("sparse_plan", tt::as_stream(stream));
   hipError_t e = rocprim::radix_sort_pairs(workspace, temp, ids, sorted_ids, rocprim::counting_iterator<int32_t>(0), order,
                                            (size_t)n_ids, 0u, (unsigned)bits, tt::as_stream(stream), false);

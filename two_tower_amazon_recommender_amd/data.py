@@ -1,0 +1,53 @@
+"""Training-input reader: the parquet the reference's ``prepare_training_data.py:216-218`` writes
+(``combined_interactions.parquet`` with int64 ``user_idx`` / ``item_idx``) or the preprocessor's
+``user_id_encoded`` / ``item_id_encoded`` columns (``src/data/preprocessor.py:481-482``).
+``mappings.pkl`` (``prepare_training_data.py:229-234``) is NOT read: loading a pickle executes code; the
+row counts come from the id columns (max + 1), which is what the sorted-enumerate encoding guarantees."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+ID_COLUMNS = (("user_idx", "item_idx"), ("user_id_encoded", "item_id_encoded"))
+
+
+def read_interactions(path) -> tuple[np.ndarray, np.ndarray]:
+    import pyarrow.parquet as pq
+    names = pq.read_schema(path).names
+    for ucol, icol in ID_COLUMNS:
+        if ucol in names and icol in names:
+            tbl = pq.read_table(path, columns=[ucol, icol])
+            u = tbl.column(ucol).to_numpy().astype(np.int64, copy=False)
+            i = tbl.column(icol).to_numpy().astype(np.int64, copy=False)
+            if u.size and (u.min() < 0 or i.min() < 0):
+                raise ValueError("negative ids in the interaction file")
+            return u, i
+    raise KeyError(f"{path}: none of the id column pairs {ID_COLUMNS} found (columns: {names})")
+
+
+class BatchIterator:
+    """Shuffled fixed-size batches of (user_idx, item_idx), resident on the device; the last partial batch
+    of an epoch is dropped (the kernels' buffers are sized for one batch size)."""
+
+    def __init__(self, user_idx: np.ndarray, item_idx: np.ndarray, batch_size: int, device, seed: int = 42, shuffle=True):
+        if len(user_idx) != len(item_idx):
+            raise ValueError("user_idx and item_idx differ in length")
+        self.u = torch.from_numpy(np.ascontiguousarray(user_idx)).to(device)
+        self.i = torch.from_numpy(np.ascontiguousarray(item_idx)).to(device)
+        self.batch_size, self.shuffle = batch_size, shuffle
+        self.gen = torch.Generator(device="cpu").manual_seed(seed)
+        self.n_batches = len(user_idx) // batch_size
+
+    def __len__(self):
+        return self.n_batches
+
+    def __iter__(self):
+        n = self.u.numel()
+        if self.shuffle:
+            perm = torch.randperm(n, generator=self.gen).to(self.u.device)
+            u, i = self.u[perm], self.i[perm]
+        else:
+            u, i = self.u, self.i
+        b = self.batch_size
+        for k in range(self.n_batches):
+            yield u[k * b:(k + 1) * b], i[k * b:(k + 1) * b]

@@ -1,0 +1,42 @@
+"""``TwoTowerModel`` — a ``tfrs.Model``-shaped facade over the HIP train step (the reference intended a
+``tfrs.Model`` subclass in ``src/models``; it is a docstring stub, ``/root/reference/src/models/__init__.py:1``).
+
+    model = TwoTowerModel(cfg)                       # cfg from config.model_config_from_dict(...)
+    loss  = model.train_step({"user_idx": u, "item_idx": i})     # tfrs.Model.train_step(features)
+    val   = model.test_step({"user_idx": u, "item_idx": i})
+"""
+from __future__ import annotations
+
+import torch
+
+from .trainer import TwoTowerConfig, TwoTowerTrainer
+
+USER_KEYS = ("user_idx", "user_id_encoded")      # prepare_training_data.py:209 / preprocessor.py:481
+ITEM_KEYS = ("item_idx", "item_id_encoded")      # :210 / :482
+
+
+def _pick(features: dict, keys):
+    for k in keys:
+        if k in features:
+            return features[k]
+    raise KeyError(f"features need one of {keys}")
+
+
+class TwoTowerModel:
+    def __init__(self, cfg: TwoTowerConfig, device="cuda:0", seed: int | None = 42):
+        self.trainer = TwoTowerTrainer(cfg, device, seed=seed)
+        self.cfg = cfg
+
+    def compute_loss(self, features: dict, training: bool = False) -> torch.Tensor:
+        u, i = _pick(features, USER_KEYS), _pick(features, ITEM_KEYS)
+        kw = {k: features[k] for k in ("sample_weight", "candidate_sampling_probability", "candidate_ids") if k in features}
+        if training:
+            return self.trainer.step(u, i, **kw)
+        return self.trainer.evaluate(u, i, **kw)
+
+    def train_step(self, features: dict) -> dict:
+        loss = self.compute_loss(features, training=True)
+        return {"loss": loss, "regularization_loss": None, "total_loss": loss}
+
+    def test_step(self, features: dict) -> dict:
+        return {"loss": self.compute_loss(features, training=False)}

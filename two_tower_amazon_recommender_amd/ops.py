@@ -52,6 +52,15 @@ def fill_uniform_(dst: torch.Tensor, seed: int, tensor_id: int, lo: float, scale
     return dst
 
 
+def fill_uniform_rows_(dst: torch.Tensor, seed: int, tensor_id: int, lo: float, scale: float, row_start: int, row_stride: int):
+    """dst[lr, :] = row (row_start + lr*row_stride) of the synthetic [*, dim] tensor (a row-sharded table's shard)."""
+    _chk(dst, torch.float32, "dst", 2)
+    lib = _lib.load()
+    _lib.check(lib.tt_fill_uniform_rows_f32(_p(dst), dst.shape[0], dst.shape[1], row_start, row_stride, seed, tensor_id,
+                                            lo, scale, _stream()), "tt_fill_uniform_rows_f32")
+    return dst
+
+
 def fill_ids_(dst: torch.Tensor, seed: int, tensor_id: int, num_rows: int, variant: str = "U", start: int = 0):
     _chk(dst, torch.int64, "dst")
     v = {"U": _lib.TT_IDS_UNIFORM, "Z": _lib.TT_IDS_POWERLAW}[variant]

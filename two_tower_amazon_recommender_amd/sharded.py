@@ -1,0 +1,282 @@
+"""Row-sharded embedding tables over the GPUs of one node (BASELINE.json configs 4-5).
+
+One process per GPU (``torch.distributed``; backend "nccl" = RCCL over xGMI).  Table row ``id`` lives on
+rank ``id % world`` at local row ``id // world`` (mod placement balances skewed ids).  Per table and step:
+
+  route   (index plumbing, torch ops, static shapes — no host sync):
+          sort positions by (owner, local row); de-duplicate; slot every distinct id into a fixed-capacity
+          send buffer [world, cap] (padding id -1)
+  C1      all-to-all of the id buffers                      (world*cap*8 B per rank)
+  K1      owner gathers its rows for the received ids       (HIP gather; -1 -> zero row)
+  C2      all-to-all of the rows back                       (world*cap*4*dim B per rank)
+  K1'     expand to per-position embeddings                 (HIP gather from the received buffer)
+  ... towers, scorer, loss, backward ...
+  K2'     per-position row gradients -> per-distinct-id sums in the send buffer (the sparse-SGD kernel
+          with lr = -1 on a zeroed buffer: w = 0 - (-1*g) = g, ascending-position f32 sums)
+  C3      all-to-all of the gradient rows to the owners
+  K2      owner sorts the received ids and applies the fused sparse SGD/Adagrad (duplicates from
+          different ranks are summed first, in rank order: bitwise reproducible)
+
+xGMI is point-to-point (7 links x ~153 GB/s per GPU): an all-to-all uses every link at once, one peer per
+link.  The buffers are fixed-size so no step waits on the host; ``capacity_factor`` x the mean distinct ids
+per peer is reserved and an overflow raises at the next ``check()``.
+
+The exchange code is device-agnostic torch + torch.distributed; only the three row kernels come from a
+``backend`` (default: the HIP ops; the CPU/gloo tests pass a NumPy-oracle backend).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+_KEY_SHIFT = 40          # local row ids < 2^40
+
+
+class HipRowBackend:
+    """The product's row kernels (C ABI of include/twotower_hip.h).  No fallback."""
+
+    def __init__(self, device):
+        from . import ops
+        self.ops = ops
+        self.device = device
+        self._plans = {}
+
+    def gather(self, table, ids, out, oob_flag):
+        self.ops.embedding_gather(table, ids, out=out, oob_flag=oob_flag)
+
+    def segment_sum(self, out_zeroed, grads, sorted_flat, order):
+        """out[f] = sum of grads[p] over positions p with flat index f, ascending p (out must be zero)."""
+        plan = _PlanView(sorted_flat, order)
+        self.ops.sparse_sgd_(out_zeroed, grads, plan, lr=-1.0)
+
+    def apply(self, opt, table, accum, ids, grads, lr, eps):
+        n = ids.numel()
+        plan = self._plans.get(n)
+        if plan is None:
+            plan = self._plans[n] = self.ops.SparsePlan(n, ids.device)
+        plan.run(ids, table.shape[0])
+        if opt == "sgd":
+            self.ops.sparse_sgd_(table, grads, plan, lr)
+        else:
+            self.ops.sparse_adagrad_(table, accum, grads, plan, lr, eps)
+
+
+class _PlanView:
+    def __init__(self, sorted_ids, order):
+        self.sorted_ids, self.order, self.n_ids = sorted_ids, order, sorted_ids.numel()
+
+
+def shard_rows(num_rows: int, world: int, rank: int) -> int:
+    """Rows of a table that live on ``rank`` (ids rank, rank+world, ...)."""
+    return (num_rows - rank + world - 1) // world if num_rows > rank else 0
+
+
+class ShardedEmbedding:
+    def __init__(self, num_rows: int, dim: int, batch: int, device, group=None, capacity_factor: float = 2.0,
+                 backend=None, table: torch.Tensor | None = None, accum: torch.Tensor | None = None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.num_rows, self.dim, self.batch, self.device = num_rows, dim, batch, device
+        w = self.world
+        mean = (batch + w - 1) // w
+        cap = batch if w == 1 else min(batch, int(mean * capacity_factor + 63) // 64 * 64)
+        self.cap = max(cap, 1)
+        self.local_rows = max(shard_rows(num_rows, w, self.rank), 1)
+        self.table = table if table is not None else torch.zeros(self.local_rows, dim, device=device)
+        self.accum = accum
+        self.backend = backend if backend is not None else HipRowBackend(device)
+        n = w * self.cap
+        i64 = dict(dtype=torch.int64, device=device)
+        self.send_ids = torch.empty(n, **i64)
+        self.recv_ids = torch.empty(n, **i64)
+        self.rows_out = torch.empty(n, dim, device=device)        # owner side: gathered rows / received grads
+        self.rows_in = torch.empty(n, dim, device=device)         # requester side: received rows / grads to send
+        self.pos_flat = torch.empty(batch, **i64)
+        self.sorted_flat = torch.empty(batch, **i64)
+        self.order32 = torch.empty(batch, dtype=torch.int32, device=device)
+        self.flags = torch.zeros(2, dtype=torch.int32, device=device)   # [oob, overflow]
+        self._arange_w = torch.arange(w, **i64)
+
+    # ---------------------------------------------------------------- routing (static shapes, no sync)
+    def route(self, ids: torch.Tensor):
+        w, cap = self.world, self.cap
+        owner = ids % w
+        lrow = ids // w
+        bad = (ids < 0) | (ids >= self.num_rows)
+        # out-of-range ids: flagged; routed as padding so nothing is read or written for them
+        key = torch.where(bad, torch.full_like(ids, (w << _KEY_SHIFT) - 1), (owner << _KEY_SHIFT) + lrow)
+        skey, order = torch.sort(key, stable=True)
+        head = torch.ones_like(skey, dtype=torch.bool)
+        head[1:] = skey[1:] != skey[:-1]
+        uidx = torch.cumsum(head.to(torch.int64), 0) - 1
+        sowner = torch.clamp(skey >> _KEY_SHIFT, max=w - 1)
+        counts = torch.zeros(w, dtype=torch.int64, device=ids.device).scatter_add_(0, sowner, head.to(torch.int64))
+        bstart = torch.cumsum(counts, 0) - counts
+        slot = uidx - bstart[sowner]
+        over = slot >= cap
+        flat = sowner * cap + torch.clamp(slot, max=cap - 1)
+        sbad = bad[order]
+        self.flags[0] |= bad.any().to(torch.int32)
+        self.flags[1] |= (over & ~sbad).any().to(torch.int32)
+        self.send_ids.fill_(-1)
+        slrow = torch.where(sbad, torch.full_like(skey, -1), skey & ((1 << _KEY_SHIFT) - 1))
+        self.send_ids.scatter_(0, flat, slrow)
+        self.sorted_flat.copy_(flat)
+        self.order32.copy_(order.to(torch.int32))
+        self.pos_flat.scatter_(0, order, flat)
+
+    def _a2a(self, out, inp):
+        if self.world == 1:
+            out.copy_(inp)
+        else:
+            dist.all_to_all_single(out, inp, group=self.group)
+
+    # ---------------------------------------------------------------- forward / backward
+    def lookup(self, ids: torch.Tensor, out: torch.Tensor):
+        """out[p, :] = T[ids[p], :] for this rank's batch (C1, K1, C2, K1')."""
+        self.route(ids)
+        self._a2a(self.recv_ids, self.send_ids)                                   # C1
+        self.backend.gather(self.table, self.recv_ids, self.rows_out, self.flags[0:1])   # K1 on the owner
+        self._a2a(self.rows_in, self.rows_out)                                    # C2
+        self.backend.gather(self.rows_in, self.pos_flat, out, None)              # K1': expand duplicates
+        return out
+
+    def apply_gradients(self, grads: torch.Tensor, opt: str, lr: float, eps: float = 1e-7):
+        """grads[p, :] = dLoss/d(out[p, :]) of the last lookup (K2', C3, K2)."""
+        self.rows_in.zero_()
+        self.backend.segment_sum(self.rows_in, grads, self.sorted_flat, self.order32)   # K2'
+        self._a2a(self.rows_out, self.rows_in)                                    # C3
+        self.backend.apply(opt, self.table, self.accum, self.recv_ids, self.rows_out, lr, eps)   # K2
+
+    def check(self):
+        """Host check (synchronises): out-of-range ids (TF's gather raises) and exchange-buffer overflow."""
+        f = self.flags.tolist()          # (a copy: .cpu() would alias a CPU tensor)
+        self.flags.zero_()
+        if int(f[0]):
+            raise IndexError("embedding id out of range in a previous step")
+        if int(f[1]):
+            raise RuntimeError(f"sharded exchange overflow: more than {self.cap} distinct ids for one owner; "
+                               "raise capacity_factor")
+
+
+class ShardedTwoTowerTrainer:
+    """Data-parallel towers + row-sharded tables: one instance per rank / GPU.
+
+    ``cfg.batch_size`` is the PER-RANK batch; ``cfg.n_users`` / ``cfg.n_items`` are the GLOBAL row counts.
+    negatives="local"  — each rank's queries score against its own candidates (what tfrs.tasks.Retrieval
+                         does under a data-parallel tf.distribute strategy: the task sees the per-replica batch);
+                         total loss = sum over ranks.
+    negatives="global" — candidates (and their ids) are all-gathered, every query sees world*batch candidates
+                         (identical to the single-device loss on the global batch), dC is reduce-scattered.
+    Dense tower gradients are summed with one all-reduce of a flat ~0.5 MB bucket.
+    """
+
+    def __init__(self, cfg, device, group=None, seed: int | None = None, negatives: str = "local",
+                 capacity_factor: float = 2.0):
+        from . import ops
+        from .trainer import Tower, TID_USER_TABLE, TID_ITEM_TABLE
+        cfg.validate()
+        if negatives not in ("local", "global"):
+            raise ValueError("negatives must be 'local' or 'global'")
+        self.ops, self.cfg, self.group, self.negatives = ops, cfg, group, negatives
+        self.dev = dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("ShardedTwoTowerTrainer needs a CUDA/HIP device: there is no CPU fallback")
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        b, d, w = cfg.batch_size, cfg.embedding_dim, self.world
+        adagrad = cfg.optimizer == "adagrad"
+        self.user_emb = ShardedEmbedding(cfg.n_users, d, b, dev, group, capacity_factor)
+        self.item_emb = ShardedEmbedding(cfg.n_items, d, b, dev, group, capacity_factor)
+        if adagrad:
+            self.user_emb.accum = torch.full_like(self.user_emb.table, cfg.adagrad_initial_accumulator)
+            self.item_emb.accum = torch.full_like(self.item_emb.table, cfg.adagrad_initial_accumulator)
+        n_tower = Tower.param_count(cfg)
+        self.dense_flat = torch.zeros(2 * n_tower, device=dev)
+        self.dense_accum = torch.full_like(self.dense_flat, cfg.adagrad_initial_accumulator) if adagrad else None
+        self.dense_grad = torch.empty_like(self.dense_flat)
+        self.user_tower = Tower(cfg, self.dense_flat, self.dense_accum, 0, dev)
+        self.item_tower = Tower(cfg, self.dense_flat, self.dense_accum, n_tower, dev)
+        l2 = cfg.l2_regularization
+        # pass 1: slabs -> flat gradient (no update); pass 2 (after the all-reduce): update from the flat gradient
+        self._segs_reduce = self.user_tower.segments(l2, self.dense_grad, 0) + \
+            self.item_tower.segments(l2, self.dense_grad, n_tower)
+        self._segs_apply = []
+        off = 0
+        for tower in (self.user_tower, self.item_tower):
+            for l in range(tower.n_layers):
+                for p, acc, reg in ((tower.w[l], tower.w_acc[l], l2), (tower.b[l], tower.b_acc[l], 0.0)):
+                    self._segs_apply.append(ops.make_dense_seg(p, acc, self.dense_grad[off:off + p.numel()], 1, reg))
+                    off += p.numel()
+        sd = cfg.tower_dims[-1]
+        nc = b * w if negatives == "global" else b
+        self.ws = torch.empty(ops.retrieval_workspace_bytes(b, nc, sd), dtype=torch.uint8, device=dev)
+        self.lse = torch.empty(b, device=dev)
+        self.per_row = torch.empty(b, device=dev)
+        self.loss = torch.empty(1, device=dev)
+        if negatives == "global":
+            self.c_all = torch.empty(nc, sd, device=dev)
+            self.dc_all = torch.empty(nc, sd, device=dev)
+        if seed is not None:
+            self.init_synthetic(seed)
+
+    def init_synthetic(self, seed: int):
+        """Same values as the single-GPU trainer / oracle.synthetic_state: each rank fills only its rows."""
+        import math
+        from .trainer import TID_USER_TABLE, TID_ITEM_TABLE, TID_DENSE_BASE
+        ops, w, r = self.ops, self.world, self.rank
+        for emb, tid in ((self.user_emb, TID_USER_TABLE), (self.item_emb, TID_ITEM_TABLE)):
+            n = shard_rows(emb.num_rows, w, r)
+            if n:
+                ops.fill_uniform_rows_(emb.table[:n], seed, tid, -0.05, 0.1, row_start=r, row_stride=w)
+        self.dense_flat.zero_()
+        for t, tower in enumerate((self.user_tower, self.item_tower)):
+            for l, wt in enumerate(tower.w):
+                lim = torch.tensor(math.sqrt(6.0 / (wt.shape[0] + wt.shape[1])), dtype=torch.float64).to(torch.float32)
+                ops.fill_uniform_(wt, seed, TID_DENSE_BASE + 2 * l + t, -lim.item(), (lim + lim).item())
+
+    def synthetic_batch(self, seed: int, step: int, variant: str = "U", out=None):
+        """This rank's slice of the global synthetic batch of step ``step`` (global batch = world * batch)."""
+        from .trainer import TID_USER_IDS, TID_ITEM_IDS
+        b = self.cfg.batch_size
+        if out is None:
+            out = (torch.empty(b, dtype=torch.int64, device=self.dev), torch.empty(b, dtype=torch.int64, device=self.dev))
+        start = (step * self.world + self.rank) * b
+        self.ops.fill_ids_(out[0], seed, TID_USER_IDS, self.cfg.n_users, variant, start=start)
+        self.ops.fill_ids_(out[1], seed, TID_ITEM_IDS, self.cfg.n_items, variant, start=start)
+        return out
+
+    def step(self, user_ids: torch.Tensor, item_ids: torch.Tensor) -> torch.Tensor:
+        """One train step on this rank's batch; returns this rank's (device, unsynchronised) loss."""
+        cfg, ops, ut, it = self.cfg, self.ops, self.user_tower, self.item_tower
+        b, w = cfg.batch_size, self.world
+        self.user_emb.lookup(user_ids, ut.acts[0])
+        self.item_emb.lookup(item_ids, it.acts[0])
+        q = ut.forward()
+        c = it.forward()
+        inv_t = 1.0 / cfg.temperature
+        if self.negatives == "local" or w == 1:
+            ops.retrieval_fwd(q, c, inv_t, self.ws, self.lse, self.per_row, self.loss)
+            ops.retrieval_bwd(q, c, inv_t, self.ws, self.lse, ut.dz[-1], it.dz[-1])
+        else:
+            dist.all_gather_into_tensor(self.c_all, c, group=self.group)                       # C4
+            off = self.rank * b
+            ops.retrieval_fwd(q, self.c_all, inv_t, self.ws, self.lse, self.per_row, self.loss, diag_offset=off)
+            ops.retrieval_bwd(q, self.c_all, inv_t, self.ws, self.lse, ut.dz[-1], self.dc_all, diag_offset=off)
+            dist.reduce_scatter_tensor(it.dz[-1], self.dc_all, op=dist.ReduceOp.SUM, group=self.group)   # C5
+        ut.backward()
+        it.backward()
+        if w == 1:
+            ops.dense_update_(self._segs_reduce, cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon, apply=True)
+        else:
+            ops.dense_update_(self._segs_reduce, cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon, apply=False)
+            dist.all_reduce(self.dense_grad, op=dist.ReduceOp.SUM, group=self.group)           # C6
+            ops.dense_update_(self._segs_apply, cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon, apply=True)
+        self.user_emb.apply_gradients(ut.demb, cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon)
+        self.item_emb.apply_gradients(it.demb, cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon)
+        return self.loss
+
+    def check_ids(self):
+        self.user_emb.check()
+        self.item_emb.check()

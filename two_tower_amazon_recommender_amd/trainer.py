@@ -202,6 +202,32 @@ class TwoTowerTrainer:
         self.apply_gradients()
         return loss
 
+    def evaluate(self, user_ids: torch.Tensor, item_ids: torch.Tensor, **loss_kw) -> torch.Tensor:
+        """Forward only (validation loss, SUM over the batch); device tensor, unsynchronised."""
+        cfg, ut, it = self.cfg, self.user_tower, self.item_tower
+        ops.embedding_gather2(self.user_table, user_ids, ut.acts[0], self.item_table, item_ids, it.acts[0], self.oob)
+        q, c = ut.forward(), it.forward()
+        kw = dict(sample_weight=loss_kw.get("sample_weight"), cand_prob=loss_kw.get("candidate_sampling_probability"),
+                  cand_ids=loss_kw.get("candidate_ids"))
+        return ops.retrieval_fwd(q, c, 1.0 / cfg.temperature, self.ws, self.lse, self.per_row, self.loss, **kw)
+
+    # ------------------------------------------------------------------ checkpoint (SURVEY.md §8f row 4)
+    def state_dict(self) -> dict:
+        sd = {"config": dict(self.cfg.__dict__), "user_table": self.user_table, "item_table": self.item_table,
+              "dense": self.dense_flat}
+        if self.cfg.optimizer == "adagrad":
+            sd.update(user_accum=self.user_accum, item_accum=self.item_accum, dense_accum=self.dense_accum)
+        return sd
+
+    def load_state_dict(self, sd: dict):
+        for k in ("n_users", "n_items", "embedding_dim", "tower_dims", "optimizer"):
+            if sd["config"][k] != getattr(self.cfg, k):
+                raise ValueError(f"checkpoint {k}={sd['config'][k]!r} does not match the trainer's {getattr(self.cfg, k)!r}")
+        self.user_table.copy_(sd["user_table"]); self.item_table.copy_(sd["item_table"]); self.dense_flat.copy_(sd["dense"])
+        if self.cfg.optimizer == "adagrad":
+            self.user_accum.copy_(sd["user_accum"]); self.item_accum.copy_(sd["item_accum"])
+            self.dense_accum.copy_(sd["dense_accum"])
+
     def check_ids(self):
         """Host check of the out-of-range flag (TF's CPU gather raises InvalidArgumentError); synchronises."""
         if int(self.oob.item()) != 0:
