@@ -52,7 +52,7 @@ const char* tt_last_error(void);
  * tt_profile_enable("score_bwd,gather", 4096) makes every launch of the kernels carrying one
  * of those tags record a hipEvent pair on ITS OWN stream (capacity = launches kept per tag);
  * tags: fill, gather, sparse_plan, sparse_apply, dense_fwd, dense_bwd_dx, dense_bwd_dw,
- * dense_update, score_fwd, score_bwd, score_aux.  An empty string (or NULL) disables it.
+ * dense_update, score_fwd, score_bwd, score_fused, score_aux.  An empty string (or NULL) disables it.
  * tt_profile_read synchronises on the recorded events, writes up to `cap` durations in
  * milliseconds (launch order) to the HOST array `ms`, stores the number of launches seen in
  * *count (HOST) and clears the tag.  Disabled = one predictable branch per launch.           */
@@ -187,6 +187,16 @@ int tt_retrieval_bwd_f32(const float* q, const float* c, int64_t nq, int64_t nc,
                          const float* lse, float grad_scale,
                          void* workspace, int64_t workspace_bytes,
                          float* dq, float* dc, tt_stream_t stream);
+
+/* Fused training form: loss AND both gradients in two passes over the logits instead of three
+ * (pass 1: online softmax with the candidate-weighted sum -> lse, per_row, loss, dq;  pass 2: dc).
+ * Same semantics and outputs as tt_retrieval_fwd_f32 followed by tt_retrieval_bwd_f32.          */
+int tt_retrieval_fwd_bwd_f32(const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
+                             int64_t diag_offset, float inv_temperature,
+                             const float* sample_weight, const float* cand_prob, const int64_t* cand_ids,
+                             float grad_scale, void* workspace, int64_t workspace_bytes,
+                             float* lse, float* per_row, float* loss, float* dq, float* dc,
+                             tt_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -221,7 +221,7 @@ def test_dense_update_segments(dev, opt):
 
 
 # ----------------------------------------------------------------------------------- a3+a4 retrieval
-def run_retrieval(dev, q, c, temperature, w=None, p=None, ids=None, off=0, grad_scale=1.0):
+def run_retrieval(dev, q, c, temperature, w=None, p=None, ids=None, off=0, grad_scale=1.0, fused=False):
     nq, nc, d = q.shape[0], c.shape[0], q.shape[1]
     ws = torch.empty(ops.retrieval_workspace_bytes(nq, nc, d), dtype=torch.uint8, device=dev)
     lse = torch.empty(nq, device=dev); per_row = torch.empty(nq, device=dev); loss = torch.empty(1, device=dev)
@@ -230,18 +230,27 @@ def run_retrieval(dev, q, c, temperature, w=None, p=None, ids=None, off=0, grad_
     kw = dict(sample_weight=None if w is None else T(w.astype(np.float32), dev),
               cand_prob=None if p is None else T(p.astype(np.float32), dev),
               cand_ids=None if ids is None else T(ids.astype(np.int64), dev), diag_offset=off)
-    ops.retrieval_fwd(dq_, dc_, 1.0 / temperature, ws, lse, per_row, loss, **kw)
-    ops.retrieval_bwd(dq_, dc_, 1.0 / temperature, ws, lse, dq, dc, grad_scale=grad_scale, **kw)
+    if fused:
+        ops.retrieval_fwd_bwd(dq_, dc_, 1.0 / temperature, ws, lse, per_row, loss, dq, dc, grad_scale=grad_scale, **kw)
+    else:
+        ops.retrieval_fwd(dq_, dc_, 1.0 / temperature, ws, lse, per_row, loss, **kw)
+        ops.retrieval_bwd(dq_, dc_, 1.0 / temperature, ws, lse, dq, dc, grad_scale=grad_scale, **kw)
     return loss.item(), per_row.cpu().numpy(), lse.cpu().numpy(), dq.cpu().numpy(), dc.cpu().numpy()
 
 
 def check_retrieval(dev, nq, nc, d, temperature=0.1, scale=0.3, use_w=False, use_p=False, use_ids=False, off=0, seed=41):
+    """Checks BOTH forms: separate fwd + bwd entry points, and the fused two-pass training entry."""
+    for fused in (False, True):
+        _check_retrieval(dev, nq, nc, d, temperature, scale, use_w, use_p, use_ids, off, seed, fused)
+
+
+def _check_retrieval(dev, nq, nc, d, temperature, scale, use_w, use_p, use_ids, off, seed, fused):
     q = synth.uniform_f32(seed, 1, nq * d, -scale, 2 * scale).reshape(nq, d)
     c = synth.uniform_f32(seed, 2, nc * d, -scale, 2 * scale).reshape(nc, d)
     w = synth.uniform_f32(seed, 3, nq, 0.5, 1.5) if use_w else None
     p = synth.uniform_f32(seed, 4, nc, 0.0, 0.3) if use_p else None      # includes values < 1e-6 (clip)
     ids = synth.ids_powerlaw(seed, 5, nc, max(nc // 4, 2)) if use_ids else None
-    loss, per_row, lse, dq, dc = run_retrieval(dev, q, c, temperature, w, p, ids, off)
+    loss, per_row, lse, dq, dc = run_retrieval(dev, q, c, temperature, w, p, ids, off, fused=fused)
     kw = dict(temperature=temperature, sample_weight=w, candidate_sampling_probability=p, candidate_ids=ids,
               remove_accidental_hits=use_ids, diag_offset=off)
     rl, rper, rlse = tt.retrieval_loss(q, c, **kw)
@@ -291,11 +300,28 @@ def test_retrieval_grad_scale_linearity(dev):
     assert np.allclose(dq2, 2 * dq1, rtol=1e-6, atol=1e-9) and np.allclose(dc2, 2 * dc1, rtol=1e-6, atol=1e-9)
 
 
-def test_retrieval_is_deterministic(dev):
+@pytest.mark.parametrize("fused", [False, True])
+def test_retrieval_is_deterministic(dev, fused):
     q = synth.uniform_f32(44, 1, 2048 * 128, -0.3, 0.6).reshape(2048, 128)
-    a = run_retrieval(dev, q, q[::-1].copy(), 0.1)
-    b = run_retrieval(dev, q, q[::-1].copy(), 0.1)
+    a = run_retrieval(dev, q, q[::-1].copy(), 0.1, fused=fused)
+    b = run_retrieval(dev, q, q[::-1].copy(), 0.1, fused=fused)
     assert a[0] == b[0] and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+
+
+def test_fused_online_rescale_branch_is_exercised(dev):
+    """Force the lazy-rescale branch late in the sweep: one candidate far along the row has a logit ~100 (log2
+    units) above everything before it, for a few queries only (wave-uniform branch, per-lane factors)."""
+    nq, d = 1024, 128
+    q = synth.uniform_f32(46, 1, nq * d, -0.3, 0.6).reshape(nq, d)
+    c = synth.uniform_f32(46, 2, nq * d, -0.3, 0.6).reshape(nq, d)
+    for row, col in ((5, 900), (37, 1000), (700, 1023)):
+        c[col] = 3.0 * q[row] / np.linalg.norm(q[row]) ** 2 * 2.5      # q_row . c_col = 7.5 -> logit 75
+    loss, per_row, lse, dq, dc = run_retrieval(dev, q, c, 0.1, fused=True)
+    rl, rper, rlse = tt.retrieval_loss(q, c, temperature=0.1)
+    rdq, rdc = tt.retrieval_grad(q, c, temperature=0.1)
+    assert abs(loss - rl) <= 1e-4 * abs(rl)
+    assert np.abs(lse - rlse).max() <= 1e-4 * np.abs(rlse).max()
+    assert np.abs(dq - rdq).max() <= 1e-4 * np.abs(rdq).max() and np.abs(dc - rdc).max() <= 1e-4 * np.abs(rdc).max()
 
 
 def test_retrieval_rejects_bad_shapes(dev):

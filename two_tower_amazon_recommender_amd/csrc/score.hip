@@ -34,7 +34,8 @@ constexpr float kLog2e = 1.44269504088896340736f;
 constexpr float kLn2 = 0.69314718055994530942f;
 constexpr float kNegBig = -1.0e30f;   // log2-domain stand-in for -inf (tfrs uses finfo.min/100)
 
-enum { MODE_FWD = 0, MODE_BWD = 1 };
+enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2 };
+constexpr float kRescaleThr = 8.0f;   // FUSED: rescale the accumulators only when a row max grows by > 2^8 (p stays <= 256)
 
 struct ScoreArgs {
   const float* R;
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void score_kernel(ScoreArg
   float run_m = kNegBig, run_l = 0.f, pos = 0.f;
   bool have_pos = false;
   f32x16 G[NB];
-  if constexpr (MODE == MODE_BWD) {
+  if constexpr (MODE != MODE_FWD) {
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -243,17 +244,54 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void score_kernel(ScoreArg
       run_m = m_new;
     } else {
       float coef[16];
+      if constexpr (MODE == MODE_BWD) {
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const float w = sc[reg] * sr;
-        float e = __builtin_amdgcn_exp2f(__builtin_fmaf(X[reg], p.c1, ac[reg]) + ar) * w;
-        if constexpr (HAS_IDS) e = dup[reg] ? 0.f : e;
-        coef[reg] = e;
-      }
-      if (diag_tile) {
+        for (int reg = 0; reg < 16; ++reg) {
+          const float w = sc[reg] * sr;
+          float e = __builtin_amdgcn_exp2f(__builtin_fmaf(X[reg], p.c1, ac[reg]) + ar) * w;
+          if constexpr (HAS_IDS) e = dup[reg] ? 0.f : e;
+          coef[reg] = e;
+        }
+        if (diag_tile) {
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg)
-          if (tt::acc_row(reg, 0) == dloc) coef[reg] -= sc[reg] * sr;
+          for (int reg = 0; reg < 16; ++reg)
+            if (tt::acc_row(reg, 0) == dloc) coef[reg] -= sc[reg] * sr;
+        }
+      } else {
+        // FUSED (flash-style): online softmax over c; coef = exp2(t - m_row) un-normalised, the accumulators
+        // carry sum_c p*K[c] at scale m_row.  Both lane halves of a row share ONE running max (GEMM2 sums
+        // over both halves' c).  Lazy rescale (threshold kRescaleThr): wave-uniform branch.
+        float mx = kNegBig;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          float v = __builtin_fmaf(X[reg], p.c1, ac[reg]);
+          if constexpr (HAS_IDS) v = dup[reg] ? kNegBig : v;
+          coef[reg] = v;
+          mx = fmaxf(mx, v);
+        }
+        if (diag_tile) {
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg)
+            if (tt::acc_row(reg, 0) == dloc) { pos = coef[reg]; have_pos = true; }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        if (__any(mx - run_m > kRescaleThr)) {
+          const float m_new = fmaxf(run_m, mx);
+          const float alpha = __builtin_amdgcn_exp2f(run_m - m_new);
+          run_l *= alpha;
+#pragma unroll
+          for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) G[b][i] *= alpha;
+          run_m = m_new;
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          coef[reg] = __builtin_amdgcn_exp2f(coef[reg] - run_m);
+          sum += coef[reg];
+        }
+        run_l += sum;
       }
       if (t + 1 < ntiles) load_tile(t + 1);
       // ---- GEMM2: G^T[d = NB*i + b][r] += K[c(reg,h)][d] * coef[reg] ----
@@ -296,6 +334,16 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void score_kernel(ScoreArg
   }
 
   // ---- epilogue ----
+  if constexpr (MODE == MODE_FUSED) {
+    const float L = run_l + __shfl_xor(run_l, 32);      // both halves share run_m
+    if (r_ok) {
+      if (h == 0) {
+        p.part_m[(int64_t)split * p.n_r + r] = run_m;
+        p.part_l[(int64_t)split * p.n_r + r] = L;
+      }
+      if (have_pos) p.pos2[r] = pos;
+    }
+  }
   if constexpr (MODE == MODE_FWD) {
     const float om = __shfl_xor(run_m, 32);
     const float ol = __shfl_xor(run_l, 32);
@@ -377,6 +425,57 @@ __global__ __launch_bounds__(1024) void fwd_combine_kernel(const float* __restri
   if (threadIdx.x == 0) loss[0] = red[0];
 }
 
+// FUSED pass 1 epilogue: per-split (max, sum, G) -> lse, per-row loss, the per-row terms of the dc pass, and
+//   dq[r] = (w_r/T*g) * ( sum_s G_s[r]*2^(m_s-M) / L  -  c[r+diag] ).   32 lanes per row, 8 rows per block.
+__global__ __launch_bounds__(256) void fused_combine_kernel(const float* __restrict__ part_m, const float* __restrict__ part_l,
+                                                            const float* __restrict__ pos2, const float* __restrict__ w,
+                                                            const f32x4* __restrict__ slab, const f32x4* __restrict__ cpos,
+                                                            int64_t n_r, int d4, int nsplit, float scale,
+                                                            float* __restrict__ lse, float* __restrict__ per_row,
+                                                            float* __restrict__ aq, float* __restrict__ sq,
+                                                            f32x4* __restrict__ dq) {
+  const int64_t row = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int lane = threadIdx.x & 31;
+  if (row >= n_r) return;
+  float M = kNegBig;
+  for (int s = 0; s < nsplit; ++s) M = fmaxf(M, part_m[(int64_t)s * n_r + row]);
+  float L = 0.f;
+  for (int s = 0; s < nsplit; ++s)
+    L += part_l[(int64_t)s * n_r + row] * __builtin_amdgcn_exp2f(part_m[(int64_t)s * n_r + row] - M);
+  const float lse2 = M + __log2f(L);
+  const float wr = (w != nullptr ? w[row] : 1.0f);
+  const float sr = wr * scale;
+  if (lane == 0) {
+    lse[row] = lse2 * kLn2;
+    per_row[row] = (lse2 - pos2[row]) * kLn2 * wr;
+    aq[row] = -lse2;
+    sq[row] = sr;
+  }
+  const float inv_l = 1.0f / L;
+  for (int c = lane; c < d4; c += 32) {
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < nsplit; ++s) {
+      const float wt = __builtin_amdgcn_exp2f(part_m[(int64_t)s * n_r + row] - M);
+      acc += slab[((int64_t)s * n_r + row) * d4 + c] * wt;
+    }
+    dq[row * d4 + c] = (acc * inv_l - cpos[row * d4 + c]) * sr;
+  }
+}
+
+// loss = sum_r per_row[r], fixed order (one workgroup)
+__global__ __launch_bounds__(1024) void sum_rows_kernel(const float* __restrict__ per_row, int64_t n, float* __restrict__ loss) {
+  __shared__ float red[1024];
+  float acc = 0.f;
+  for (int64_t r = threadIdx.x; r < n; r += 1024) acc += per_row[r];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = red[0];
+}
+
 // out[i] = sum_s slab[s][i], s ascending (float4)
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const f32x4* __restrict__ slab, f32x4* __restrict__ out,
                                                            int64_t n4, int nsplit) {
@@ -438,12 +537,12 @@ int launch_score(const ScoreArgs& a, bool has_ids, hipStream_t stream) {
       raised = true;
     }
   }
-  tt::ProfScope prof(MODE == MODE_FWD ? "score_fwd" : "score_bwd", stream);
+  tt::ProfScope prof(MODE == MODE_FWD ? "score_fwd" : (MODE == MODE_BWD ? "score_bwd" : "score_fused"), stream);
   if (has_ids)
     hipLaunchKernelGGL((score_kernel<D, MODE, true>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
   else
     hipLaunchKernelGGL((score_kernel<D, MODE, false>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
-  return tt::check_launch(MODE == MODE_FWD ? "score_fwd" : "score_bwd");
+  return tt::check_launch(MODE == MODE_FWD ? "score_fwd" : (MODE == MODE_BWD ? "score_bwd" : "score_fused"));
 }
 
 template <int MODE>
@@ -577,6 +676,76 @@ extern "C" int tt_retrieval_bwd_f32(const float* q, const float* c, int64_t nq, 
       hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
                          reinterpret_cast<const f32x4*>(slab), reinterpret_cast<f32x4*>(dc), n4, a.nsplit);
     }
+    if ((rc = tt::check_launch("reduce_slabs(dc)")) != TT_OK) return rc;
+  }
+  return TT_OK;
+}
+
+// Fused training entry: loss AND both gradients in two passes (8*B^2*D executed FLOPs instead of 10):
+//   pass 1 (R = q, K = c, MODE_FUSED): online softmax + sum_c p*c  -> lse, per-row loss, dq
+//   pass 2 (R = c, K = q, MODE_BWD)  : recompute with the final lse -> dc
+extern "C" int tt_retrieval_fwd_bwd_f32(const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
+                                        int64_t diag_offset, float inv_temperature, const float* sample_weight,
+                                        const float* cand_prob, const int64_t* cand_ids, float grad_scale, void* workspace,
+                                        int64_t workspace_bytes, float* lse, float* per_row, float* loss, float* dq,
+                                        float* dc, tt_stream_t stream_) {
+  int rc = check_common("tt_retrieval_fwd_bwd_f32", q, c, nq, nc, dim, diag_offset, workspace, workspace_bytes);
+  if (rc != TT_OK) return rc;
+  TT_REQUIRE(lse && per_row && loss && dq && dc, "tt_retrieval_fwd_bwd_f32: null output pointer");
+  TT_REQUIRE(tt::aligned16(dq) && tt::aligned16(dc), "tt_retrieval_fwd_bwd_f32: dq/dc must be 16-byte aligned");
+  hipStream_t stream = tt::as_stream(stream_);
+  const WsLayout w = ws_layout(nq, nc, dim);
+  char* ws = static_cast<char*>(workspace);
+  float* bias = reinterpret_cast<float*>(ws + w.off_bias);
+  float* aq = reinterpret_cast<float*>(ws + w.off_aq);
+  float* sq = reinterpret_cast<float*>(ws + w.off_sq);
+  float* slab = reinterpret_cast<float*>(ws + w.off_slab);
+  if (cand_prob != nullptr) {
+    hipLaunchKernelGGL(prob_bias_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, stream, cand_prob, bias, nc);
+    if ((rc = tt::check_launch("prob_bias")) != TT_OK) return rc;
+  }
+  const float* biasp = cand_prob != nullptr ? bias : nullptr;
+  {
+    ScoreArgs a{};
+    a.R = q; a.K = c; a.n_r = nq; a.n_c = nc; a.diag = diag_offset;
+    a.c1 = kLog2e * inv_temperature;
+    a.a_c = biasp;
+    a.id_r = cand_ids != nullptr ? cand_ids + diag_offset : nullptr;
+    a.id_c = cand_ids;
+    a.nsplit = w.ns_q;
+    a.c_per_split = align_up((nc + a.nsplit - 1) / a.nsplit, 32);
+    a.part_m = reinterpret_cast<float*>(ws + w.off_pm);
+    a.part_l = reinterpret_cast<float*>(ws + w.off_pl);
+    a.pos2 = reinterpret_cast<float*>(ws + w.off_pos);
+    a.slab = slab;
+    if ((rc = dispatch_score<MODE_FUSED>(dim, a, cand_ids != nullptr, stream)) != TT_OK) return rc;
+    {
+      tt::ProfScope prof("score_aux", stream);
+      hipLaunchKernelGGL(fused_combine_kernel, dim3((unsigned)((nq + 7) / 8)), dim3(256), 0, stream, a.part_m, a.part_l, a.pos2,
+                         sample_weight, reinterpret_cast<const f32x4*>(slab),
+                         reinterpret_cast<const f32x4*>(c + diag_offset * dim), nq, dim / 4, a.nsplit,
+                         inv_temperature * grad_scale, lse, per_row, aq, sq, reinterpret_cast<f32x4*>(dq));
+      if ((rc = tt::check_launch("fused_combine")) != TT_OK) return rc;
+      hipLaunchKernelGGL(sum_rows_kernel, dim3(1), dim3(1024), 0, stream, per_row, nq, loss);
+      if ((rc = tt::check_launch("sum_rows")) != TT_OK) return rc;
+    }
+  }
+  {
+    ScoreArgs a{};
+    a.R = c; a.K = q; a.n_r = nc; a.n_c = nq; a.diag = -diag_offset;
+    a.c1 = kLog2e * inv_temperature;
+    a.a_r = biasp; a.s_r = nullptr; a.a_c = aq; a.s_c = sq;
+    a.id_r = cand_ids;
+    a.id_c = cand_ids != nullptr ? cand_ids + diag_offset : nullptr;
+    a.nsplit = w.ns_c;
+    a.c_per_split = align_up((nq + a.nsplit - 1) / a.nsplit, 32);
+    a.slab = slab;
+    if ((rc = dispatch_score<MODE_BWD>(dim, a, cand_ids != nullptr, stream)) != TT_OK) return rc;
+    const int64_t n4 = nc * dim / 4;
+    const int64_t blocks = (n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048;
+    tt::ProfScope prof("score_aux", stream);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
+                       reinterpret_cast<const f32x4*>(slab), reinterpret_cast<f32x4*>(dc), n4, a.nsplit);
     if ((rc = tt::check_launch("reduce_slabs(dc)")) != TT_OK) return rc;
   }
   return TT_OK;

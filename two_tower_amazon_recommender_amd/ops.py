@@ -245,3 +245,24 @@ def retrieval_bwd(q, c, inv_temperature: float, workspace, lse, dq, dc, sample_w
                                         _p(workspace), workspace.numel(), _p(dq), _p(dc), _stream()),
                "tt_retrieval_bwd_f32")
     return dq, dc
+
+
+def retrieval_fwd_bwd(q, c, inv_temperature: float, workspace, lse, per_row, loss, dq, dc, sample_weight=None,
+                      cand_prob=None, cand_ids=None, diag_offset: int = 0, grad_scale: float = 1.0):
+    """Loss and both gradients in two fused passes (training form)."""
+    _chk(q, torch.float32, "query_embeddings", 2)
+    _chk(c, torch.float32, "candidate_embeddings", 2)
+    if q.shape[1] != c.shape[1]:
+        raise RuntimeError(f"retrieval: embedding dims differ: {q.shape[1]} vs {c.shape[1]}")
+    if sample_weight is not None:
+        _chk(sample_weight, torch.float32, "sample_weight", 1)
+    if cand_prob is not None:
+        _chk(cand_prob, torch.float32, "candidate_sampling_probability", 1)
+    if cand_ids is not None:
+        _chk(cand_ids, torch.int64, "candidate_ids", 1)
+    lib = _lib.load()
+    _lib.check(lib.tt_retrieval_fwd_bwd_f32(_p(q), _p(c), q.shape[0], c.shape[0], q.shape[1], diag_offset, inv_temperature,
+                                            _p(sample_weight), _p(cand_prob), _p(cand_ids), grad_scale, _p(workspace),
+                                            workspace.numel(), _p(lse), _p(per_row), _p(loss), _p(dq), _p(dc), _stream()),
+               "tt_retrieval_fwd_bwd_f32")
+    return loss

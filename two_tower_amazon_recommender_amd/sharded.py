@@ -257,13 +257,12 @@ class ShardedTwoTowerTrainer:
         c = it.forward()
         inv_t = 1.0 / cfg.temperature
         if self.negatives == "local" or w == 1:
-            ops.retrieval_fwd(q, c, inv_t, self.ws, self.lse, self.per_row, self.loss)
-            ops.retrieval_bwd(q, c, inv_t, self.ws, self.lse, ut.dz[-1], it.dz[-1])
+            ops.retrieval_fwd_bwd(q, c, inv_t, self.ws, self.lse, self.per_row, self.loss, ut.dz[-1], it.dz[-1])
         else:
             dist.all_gather_into_tensor(self.c_all, c, group=self.group)                       # C4
             off = self.rank * b
-            ops.retrieval_fwd(q, self.c_all, inv_t, self.ws, self.lse, self.per_row, self.loss, diag_offset=off)
-            ops.retrieval_bwd(q, self.c_all, inv_t, self.ws, self.lse, ut.dz[-1], self.dc_all, diag_offset=off)
+            ops.retrieval_fwd_bwd(q, self.c_all, inv_t, self.ws, self.lse, self.per_row, self.loss, ut.dz[-1], self.dc_all,
+                                  diag_offset=off)
             dist.reduce_scatter_tensor(it.dz[-1], self.dc_all, op=dist.ReduceOp.SUM, group=self.group)   # C5
         ut.backward()
         it.backward()

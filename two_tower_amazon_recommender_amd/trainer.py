@@ -141,6 +141,7 @@ class TwoTowerTrainer:
         self.oob = torch.zeros(1, dtype=torch.int32, device=dev)
         self.user_plan = ops.SparsePlan(b, dev)
         self.item_plan = ops.SparsePlan(b, dev)
+        self._side = torch.cuda.Stream(device=dev)
         self._segs = self.user_tower.segments(cfg.l2_regularization) + self.item_tower.segments(cfg.l2_regularization)
         if seed is not None:
             self.init_synthetic(seed)
@@ -178,8 +179,9 @@ class TwoTowerTrainer:
         q = ut.forward()
         c = it.forward()
         kw = dict(sample_weight=sample_weight, cand_prob=candidate_sampling_probability, cand_ids=candidate_ids)
-        ops.retrieval_fwd(q, c, 1.0 / cfg.temperature, self.ws, self.lse, self.per_row, self.loss, **kw)
-        ops.retrieval_bwd(q, c, 1.0 / cfg.temperature, self.ws, self.lse, ut.dz[-1], it.dz[-1], **kw)
+        # loss + dq + dc in two fused passes over the logits (never materialised)
+        ops.retrieval_fwd_bwd(q, c, 1.0 / cfg.temperature, self.ws, self.lse, self.per_row, self.loss,
+                              ut.dz[-1], it.dz[-1], **kw)
         ut.backward()
         it.backward()
         return self.loss
@@ -195,10 +197,14 @@ class TwoTowerTrainer:
         """One train step; returns the (device, unsynchronised) retrieval loss (SUM over the batch)."""
         if user_ids.numel() != self.cfg.batch_size or item_ids.numel() != self.cfg.batch_size:
             raise ValueError(f"batch must have {self.cfg.batch_size} pairs")
-        # the sort plans depend on the ids only
-        self.user_plan.run(user_ids, self.cfg.n_users)
-        self.item_plan.run(item_ids, self.cfg.n_items)
+        # the sort plans depend on the ids only: they run on a side stream beside the forward/backward pass
+        main = torch.cuda.current_stream()
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            self.user_plan.run(user_ids, self.cfg.n_users)
+            self.item_plan.run(item_ids, self.cfg.n_items)
         loss = self.forward_backward(user_ids, item_ids, **loss_kw)
+        main.wait_stream(self._side)
         self.apply_gradients()
         return loss
 
