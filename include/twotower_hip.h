@@ -52,7 +52,7 @@ const char* tt_last_error(void);
  * tt_profile_enable("score_bwd,gather", 4096) makes every launch of the kernels carrying one
  * of those tags record a hipEvent pair on ITS OWN stream (capacity = launches kept per tag);
  * tags: fill, gather, sparse_plan, sparse_apply, dense_fwd, dense_bwd_dx, dense_bwd_dw,
- * dense_update, score_fwd, score_bwd, score_fused, score_aux.  An empty string (or NULL) disables it.
+ * dense_update, score_fwd, score_bwd, score_fused, score_aux, route, scatter_rows.  An empty string (or NULL) disables it.
  * tt_profile_read synchronises on the recorded events, writes up to `cap` durations in
  * milliseconds (launch order) to the HOST array `ms`, stores the number of launches seen in
  * *count (HOST) and clears the tag.  Disabled = one predictable branch per launch.           */
@@ -116,6 +116,20 @@ int tt_sparse_update2_f32(int32_t opt,
                           float* table_b, float* accum_b, int64_t rows_b, const float* grads_b,
                           const int64_t* sorted_ids_b, const int32_t* order_b,
                           int32_t dim, int64_t n_ids, float lr, float eps, tt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Row-sharded tables (multi-GPU): requester-side routing for the all-to-all exchange.
+ * Row `id` lives on rank id % world at local row id / world.
+ *   tt_route_by_owner_i64: stable partition of ids[n_ids] by owner into send_ids [world*cap] (local row ids,
+ *     bucket o at [o*cap, (o+1)*cap), ascending position inside a bucket, padding -1) and
+ *     pos_flat[p] = the slot of position p (or -1).  flags (device int32[2], may be NULL): [0] |= 1 when an id
+ *     is outside [0,num_rows) (routed nowhere), [1] |= 1 when a bucket overflows `cap`.  world <= 16.
+ *   tt_scatter_rows_f32: dst[idx[p], :] = src[p, :] for 0 <= idx[p] < dst_rows (per-position gradient rows
+ *     into the send buffer; duplicates are summed later, on the owner, by the sparse optimizer).            */
+int tt_route_by_owner_i64(const int64_t* ids, int64_t n_ids, int32_t world, int64_t num_rows, int32_t cap,
+                          int64_t* send_ids, int64_t* pos_flat, int32_t* flags, tt_stream_t stream);
+int tt_scatter_rows_f32(const float* src, const int64_t* idx, int64_t n, int32_t dim,
+                        float* dst, int64_t dst_rows, tt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * a2 — MLP tower layers (Keras Dense; configs/data_config.yaml:56-57 *_tower_dims).

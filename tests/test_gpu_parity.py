@@ -354,3 +354,53 @@ def test_full_size_properties_cfg3(dev):
     ref = 10.0 * (c.double().mean(0, keepdim=True) - c.double())
     assert (dq.double() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
     assert dc.abs().max().item() <= 1e-6
+
+
+# ----------------------------------------------------------------------------------- sharded routing kernels
+def np_route(ids, world, num_rows, cap):
+    send = np.full(world * cap, -1, dtype=np.int64)
+    pos = np.full(len(ids), -1, dtype=np.int64)
+    fill = [0] * world
+    oob = over = 0
+    for p, v in enumerate(ids):
+        if v < 0 or v >= num_rows:
+            oob = 1
+            continue
+        o = int(v % world)
+        if fill[o] < cap:
+            send[o * cap + fill[o]] = v // world
+            pos[p] = o * cap + fill[o]
+        else:
+            over = 1
+        fill[o] += 1
+    return send, pos, oob, over
+
+
+@pytest.mark.parametrize("world,n,rows,cap,variant", [(1, 8192, 10_000_000, 8192, "U"), (2, 8192, 10_000_000, 8192, "Z"),
+                                                      (8, 8192, 100_000_000, 2048, "U"), (8, 8192, 100_000_000, 2048, "Z"),
+                                                      (8, 1000, 37, 128, "U"), (4, 1, 10, 64, "U"), (16, 5000, 1000, 512, "Z"),
+                                                      (8, 8192, 1000, 1024, "Z")])
+def test_route_by_owner_matches_stable_partition(dev, world, n, rows, cap, variant):
+    ids = synth.batch_ids(61, 3, 0, n, rows, variant)
+    if n > 10:
+        ids[7] = rows            # out of range
+        ids[9] = -5
+    send = torch.empty(world * cap, dtype=torch.int64, device=dev)
+    pos = torch.empty(n, dtype=torch.int64, device=dev)
+    flags = torch.zeros(2, dtype=torch.int32, device=dev)
+    ops.route_by_owner(T(ids, dev), world, rows, cap, send, pos, flags)
+    rs, rp, oob, over = np_route(ids, world, rows, cap)
+    assert np.array_equal(send.cpu().numpy(), rs) and np.array_equal(pos.cpu().numpy(), rp)
+    assert flags.tolist() == [oob, over]
+
+
+def test_scatter_rows(dev):
+    n, d, rows = 5000, 128, 9000
+    src = synth.uniform_f32(62, 1, n * d, -1.0, 2.0).reshape(n, d)
+    idx = np.random.default_rng(0).permutation(rows)[:n].astype(np.int64)
+    idx[::17] = -1
+    dst = torch.zeros(rows, d, device=dev)
+    ops.scatter_rows(T(src, dev), T(idx, dev), dst)
+    ref = np.zeros((rows, d), dtype=np.float32)
+    ref[idx[idx >= 0]] = src[idx >= 0]
+    assert np.array_equal(dst.cpu().numpy(), ref)

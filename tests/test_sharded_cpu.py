@@ -18,7 +18,27 @@ ROOT = pathlib.Path(__file__).resolve().parents[1]
 
 
 class OracleRowBackend:
-    """Test-only stand-in for HipRowBackend built from the oracle's row functions."""
+    """Test-only stand-in for HipRowBackend: NumPy restatements of the row kernels (route = stable partition by
+    owner, gather, scatter_rows, sort+apply through the oracle's sparse optimizers)."""
+
+    def route(self, ids, world, num_rows, cap, send_ids, pos_flat, flags):
+        i = ids.numpy()
+        send = np.full(world * cap, -1, dtype=np.int64)
+        pos = np.full(len(i), -1, dtype=np.int64)
+        fill = [0] * world
+        for p, v in enumerate(i):
+            if v < 0 or v >= num_rows:
+                flags[0] = 1
+                continue
+            o = int(v % world)
+            if fill[o] < cap:
+                send[o * cap + fill[o]] = v // world
+                pos[p] = o * cap + fill[o]
+            else:
+                flags[1] = 1
+            fill[o] += 1
+        send_ids.copy_(torch.from_numpy(send))
+        pos_flat.copy_(torch.from_numpy(pos))
 
     def gather(self, table, ids, out, oob_flag):
         t, i = table.numpy(), ids.numpy()
@@ -29,11 +49,13 @@ class OracleRowBackend:
         if oob_flag is not None and ((~ok) & (i != -1)).any():
             oob_flag.fill_(1)
 
-    def segment_sum(self, out_zeroed, grads, sorted_flat, order):
-        o = out_zeroed.numpy()
-        g = grads.numpy()
-        for f, p in zip(sorted_flat.numpy(), order.numpy()):      # sorted: ascending position inside a run
-            o[f] = o[f] + g[p]
+    def scatter_rows(self, src, idx, dst):
+        i = idx.numpy()
+        ok = i >= 0
+        dst.numpy()[i[ok]] = src.numpy()[ok]
+
+    def plan(self, ids, num_rows):
+        pass
 
     def apply(self, opt, table, accum, ids, grads, lr, eps):
         from oracle import two_tower as tt
@@ -117,7 +139,7 @@ def _run(world, case):
 @pytest.mark.parametrize("case", [
     (1000, 32, 256, "sgd", "U", 2.0),
     (1000, 32, 256, "adagrad", "Z", 2.0),       # heavy duplicates inside and across ranks
-    (37, 8, 64, "sgd", "U", 4.0),               # tiny table: every id duplicated many times; ragged shards
+    (37, 8, 64, "sgd", "U", 4.0),               # tiny table: every id duplicated many times; ragged shards (cap = batch)
 ])
 def test_sharded_embedding_world2(case):
     _run(2, case)
@@ -137,7 +159,7 @@ def _worker_flags(rank, world, port, ret):
                                table=torch.zeros(500, 8))
         assert emb.cap == 64
         out = torch.empty(128, 8)
-        ids = torch.arange(128, dtype=torch.int64) * 2            # all even: 128 distinct ids for owner 0 > cap 64
+        ids = torch.arange(128, dtype=torch.int64) * 2            # all even: 128 positions for owner 0 > cap 64
         emb.lookup(ids, out)
         try:
             emb.check()

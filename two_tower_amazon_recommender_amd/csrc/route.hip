@@ -1,0 +1,114 @@
+// Requester-side routing of the row-sharded embedding exchange.
+//
+// route_kernel   : stable partition of a batch of ids by owner rank (owner = id % world, local row = id / world)
+//                  into fixed-capacity per-owner send buffers (padding id -1) + the flat slot of every position.
+//                  One workgroup, 16 waves; per 1024-position round: `world` wave ballots give the rank inside the
+//                  wave, a 16 x world table in LDS gives the offsets across waves (ascending position order inside
+//                  every owner bucket: deterministic).  Integer/byte work, latency-bound (a few microseconds).
+// scatter_rows   : dst[idx[p], :] = src[p, :] (idx < 0 skipped) — per-position gradient rows into the send buffer;
+//                  HBM-bound, dim/4 lanes per row like the gather.
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxWorld = 16;
+
+__global__ __launch_bounds__(1024) void route_kernel(const int64_t* __restrict__ ids, int64_t n, int world, int64_t num_rows,
+                                                     int cap, int64_t* __restrict__ send_ids, int64_t* __restrict__ pos_flat,
+                                                     int32_t* __restrict__ flags) {
+  __shared__ int wave_cnt[16][kMaxWorld];
+  __shared__ int wave_off[16][kMaxWorld];
+  __shared__ int running[kMaxWorld];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (int64_t i = tid; i < (int64_t)world * cap; i += 1024) send_ids[i] = -1;
+  if (tid < kMaxWorld) running[tid] = 0;
+  __syncthreads();
+  bool oob = false, over = false;
+  const int64_t rounds = (n + 1023) / 1024;
+  for (int64_t r = 0; r < rounds; ++r) {
+    const int64_t p = r * 1024 + tid;
+    const bool valid = p < n;
+    const int64_t id = valid ? ids[p] : 0;
+    const bool bad = valid && (id < 0 || id >= num_rows);
+    const int owner = (valid && !bad) ? (int)(id % world) : -1;
+    int my_rank = 0;
+    for (int o = 0; o < world; ++o) {
+      const unsigned long long m = __ballot(owner == o);
+      if (owner == o) my_rank = __popcll(m & lt_mask);
+      if (lane == 0) wave_cnt[wave][o] = __popcll(m);
+    }
+    __syncthreads();
+    if (tid < world) {
+      int run = running[tid];
+      for (int w = 0; w < 16; ++w) {
+        wave_off[w][tid] = run;
+        run += wave_cnt[w][tid];
+      }
+      running[tid] = run;
+    }
+    __syncthreads();
+    if (owner >= 0) {
+      const int slot = wave_off[wave][owner] + my_rank;
+      if (slot < cap) {
+        send_ids[(int64_t)owner * cap + slot] = id / world;
+        pos_flat[p] = (int64_t)owner * cap + slot;
+      } else {
+        pos_flat[p] = -1;
+        over = true;
+      }
+    } else if (valid) {
+      pos_flat[p] = -1;
+      oob = oob || bad;
+    }
+  }
+  if (flags != nullptr) {
+    if (oob) atomicOr(&flags[0], 1);
+    if (over) atomicOr(&flags[1], 1);
+  }
+}
+
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const tt::f32x4* __restrict__ src, const int64_t* __restrict__ idx,
+                                                           int64_t n, int dim4, int lpr_log2, tt::f32x4* __restrict__ dst,
+                                                           int64_t dst_rows) {
+  const int lpr = 1 << lpr_log2;
+  const int groups = 256 >> lpr_log2;
+  const int64_t p = (int64_t)blockIdx.x * groups + (threadIdx.x >> lpr_log2);
+  const int l = threadIdx.x & (lpr - 1);
+  if (p >= n) return;
+  const int64_t d = idx[p];
+  if (d < 0 || d >= dst_rows) return;
+  for (int c = l; c < dim4; c += lpr) dst[d * dim4 + c] = src[p * dim4 + c];
+}
+
+}  // namespace
+
+extern "C" int tt_route_by_owner_i64(const int64_t* ids, int64_t n_ids, int32_t world, int64_t num_rows, int32_t cap,
+                                     int64_t* send_ids, int64_t* pos_flat, int32_t* flags, tt_stream_t stream_) {
+  TT_REQUIRE(n_ids >= 0 && world >= 1 && world <= kMaxWorld && num_rows > 0 && cap >= 1,
+             "tt_route_by_owner_i64: need n_ids >= 0, 1 <= world <= %d, num_rows > 0, cap >= 1", kMaxWorld);
+  TT_REQUIRE(send_ids != nullptr && (n_ids == 0 || (ids != nullptr && pos_flat != nullptr)), "tt_route_by_owner_i64: null pointer");
+  hipStream_t stream = tt::as_stream(stream_);
+  tt::ProfScope prof("route", stream);
+  hipLaunchKernelGGL(route_kernel, dim3(1), dim3(1024), 0, stream, ids, n_ids, world, num_rows, cap, send_ids, pos_flat, flags);
+  return tt::check_launch("tt_route_by_owner_i64");
+}
+
+extern "C" int tt_scatter_rows_f32(const float* src, const int64_t* idx, int64_t n, int32_t dim, float* dst, int64_t dst_rows,
+                                   tt_stream_t stream_) {
+  TT_REQUIRE(n >= 0 && dim > 0 && dim % 4 == 0 && dst_rows >= 0, "tt_scatter_rows_f32: bad n/dim/dst_rows");
+  if (n == 0) return TT_OK;
+  TT_REQUIRE(src && idx && dst, "tt_scatter_rows_f32: null pointer");
+  TT_REQUIRE(tt::aligned16(src) && tt::aligned16(dst), "tt_scatter_rows_f32: src/dst must be 16-byte aligned");
+  const int dim4 = dim / 4;
+  int lpr_log2 = 0;
+  while ((1 << lpr_log2) < dim4 && lpr_log2 < 6) ++lpr_log2;
+  const int groups = 256 >> lpr_log2;
+  const int64_t blocks = (n + groups - 1) / groups;
+  TT_REQUIRE(blocks <= 0x7fffffff, "tt_scatter_rows_f32: n too large");
+  hipStream_t stream = tt::as_stream(stream_);
+  tt::ProfScope prof("scatter_rows", stream);
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<const tt::f32x4*>(src),
+                     idx, n, dim4, lpr_log2, reinterpret_cast<tt::f32x4*>(dst), dst_rows);
+  return tt::check_launch("tt_scatter_rows_f32");
+}

@@ -104,6 +104,29 @@ def embedding_gather2(table_a, ids_a, out_a, table_b, ids_b, out_b, oob_flag=Non
     return out_a, out_b
 
 
+# ----------------------------------------------------------------------------- sharded routing
+def route_by_owner(ids, world: int, num_rows: int, cap: int, send_ids, pos_flat, flags=None):
+    _chk(ids, torch.int64, "ids", 1)
+    _chk(send_ids, torch.int64, "send_ids")
+    _chk(pos_flat, torch.int64, "pos_flat")
+    if send_ids.numel() < world * cap or pos_flat.numel() < ids.numel():
+        raise RuntimeError("route_by_owner: output buffers too small")
+    lib = _lib.load()
+    _lib.check(lib.tt_route_by_owner_i64(_p(ids), ids.numel(), world, num_rows, cap, _p(send_ids), _p(pos_flat), _p(flags),
+                                         _stream()), "tt_route_by_owner_i64")
+
+
+def scatter_rows(src, idx, dst):
+    _chk(src, torch.float32, "src", 2)
+    _chk(idx, torch.int64, "idx", 1)
+    _chk(dst, torch.float32, "dst", 2)
+    if src.shape[1] != dst.shape[1] or idx.numel() != src.shape[0]:
+        raise RuntimeError("scatter_rows: shape mismatch")
+    lib = _lib.load()
+    _lib.check(lib.tt_scatter_rows_f32(_p(src), _p(idx), src.shape[0], src.shape[1], _p(dst), dst.shape[0], _stream()),
+               "tt_scatter_rows_f32")
+
+
 # ----------------------------------------------------------------------------- a5 sparse optimizer
 class SparsePlan:
     """Sorted (id, position) list of one id batch; reusable buffers."""

@@ -3,33 +3,35 @@
 One process per GPU (``torch.distributed``; backend "nccl" = RCCL over xGMI).  Table row ``id`` lives on
 rank ``id % world`` at local row ``id // world`` (mod placement balances skewed ids).  Per table and step:
 
-  route   (index plumbing, torch ops, static shapes — no host sync):
-          sort positions by (owner, local row); de-duplicate; slot every distinct id into a fixed-capacity
-          send buffer [world, cap] (padding id -1)
+  route   HIP kernel: stable partition of the batch by owner into fixed-capacity send buffers [world, cap]
+          (padding id -1) + the flat slot of every position               (tt_route_by_owner_i64)
   C1      all-to-all of the id buffers                      (world*cap*8 B per rank)
   K1      owner gathers its rows for the received ids       (HIP gather; -1 -> zero row)
+  plan    owner sorts the received ids (side stream, beside the forward/backward pass)
   C2      all-to-all of the rows back                       (world*cap*4*dim B per rank)
   K1'     expand to per-position embeddings                 (HIP gather from the received buffer)
   ... towers, scorer, loss, backward ...
-  K2'     per-position row gradients -> per-distinct-id sums in the send buffer (the sparse-SGD kernel
-          with lr = -1 on a zeroed buffer: w = 0 - (-1*g) = g, ascending-position f32 sums)
+  K2'     per-position gradient rows into the send buffer   (tt_scatter_rows_f32)
   C3      all-to-all of the gradient rows to the owners
-  K2      owner sorts the received ids and applies the fused sparse SGD/Adagrad (duplicates from
-          different ranks are summed first, in rank order: bitwise reproducible)
+  K2      owner applies the fused sparse SGD/Adagrad: duplicates — inside one rank's batch and across ranks —
+          are summed first, in (source rank, position) order: bitwise reproducible
 
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): an all-to-all uses every link at once, one peer per
-link.  The buffers are fixed-size so no step waits on the host; ``capacity_factor`` x the mean distinct ids
-per peer is reserved and an overflow raises at the next ``check()``.
+link.  The buffers are fixed-size so no step waits on the host; ``capacity_factor`` x the mean positions per
+peer is reserved and an overflow raises at the next ``check()``.
 
-The exchange code is device-agnostic torch + torch.distributed; only the three row kernels come from a
-``backend`` (default: the HIP ops; the CPU/gloo tests pass a NumPy-oracle backend).
+The exchange code is device-agnostic torch.distributed; the row kernels come from a ``backend`` (default:
+the HIP ops; the CPU/gloo tests pass a NumPy-oracle backend defined in the test).
 """
 from __future__ import annotations
 
 import torch
 import torch.distributed as dist
 
-_KEY_SHIFT = 40          # local row ids < 2^40
+
+class _PlanView:
+    def __init__(self, sorted_ids, order):
+        self.sorted_ids, self.order, self.n_ids = sorted_ids, order, sorted_ids.numel()
 
 
 class HipRowBackend:
@@ -40,30 +42,36 @@ class HipRowBackend:
         self.ops = ops
         self.device = device
         self._plans = {}
+        self._side = torch.cuda.Stream(device=device)
+        self._pending = None
+
+    def route(self, ids, world, num_rows, cap, send_ids, pos_flat, flags):
+        self.ops.route_by_owner(ids, world, num_rows, cap, send_ids, pos_flat, flags)
 
     def gather(self, table, ids, out, oob_flag):
         self.ops.embedding_gather(table, ids, out=out, oob_flag=oob_flag)
 
-    def segment_sum(self, out_zeroed, grads, sorted_flat, order):
-        """out[f] = sum of grads[p] over positions p with flat index f, ascending p (out must be zero)."""
-        plan = _PlanView(sorted_flat, order)
-        self.ops.sparse_sgd_(out_zeroed, grads, plan, lr=-1.0)
+    def scatter_rows(self, src, idx, dst):
+        self.ops.scatter_rows(src, idx, dst)
+
+    def plan(self, ids, num_rows):
+        """Sort the owner-side ids on a side stream (they are known right after C1)."""
+        n = ids.numel()
+        plan = self._plans.get((n, ids.data_ptr()))
+        if plan is None:
+            plan = self._plans[(n, ids.data_ptr())] = self.ops.SparsePlan(n, ids.device)
+        self._side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._side):
+            plan.run(ids, num_rows)
+        self._pending = plan
 
     def apply(self, opt, table, accum, ids, grads, lr, eps):
-        n = ids.numel()
-        plan = self._plans.get(n)
-        if plan is None:
-            plan = self._plans[n] = self.ops.SparsePlan(n, ids.device)
-        plan.run(ids, table.shape[0])
+        plan = self._pending
+        torch.cuda.current_stream().wait_stream(self._side)
         if opt == "sgd":
             self.ops.sparse_sgd_(table, grads, plan, lr)
         else:
             self.ops.sparse_adagrad_(table, accum, grads, plan, lr, eps)
-
-
-class _PlanView:
-    def __init__(self, sorted_ids, order):
-        self.sorted_ids, self.order, self.n_ids = sorted_ids, order, sorted_ids.numel()
 
 
 def shard_rows(num_rows: int, world: int, rank: int) -> int:
@@ -89,65 +97,37 @@ class ShardedEmbedding:
         n = w * self.cap
         i64 = dict(dtype=torch.int64, device=device)
         self.send_ids = torch.empty(n, **i64)
-        self.recv_ids = torch.empty(n, **i64)
         self.rows_out = torch.empty(n, dim, device=device)        # owner side: gathered rows / received grads
-        self.rows_in = torch.empty(n, dim, device=device)         # requester side: received rows / grads to send
+        if w == 1:                                                # one rank: the "exchange" is the identity
+            self.recv_ids, self.rows_in = self.send_ids, self.rows_out
+        else:
+            self.recv_ids = torch.empty(n, **i64)
+            self.rows_in = torch.empty(n, dim, device=device)     # requester side: received rows / grads to send
         self.pos_flat = torch.empty(batch, **i64)
-        self.sorted_flat = torch.empty(batch, **i64)
-        self.order32 = torch.empty(batch, dtype=torch.int32, device=device)
         self.flags = torch.zeros(2, dtype=torch.int32, device=device)   # [oob, overflow]
-        self._arange_w = torch.arange(w, **i64)
-
-    # ---------------------------------------------------------------- routing (static shapes, no sync)
-    def route(self, ids: torch.Tensor):
-        w, cap = self.world, self.cap
-        owner = ids % w
-        lrow = ids // w
-        bad = (ids < 0) | (ids >= self.num_rows)
-        # out-of-range ids: flagged; routed as padding so nothing is read or written for them
-        key = torch.where(bad, torch.full_like(ids, (w << _KEY_SHIFT) - 1), (owner << _KEY_SHIFT) + lrow)
-        skey, order = torch.sort(key, stable=True)
-        head = torch.ones_like(skey, dtype=torch.bool)
-        head[1:] = skey[1:] != skey[:-1]
-        uidx = torch.cumsum(head.to(torch.int64), 0) - 1
-        sowner = torch.clamp(skey >> _KEY_SHIFT, max=w - 1)
-        counts = torch.zeros(w, dtype=torch.int64, device=ids.device).scatter_add_(0, sowner, head.to(torch.int64))
-        bstart = torch.cumsum(counts, 0) - counts
-        slot = uidx - bstart[sowner]
-        over = slot >= cap
-        flat = sowner * cap + torch.clamp(slot, max=cap - 1)
-        sbad = bad[order]
-        self.flags[0] |= bad.any().to(torch.int32)
-        self.flags[1] |= (over & ~sbad).any().to(torch.int32)
-        self.send_ids.fill_(-1)
-        slrow = torch.where(sbad, torch.full_like(skey, -1), skey & ((1 << _KEY_SHIFT) - 1))
-        self.send_ids.scatter_(0, flat, slrow)
-        self.sorted_flat.copy_(flat)
-        self.order32.copy_(order.to(torch.int32))
-        self.pos_flat.scatter_(0, order, flat)
 
     def _a2a(self, out, inp):
-        if self.world == 1:
-            out.copy_(inp)
-        else:
+        if self.world > 1:
             dist.all_to_all_single(out, inp, group=self.group)
 
     # ---------------------------------------------------------------- forward / backward
     def lookup(self, ids: torch.Tensor, out: torch.Tensor):
-        """out[p, :] = T[ids[p], :] for this rank's batch (C1, K1, C2, K1')."""
-        self.route(ids)
+        """out[p, :] = T[ids[p], :] for this rank's batch (route, C1, K1, C2, K1')."""
+        be = self.backend
+        be.route(ids, self.world, self.num_rows, self.cap, self.send_ids, self.pos_flat, self.flags)
         self._a2a(self.recv_ids, self.send_ids)                                   # C1
-        self.backend.gather(self.table, self.recv_ids, self.rows_out, self.flags[0:1])   # K1 on the owner
+        be.plan(self.recv_ids, self.table.shape[0])                               # owner's sort, off the critical path
+        be.gather(self.table, self.recv_ids, self.rows_out, self.flags[0:1])      # K1 on the owner
         self._a2a(self.rows_in, self.rows_out)                                    # C2
-        self.backend.gather(self.rows_in, self.pos_flat, out, None)              # K1': expand duplicates
+        be.gather(self.rows_in, self.pos_flat, out, None)                         # K1': rows of my positions
         return out
 
     def apply_gradients(self, grads: torch.Tensor, opt: str, lr: float, eps: float = 1e-7):
         """grads[p, :] = dLoss/d(out[p, :]) of the last lookup (K2', C3, K2)."""
-        self.rows_in.zero_()
-        self.backend.segment_sum(self.rows_in, grads, self.sorted_flat, self.order32)   # K2'
+        be = self.backend
+        be.scatter_rows(grads, self.pos_flat, self.rows_in)                       # K2' (padding slots are never read)
         self._a2a(self.rows_out, self.rows_in)                                    # C3
-        self.backend.apply(opt, self.table, self.accum, self.recv_ids, self.rows_out, lr, eps)   # K2
+        be.apply(opt, self.table, self.accum, self.recv_ids, self.rows_out, lr, eps)   # K2
 
     def check(self):
         """Host check (synchronises): out-of-range ids (TF's gather raises) and exchange-buffer overflow."""
@@ -156,7 +136,7 @@ class ShardedEmbedding:
         if int(f[0]):
             raise IndexError("embedding id out of range in a previous step")
         if int(f[1]):
-            raise RuntimeError(f"sharded exchange overflow: more than {self.cap} distinct ids for one owner; "
+            raise RuntimeError(f"sharded exchange overflow: more than {self.cap} positions for one owner; "
                                "raise capacity_factor")
 
 
