@@ -147,11 +147,24 @@ int tt_scatter_rows_f32(const float* src, const int64_t* idx, int64_t n, int32_t
  *         n_slabs = tt_dense_bwd_num_slabs(m).                                            */
 int tt_dense_fwd_f32(const float* x, const float* w, const float* b, float* y,
                      int64_t m, int32_t k, int32_t n, int32_t relu, tt_stream_t stream);
+/* With inverted dropout on the output (configs/data_config.yaml:58 dropout_rate): element (r, c) is dropped iff
+ * the top 24 bits of the counter-based hash of (seed, tensor_id, counter_offset + r*n + c) are < round(rate*2^24);
+ * kept elements are multiplied by 1/(1-rate).  Reproducible: oracle/synth.py::dropout_keep restates it.  The
+ * backward pass needs no mask tensor: (y > 0) marks the kept, active units; pass dx_scale = 1/(1-rate) below. */
+int tt_dense_fwd_dropout_f32(const float* x, const float* w, const float* b, float* y,
+                             int64_t m, int32_t k, int32_t n, int32_t relu,
+                             float drop_rate, uint64_t seed, uint64_t tensor_id, uint64_t counter_offset,
+                             tt_stream_t stream);
 int32_t tt_dense_bwd_num_slabs(int64_t m);
 int tt_dense_bwd_f32(const float* x, const float* w, const float* dz,
                      float* dx, const float* dx_relu_src,
                      float* dw_slabs, float* db_slabs,
                      int64_t m, int32_t k, int32_t n, tt_stream_t stream);
+/* Same, with dx additionally multiplied by dx_scale where dx_relu_src > 0 (dropout on the previous layer). */
+int tt_dense_bwd_scaled_f32(const float* x, const float* w, const float* dz,
+                            float* dx, const float* dx_relu_src, float dx_scale,
+                            float* dw_slabs, float* db_slabs,
+                            int64_t m, int32_t k, int32_t n, tt_stream_t stream);
 
 /* Dense parameter update over up to TT_MAX_DENSE_SEGS segments in one launch.
  *   g = sum_s grad_slabs[s*slab_stride + i] (s ascending) + 2*l2*w[i]

@@ -88,6 +88,23 @@ TID_SAMPLE_WEIGHT = 7
 TID_CAND_PROB = 8
 
 
+TID_DROPOUT_BASE = 64
+
+
+def dropout_tid(tower: int, layer: int) -> int:
+    return TID_DROPOUT_BASE + 2 * layer + tower
+
+
+def dropout_keep(seed: int, tensor_id: int, row_start: int, rows: int, n: int, rate: float):
+    """(keep mask [rows, n] bool, scale f32) of the product's inverted dropout: element (r, c) of the layer output
+    whose global batch row is row_start + r is dropped iff the top 24 bits of u64(counter (row_start+r)*n + c)
+    are < round(rate * 2**24).  Configs: /root/reference/configs/data_config.yaml:58 (dropout_rate: 0.1)."""
+    x = raw_u64(seed, tensor_id, rows * n, start=row_start * n)
+    p24 = np.uint64(int(float(np.float32(rate)) * 16777216.0 + 0.5))
+    keep = ((x >> np.uint64(40)) >= p24).reshape(rows, n)
+    return keep, np.float32(1.0) / (np.float32(1.0) - np.float32(rate))
+
+
 def dense_tid(tower: int, layer: int) -> int:
     """tower 0 = user, 1 = item."""
     return TID_DENSE_BASE + 2 * layer + tower

@@ -51,21 +51,30 @@ def dense_bwd(x, w, y, dy, relu: bool, mask=None):
     return dy @ w.T, x.T @ dy, dy.sum(axis=0)
 
 
-def tower_fwd(x, weights, biases):
-    """ReLU on all but the last layer.  Returns activations list."""
+def tower_fwd(x, weights, biases, dropout=None):
+    """ReLU on all but the last layer.  ``dropout``: optional list, one (keep, scale) per hidden
+    layer (oracle.synth.dropout_keep): inverted dropout on the hidden activations (Keras Dropout after each hidden
+    Dense; configs/data_config.yaml:58).  Returns activations list (post-dropout)."""
     acts = [x]
     n = len(weights)
     for l, (w, b) in enumerate(zip(weights, biases)):
-        acts.append(dense_fwd(acts[-1], w, b, relu=(l < n - 1)))
+        y = dense_fwd(acts[-1], w, b, relu=(l < n - 1))
+        if dropout is not None and l < n - 1:
+            keep, scale = dropout[l]
+            y = np.where(keep, y * y.dtype.type(scale), 0)
+        acts.append(y)
     return acts
 
 
-def tower_bwd(acts, weights, dy, masks=None):
-    """masks: optional list (one per hidden layer) of boolean arrays replacing (acts[l+1] > 0)."""
+def tower_bwd(acts, weights, dy, masks=None, scale=1.0):
+    """masks: optional list (one per hidden layer) of boolean arrays replacing (acts[l+1] > 0).
+    scale: 1/(1-rate) under dropout — (acts[l+1] > 0) marks the kept active units, whose derivative is ``scale``."""
     n = len(weights)
     dws, dbs = [None] * n, [None] * n
     for l in range(n - 1, -1, -1):
         m = None if (masks is None or l >= n - 1) else masks[l]
+        if l < n - 1:
+            m = ((acts[l + 1] > 0) if m is None else m) * dy.dtype.type(scale)
         dy, dws[l], dbs[l] = dense_bwd(acts[l], weights[l], acts[l + 1], dy, relu=(l < n - 1), mask=m)
     return dy, dws, dbs
 
@@ -205,13 +214,15 @@ def init_adagrad_state(state: ModelState, initial_accumulator_value=0.1):
 
 def forward_backward(state: ModelState, user_ids, item_ids, temperature=0.1,
                      l2=0.0, sample_weight=None, candidate_sampling_probability=None,
-                     candidate_ids=None, remove_accidental_hits=False, relu_masks=None):
+                     candidate_ids=None, remove_accidental_hits=False, relu_masks=None, dropout=None):
     """One forward+backward.  total_loss = retrieval loss (SUM) + l2 * sum(W**2)
     over Dense kernels (Keras ``kernel_regularizer=l2``; biases unregularised)."""
     ue = embedding_gather(state.user_table, user_ids)
     ie = embedding_gather(state.item_table, item_ids)
-    ua = tower_fwd(ue, state.user_tower.weights, state.user_tower.biases)
-    ia = tower_fwd(ie, state.item_tower.weights, state.item_tower.biases)
+    # dropout = (user_list, item_list, scale): per-tower lists of (keep, scale) per hidden layer
+    ud, idr, dscale = (None, None, 1.0) if dropout is None else dropout
+    ua = tower_fwd(ue, state.user_tower.weights, state.user_tower.biases, ud)
+    ia = tower_fwd(ie, state.item_tower.weights, state.item_tower.biases, idr)
     q, c = ua[-1], ia[-1]
     dt = q.dtype
     kw = dict(temperature=temperature, sample_weight=sample_weight,
@@ -221,8 +232,8 @@ def forward_backward(state: ModelState, user_ids, item_ids, temperature=0.1,
     loss, per_row, lse = retrieval_loss(q, c, **kw)
     dq, dc = retrieval_grad(q, c, **kw)
     um, im = (None, None) if relu_masks is None else relu_masks
-    due, udw, udb = tower_bwd(ua, state.user_tower.weights, dq, um)
-    die, idw, idb = tower_bwd(ia, state.item_tower.weights, dc, im)
+    due, udw, udb = tower_bwd(ua, state.user_tower.weights, dq, um, dscale)
+    die, idw, idb = tower_bwd(ia, state.item_tower.weights, dc, im, dscale)
     reg = dt.type(0)
     if l2:
         for tw, dws in ((state.user_tower, udw), (state.item_tower, idw)):

@@ -171,6 +171,21 @@ def test_dense_fwd(dev, m, k, n, relu):
         assert (y >= 0).all()
 
 
+def test_dense_fwd_dropout_mask_is_the_oracles(dev):
+    m, k, n, rate, seed, tid, row0 = 2048, 128, 256, 0.1, 77, synth.dropout_tid(1, 0), 3 * 2048
+    x = synth.uniform_f32(33, 1, m * k, -1.0, 2.0).reshape(m, k)
+    w = synth.dense_kernel(33, 2, k, n)
+    b = synth.uniform_f32(33, 3, n, 0.5, 0.5)                       # pre-activations mostly positive
+    y = ops.dense_fwd(T(x, dev), T(w, dev), T(b, dev), True, dropout=(rate, seed, tid, row0 * n)).cpu().numpy()
+    keep, scale = synth.dropout_keep(seed, tid, row0, m, n, rate)
+    ref = tt.dense_fwd(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64), True)
+    assert abs((~keep).mean() - rate) < 0.01
+    assert not y[~keep].any()                                       # dropped exactly where the oracle drops
+    assert rel_err(y, np.where(keep, ref * np.float64(scale), 0)) <= 1e-5
+    y0 = ops.dense_fwd(T(x, dev), T(w, dev), T(b, dev), True).cpu().numpy()
+    assert rel_err(y0, ref) <= 1e-5                                 # inference: no dropout
+
+
 @pytest.mark.parametrize("m,k,n,mask", [(256, 32, 32, False), (4096, 64, 64, True), (8192, 128, 256, False),
                                         (8192, 256, 128, True), (1000, 128, 512, True), (77, 36, 20, True)])
 def test_dense_bwd(dev, m, k, n, mask):

@@ -10,9 +10,9 @@ from two_tower_amazon_recommender_amd.trainer import TwoTowerConfig, TwoTowerTra
 pytestmark = pytest.mark.gpu
 
 
-def make(dev, n_users, n_items, dim, tower_dims, batch, opt, seed, l2=1e-6):
+def make(dev, n_users, n_items, dim, tower_dims, batch, opt, seed, l2=1e-6, dropout=0.0):
     cfg = TwoTowerConfig(n_users=n_users, n_items=n_items, embedding_dim=dim, tower_dims=tower_dims, temperature=0.1,
-                         l2_regularization=l2, learning_rate=0.001, optimizer=opt, batch_size=batch)
+                         l2_regularization=l2, learning_rate=0.001, optimizer=opt, batch_size=batch, dropout_rate=dropout)
     tr = TwoTowerTrainer(cfg, dev, seed=seed)
     ref = tt.synthetic_state(seed, n_users, n_items, dim, tower_dims, dtype=np.float64, optimizer=opt)
     return cfg, tr, ref
@@ -36,11 +36,13 @@ def test_synthetic_init_is_bit_identical_to_oracle(dev):
     ("cfg3-small", (50_000, 100_000, 128, [256, 128], 8192), "sgd", "U"),
     ("cfg3-small-adagrad", (50_000, 100_000, 128, [256, 128], 2048), "adagrad", "Z"),
     ("ref-config-towers", (5_000, 5_000, 128, [512, 256, 128], 1024), "sgd", "U"),
+    ("ref-config-dropout0.1", (5_000, 5_000, 128, [512, 256, 128], 1024), "adagrad", "Z"),
 ])
 def test_train_steps_match_oracle(dev, name, shape, opt, variant):
     n_users, n_items, dim, tower_dims, batch = shape
     seed = 1001
-    cfg, tr, ref = make(dev, n_users, n_items, dim, tower_dims, batch, opt, seed)
+    rate = 0.1 if "dropout" in name else 0.0          # configs/data_config.yaml:58
+    cfg, tr, ref = make(dev, n_users, n_items, dim, tower_dims, batch, opt, seed, dropout=rate)
     for step in range(3):
         uid = synth.batch_ids(seed, synth.TID_USER_IDS, step, batch, n_users, variant)
         iid = synth.batch_ids(seed, synth.TID_ITEM_IDS, step, batch, n_items, variant)
@@ -51,7 +53,13 @@ def test_train_steps_match_oracle(dev, name, shape, opt, variant):
         # pre-activation within f32 rounding of 0 may have the other sign in f64); everything else is f64.
         masks = tuple([(t.acts[l + 1] > 0).cpu().numpy() for l in range(len(tower_dims) - 1)]
                       for t in (tr.user_tower, tr.item_tower))
-        r = tt.train_step(ref, uid, iid, lr=0.001, optimizer=opt, temperature=0.1, l2=1e-6, relu_masks=masks)
+        drop = None
+        if rate:
+            dims = [dim] + tower_dims
+            per_tower = [[synth.dropout_keep(seed, synth.dropout_tid(t, l), step * batch, batch, dims[l + 1], rate)
+                          for l in range(len(tower_dims) - 1)] for t in (0, 1)]
+            drop = (per_tower[0], per_tower[1], per_tower[0][0][1])
+        r = tt.train_step(ref, uid, iid, lr=0.001, optimizer=opt, temperature=0.1, l2=1e-6, relu_masks=masks, dropout=drop)
         tr.check_ids()
         # loss: |d|/B <= 1e-4 and relative <= 1e-4
         assert abs(loss - r["loss"]) / batch <= 1e-4 and abs(loss - r["loss"]) <= 1e-4 * abs(r["loss"]), (step, loss, r["loss"])

@@ -38,8 +38,8 @@ def test_reference_yaml_schema_is_read_verbatim():
     assert loop == dict(epochs=50, patience=5, validation_freq=1, top_k_eval=[1, 5, 10, 20, 50, 100])
     cfg.validate()
     cfg2, _ = cfgmod.model_config_from_dict(doc, 1000, 2000)
-    with pytest.raises(NotImplementedError, match="dropout"):
-        cfg2.validate()
+    assert cfg2.dropout_rate == 0.1
+    cfg2.validate()
     doc["model"]["retrieval"]["candidate_sampling"] = "uniform"
     with pytest.raises(NotImplementedError, match="in_batch"):
         cfgmod.model_config_from_dict(doc, 10, 10)

@@ -34,6 +34,11 @@ struct GemmArgs {
   const float* bias;    // [N] or null
   int relu;
   const float* mask_src;   // [M][ldc] or null: C *= (mask_src > 0)
+  float mask_scale;        // multiplies the kept entries of the masked epilogue (1/(1-p) under dropout, else 1)
+  uint32_t drop_p24;       // fwd dropout: element dropped iff 24-bit hash < drop_p24 (0 = no dropout)
+  float drop_scale;        // 1/(1-p)
+  uint64_t drop_key;       // counter-based stream key
+  uint64_t drop_offset;    // counter of element (0,0); element (m,n) uses drop_offset + m*N + n
   int64_t k_per_split;     // multiple of BK
   int64_t slab_stride;     // C offset per blockIdx.z
   float* db_slabs;         // TN only: [splits][N] column sums of B
@@ -151,7 +156,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
       if (m < p.M) {
         float v = acc[reg] + bias;
         if (p.relu) v = fmaxf(v, 0.f);
-        if (p.mask_src != nullptr) v = p.mask_src[m * p.ldc + n] > 0.f ? v : 0.f;
+        if (p.drop_p24 != 0u) {      // inverted dropout on the activation (Keras Dropout after the Dense)
+          const uint64_t hsh = tt::splitmix(p.drop_key + p.drop_offset + (uint64_t)m * (uint64_t)p.N + (uint64_t)n);
+          v = ((uint32_t)(hsh >> 40) < p.drop_p24) ? 0.f : v * p.drop_scale;
+        }
+        if (p.mask_src != nullptr) v = p.mask_src[m * p.ldc + n] > 0.f ? v * p.mask_scale : 0.f;
         C[m * p.ldc + n] = v;
       }
     }
@@ -173,15 +182,32 @@ int launch(const GemmArgs& a, int splits, hipStream_t stream, const char* what, 
 
 }  // namespace
 
+static uint64_t dropout_stream_key(uint64_t seed, uint64_t tensor_id) {
+  return tt::splitmix_host(tt::splitmix_host(seed) ^ (tensor_id * 0xD6E8FEB86659FD93ull));
+}
+
 extern "C" int tt_dense_fwd_f32(const float* x, const float* w, const float* b, float* y, int64_t m, int32_t k,
                                 int32_t n, int32_t relu, tt_stream_t stream) {
+  return tt_dense_fwd_dropout_f32(x, w, b, y, m, k, n, relu, 0.f, 0, 0, 0, stream);
+}
+
+extern "C" int tt_dense_fwd_dropout_f32(const float* x, const float* w, const float* b, float* y, int64_t m, int32_t k,
+                                        int32_t n, int32_t relu, float drop_rate, uint64_t seed, uint64_t tensor_id,
+                                        uint64_t counter_offset, tt_stream_t stream) {
   TT_REQUIRE(x && w && y, "tt_dense_fwd_f32: null pointer");
+  TT_REQUIRE(drop_rate >= 0.f && drop_rate < 1.f, "tt_dense_fwd_dropout_f32: drop_rate must be in [0,1)");
   TT_REQUIRE(m > 0 && k > 0 && n > 0 && k % 4 == 0 && n % 4 == 0, "tt_dense_fwd_f32: need m>0, k%%4==0, n%%4==0 (m=%lld k=%d n=%d)",
              (long long)m, k, n);
   TT_REQUIRE(tt::aligned16(x) && tt::aligned16(w) && tt::aligned16(y), "tt_dense_fwd_f32: pointers must be 16-byte aligned");
   GemmArgs a{};
   a.A = x; a.B = w; a.C = y; a.M = m; a.N = n; a.K = k; a.lda = k; a.ldb = n; a.ldc = n;
   a.bias = b; a.relu = relu; a.k_per_split = (k + BK - 1) / BK * BK;
+  if (drop_rate > 0.f) {
+    a.drop_p24 = (uint32_t)((double)drop_rate * 16777216.0 + 0.5);
+    a.drop_scale = 1.0f / (1.0f - drop_rate);
+    a.drop_key = dropout_stream_key(seed, tensor_id);
+    a.drop_offset = counter_offset;
+  }
   return launch<true, false, false>(a, 1, tt::as_stream(stream), "tt_dense_fwd_f32", "dense_fwd");
 }
 
@@ -194,6 +220,12 @@ extern "C" int32_t tt_dense_bwd_num_slabs(int64_t m) {
 
 extern "C" int tt_dense_bwd_f32(const float* x, const float* w, const float* dz, float* dx, const float* dx_relu_src,
                                 float* dw_slabs, float* db_slabs, int64_t m, int32_t k, int32_t n, tt_stream_t stream_) {
+  return tt_dense_bwd_scaled_f32(x, w, dz, dx, dx_relu_src, 1.0f, dw_slabs, db_slabs, m, k, n, stream_);
+}
+
+extern "C" int tt_dense_bwd_scaled_f32(const float* x, const float* w, const float* dz, float* dx, const float* dx_relu_src,
+                                       float dx_scale, float* dw_slabs, float* db_slabs, int64_t m, int32_t k, int32_t n,
+                                       tt_stream_t stream_) {
   TT_REQUIRE(x && w && dz && dw_slabs && db_slabs, "tt_dense_bwd_f32: null pointer");
   TT_REQUIRE(m > 0 && k > 0 && n > 0 && k % 4 == 0 && n % 4 == 0, "tt_dense_bwd_f32: need m>0, k%%4==0, n%%4==0 (m=%lld k=%d n=%d)",
              (long long)m, k, n);
@@ -206,7 +238,7 @@ extern "C" int tt_dense_bwd_f32(const float* x, const float* w, const float* dz,
     // dx[m][k] = sum_n dz[m][n] * w[k][n]
     GemmArgs a{};
     a.A = dz; a.B = w; a.C = dx; a.M = m; a.N = k; a.K = n; a.lda = n; a.ldb = n; a.ldc = k;
-    a.mask_src = dx_relu_src; a.k_per_split = (n + BK - 1) / BK * BK;
+    a.mask_src = dx_relu_src; a.mask_scale = dx_scale; a.k_per_split = (n + BK - 1) / BK * BK;
     if ((rc = launch<true, true, false>(a, 1, stream, "tt_dense_bwd_f32(dx)", "dense_bwd_dx")) != TT_OK) return rc;
   }
   {

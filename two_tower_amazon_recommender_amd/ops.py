@@ -182,7 +182,8 @@ def sparse_update2_(opt: str, table_a, accum_a, grads_a, plan_a: SparsePlan,
 
 
 # ----------------------------------------------------------------------------- a2 dense layers
-def dense_fwd(x, w, b, relu: bool, out=None):
+def dense_fwd(x, w, b, relu: bool, out=None, dropout=None):
+    """y = act(x@w+b); ``dropout`` = (rate, seed, tensor_id, counter_offset) applies inverted dropout to y."""
     _chk(x, torch.float32, "x", 2)
     _chk(w, torch.float32, "w", 2)
     if b is not None:
@@ -195,7 +196,12 @@ def dense_fwd(x, w, b, relu: bool, out=None):
         out = torch.empty((m, n), dtype=torch.float32, device=x.device)
     _chk(out, torch.float32, "out", 2)
     lib = _lib.load()
-    _lib.check(lib.tt_dense_fwd_f32(_p(x), _p(w), _p(b), _p(out), m, k, n, int(relu), _stream()), "tt_dense_fwd_f32")
+    if dropout is None:
+        _lib.check(lib.tt_dense_fwd_f32(_p(x), _p(w), _p(b), _p(out), m, k, n, int(relu), _stream()), "tt_dense_fwd_f32")
+    else:
+        rate, seed, tid, off = dropout
+        _lib.check(lib.tt_dense_fwd_dropout_f32(_p(x), _p(w), _p(b), _p(out), m, k, n, int(relu), rate, seed, tid, off,
+                                                _stream()), "tt_dense_fwd_dropout_f32")
     return out
 
 
@@ -203,7 +209,7 @@ def dense_bwd_num_slabs(m: int) -> int:
     return int(_lib.load().tt_dense_bwd_num_slabs(m))
 
 
-def dense_bwd(x, w, dz, dx, dx_relu_src, dw_slabs, db_slabs):
+def dense_bwd(x, w, dz, dx, dx_relu_src, dw_slabs, db_slabs, dx_scale: float = 1.0):
     """dx = dz@w^T (* (dx_relu_src>0)); dw_slabs/db_slabs get the split-K partials."""
     _chk(x, torch.float32, "x", 2)
     _chk(w, torch.float32, "w", 2)
@@ -220,8 +226,8 @@ def dense_bwd(x, w, dz, dx, dx_relu_src, dw_slabs, db_slabs):
     if dw_slabs.numel() < ns * k * n or db_slabs.numel() < ns * n:
         raise RuntimeError("dense_bwd: slab buffers too small")
     lib = _lib.load()
-    _lib.check(lib.tt_dense_bwd_f32(_p(x), _p(w), _p(dz), _p(dx), _p(dx_relu_src), _p(dw_slabs), _p(db_slabs),
-                                    m, k, n, _stream()), "tt_dense_bwd_f32")
+    _lib.check(lib.tt_dense_bwd_scaled_f32(_p(x), _p(w), _p(dz), _p(dx), _p(dx_relu_src), dx_scale, _p(dw_slabs),
+                                           _p(db_slabs), m, k, n, _stream()), "tt_dense_bwd_scaled_f32")
     return ns
 
 

@@ -198,6 +198,8 @@ class ShardedTwoTowerTrainer:
         if negatives == "global":
             self.c_all = torch.empty(nc, sd, device=dev)
             self.dc_all = torch.empty(nc, sd, device=dev)
+        self.step_index = 0
+        self.dropout_seed = 0 if seed is None else seed
         if seed is not None:
             self.init_synthetic(seed)
 
@@ -233,8 +235,9 @@ class ShardedTwoTowerTrainer:
         b, w = cfg.batch_size, self.world
         self.user_emb.lookup(user_ids, ut.acts[0])
         self.item_emb.lookup(item_ids, it.acts[0])
-        q = ut.forward()
-        c = it.forward()
+        row0 = (self.step_index * w + self.rank) * b          # first global batch row of this rank
+        q = ut.forward((cfg.dropout_rate, self.dropout_seed, 0, row0))
+        c = it.forward((cfg.dropout_rate, self.dropout_seed, 1, row0))
         inv_t = 1.0 / cfg.temperature
         if self.negatives == "local" or w == 1:
             ops.retrieval_fwd_bwd(q, c, inv_t, self.ws, self.lse, self.per_row, self.loss, ut.dz[-1], it.dz[-1])
@@ -244,8 +247,9 @@ class ShardedTwoTowerTrainer:
             ops.retrieval_fwd_bwd(q, self.c_all, inv_t, self.ws, self.lse, self.per_row, self.loss, ut.dz[-1], self.dc_all,
                                   diag_offset=off)
             dist.reduce_scatter_tensor(it.dz[-1], self.dc_all, op=dist.ReduceOp.SUM, group=self.group)   # C5
-        ut.backward()
-        it.backward()
+        ut.backward(cfg.dropout_rate)
+        it.backward(cfg.dropout_rate)
+        self.step_index += 1
         if w == 1:
             ops.dense_update_(self._segs_reduce, cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon, apply=True)
         else:

@@ -56,11 +56,7 @@ def main(argv=None) -> int:
     else:
         user_idx, item_idx = datamod.read_interactions(args.data)
         n_users, n_items = int(user_idx.max()) + 1, int(item_idx.max()) + 1
-    # dropout 0.1 in the reference config is not implemented in the HIP path: say so, run with 0
-    cfg, loop = cfgmod.model_config_from_dict(doc, n_users, n_items, optimizer=args.optimizer, dropout_override=0.0)
-    if float(doc["model"].get("dropout_rate", 0.0)) != 0.0:
-        log.warning("dropout_rate %.2f in the config is ignored: dropout is not implemented in the HIP path yet",
-                    float(doc["model"]["dropout_rate"]))
+    cfg, loop = cfgmod.model_config_from_dict(doc, n_users, n_items, optimizer=args.optimizer)
     if args.batch_size:
         cfg.batch_size = args.batch_size
     epochs = args.epochs if args.epochs is not None else loop["epochs"]

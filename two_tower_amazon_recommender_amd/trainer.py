@@ -27,6 +27,7 @@ from . import ops
 # for the tests; the product does not import the oracle)
 TID_USER_TABLE, TID_ITEM_TABLE, TID_USER_IDS, TID_ITEM_IDS = 1, 2, 3, 4
 TID_DENSE_BASE = 16
+TID_DROPOUT_BASE = 64
 
 
 @dataclass
@@ -51,9 +52,8 @@ class TwoTowerConfig:
             raise ValueError("embedding_dim and tower dims must be multiples of 4")
         if self.tower_dims[-1] not in (32, 64, 128, 256):
             raise ValueError("the last tower dim (scorer dim) must be one of 32, 64, 128, 256")
-        if self.dropout_rate != 0.0:
-            raise NotImplementedError("dropout_rate > 0 is not implemented in the HIP path yet (SURVEY.md §7: "
-                                      "parity runs use rate 0)")
+        if not 0.0 <= self.dropout_rate < 1.0:
+            raise ValueError("dropout_rate must be in [0, 1)")
         if self.temperature <= 0:
             raise ValueError("temperature must be positive")
 
@@ -90,17 +90,29 @@ class Tower:
         dims = [cfg.embedding_dim] + list(cfg.tower_dims)
         return sum(dims[l] * dims[l + 1] + dims[l + 1] for l in range(len(cfg.tower_dims)))
 
-    def forward(self):
+    def forward(self, dropout=None):
+        """dropout = (rate, seed, tower_index, first_global_row) in training; None = inference (no dropout).
+        Inverted dropout follows every hidden (ReLU) layer, fused in the GEMM epilogue."""
         for l in range(self.n_layers):
-            ops.dense_fwd(self.acts[l], self.w[l], self.b[l], relu=(l < self.n_layers - 1), out=self.acts[l + 1])
+            hidden = l < self.n_layers - 1
+            d = None
+            if dropout is not None and hidden and dropout[0] > 0.0:
+                rate, seed, tower, row0 = dropout
+                d = (rate, seed, TID_DROPOUT_BASE + 2 * l + tower, row0 * self.dims[l + 1])
+            ops.dense_fwd(self.acts[l], self.w[l], self.b[l], relu=hidden, out=self.acts[l + 1], dropout=d)
         return self.acts[-1]
 
-    def backward(self):
+    def backward(self, dropout_rate: float = 0.0):
         """Consumes dz[-1]; leaves demb and the dw/db slabs."""
+        scale = 1.0
+        if dropout_rate > 0.0:      # the same f32 arithmetic as the forward kernel's launcher: 1.0f / (1.0f - rate)
+            one = torch.ones((), dtype=torch.float32)
+            scale = (one / (one - torch.tensor(dropout_rate, dtype=torch.float32))).item()
         for l in range(self.n_layers - 1, -1, -1):
             dx = self.dz[l - 1] if l > 0 else self.demb
-            mask_src = self.acts[l] if l > 0 else None       # acts[l] = ReLU output of layer l-1
-            ops.dense_bwd(self.acts[l], self.w[l], self.dz[l], dx, mask_src, self.dw_slabs[l], self.db_slabs[l])
+            mask_src = self.acts[l] if l > 0 else None       # acts[l] = (dropped-out) ReLU output of layer l-1
+            ops.dense_bwd(self.acts[l], self.w[l], self.dz[l], dx, mask_src, self.dw_slabs[l], self.db_slabs[l],
+                          dx_scale=scale if l > 0 else 1.0)
 
     def segments(self, l2: float, grad_flat=None, grad_offset: int = 0):
         segs = []
@@ -142,6 +154,8 @@ class TwoTowerTrainer:
         self.user_plan = ops.SparsePlan(b, dev)
         self.item_plan = ops.SparsePlan(b, dev)
         self._side = torch.cuda.Stream(device=dev)
+        self.step_index = 0                      # counter of the dropout stream (global batch row = step*batch + r)
+        self.dropout_seed = 0 if seed is None else seed
         self._segs = self.user_tower.segments(cfg.l2_regularization) + self.item_tower.segments(cfg.l2_regularization)
         if seed is not None:
             self.init_synthetic(seed)
@@ -176,14 +190,16 @@ class TwoTowerTrainer:
                          candidate_sampling_probability=None, candidate_ids=None):
         cfg, ut, it = self.cfg, self.user_tower, self.item_tower
         ops.embedding_gather2(self.user_table, user_ids, ut.acts[0], self.item_table, item_ids, it.acts[0], self.oob)
-        q = ut.forward()
-        c = it.forward()
+        row0 = self.step_index * cfg.batch_size
+        q = ut.forward((cfg.dropout_rate, self.dropout_seed, 0, row0))
+        c = it.forward((cfg.dropout_rate, self.dropout_seed, 1, row0))
         kw = dict(sample_weight=sample_weight, cand_prob=candidate_sampling_probability, cand_ids=candidate_ids)
         # loss + dq + dc in two fused passes over the logits (never materialised)
         ops.retrieval_fwd_bwd(q, c, 1.0 / cfg.temperature, self.ws, self.lse, self.per_row, self.loss,
                               ut.dz[-1], it.dz[-1], **kw)
-        ut.backward()
-        it.backward()
+        ut.backward(cfg.dropout_rate)
+        it.backward(cfg.dropout_rate)
+        self.step_index += 1
         return self.loss
 
     def apply_gradients(self):
@@ -233,6 +249,41 @@ class TwoTowerTrainer:
         if self.cfg.optimizer == "adagrad":
             self.user_accum.copy_(sd["user_accum"]); self.item_accum.copy_(sd["item_accum"])
             self.dense_accum.copy_(sd["dense_accum"])
+
+    # ------------------------------------------------------------------ HIP graph replay of the whole step
+    def capture_graph(self):
+        """Capture one train step (all ~25 launches, both streams) into a HIP graph.  ``step_graph(u, i)`` then
+        copies the ids into the captured buffers and replays: one host call per step, no launch gaps."""
+        if self.cfg.dropout_rate > 0.0:
+            raise NotImplementedError("graph replay with dropout: the per-step counter is a kernel argument")
+        b = self.cfg.batch_size
+        self._g_uid = torch.zeros(b, dtype=torch.int64, device=self.dev)
+        self._g_iid = torch.zeros(b, dtype=torch.int64, device=self.dev)
+        state = [t.clone() for t in (self.user_table[:1], self.item_table[:1], self.dense_flat)]
+        acc = None
+        if self.cfg.optimizer == "adagrad":
+            acc = [t.clone() for t in (self.user_accum[:1], self.item_accum[:1], self.dense_accum)]
+        s = torch.cuda.Stream(device=self.dev)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self.step(self._g_uid, self._g_iid)          # warm-up on the capture stream (ids 0: touches row 0 only)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self.step(self._g_uid, self._g_iid)
+        torch.cuda.synchronize()
+        # undo the warm-up step's update (row 0 of both tables, dense parameters)
+        self.user_table[:1].copy_(state[0]); self.item_table[:1].copy_(state[1]); self.dense_flat.copy_(state[2])
+        if acc is not None:
+            self.user_accum[:1].copy_(acc[0]); self.item_accum[:1].copy_(acc[1]); self.dense_accum.copy_(acc[2])
+        return self
+
+    def step_graph(self, user_ids: torch.Tensor, item_ids: torch.Tensor) -> torch.Tensor:
+        self._g_uid.copy_(user_ids, non_blocking=True)
+        self._g_iid.copy_(item_ids, non_blocking=True)
+        self._graph.replay()
+        return self.loss
 
     def check_ids(self):
         """Host check of the out-of-range flag (TF's CPU gather raises InvalidArgumentError); synchronises."""
