@@ -52,7 +52,7 @@ const char* tt_last_error(void);
  * tt_profile_enable("score_bwd,gather", 4096) makes every launch of the kernels carrying one
  * of those tags record a hipEvent pair on ITS OWN stream (capacity = launches kept per tag);
  * tags: fill, gather, sparse_plan, sparse_apply, dense_fwd, dense_bwd_dx, dense_bwd_dw,
- * dense_update, score_fwd, score_bwd, score_fused, score_aux, route, scatter_rows.  An empty string (or NULL) disables it.
+ * dense_update, score_fwd, score_bwd, score_fused, score_rank, score_aux, route, scatter_rows.  An empty string (or NULL) disables it.
  * tt_profile_read synchronises on the recorded events, writes up to `cap` durations in
  * milliseconds (launch order) to the HOST array `ms`, stores the number of launches seen in
  * *count (HOST) and clears the tag.  Disabled = one predictable branch per launch.           */
@@ -224,6 +224,14 @@ int tt_retrieval_fwd_bwd_f32(const float* q, const float* c, int64_t nq, int64_t
                              float grad_scale, void* workspace, int64_t workspace_bytes,
                              float* lse, float* per_row, float* loss, float* dq, float* dc,
                              tt_stream_t stream);
+
+/* Retrieval metrics (configs/data_config.yaml:71 top_k_eval; tfrs.metrics.FactorizedTopK's role):
+ * rank[i] = number of candidates j != pos_index[i] with s_ij > s_{i,pos_index[i]} over ALL nc candidates
+ * (nc may be the whole item corpus; nq <= or > nc both allowed).  Recall@K = mean(rank < K),
+ * NDCG@K = mean([rank < K] / log2(rank + 2)).  Same workspace size as the loss entry points.           */
+int tt_retrieval_rank_f32(const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
+                          float inv_temperature, const float* cand_prob, const int64_t* pos_index,
+                          void* workspace, int64_t workspace_bytes, int32_t* rank, tt_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -141,6 +141,18 @@ def retrieval_grad(q, c, temperature=None, sample_weight=None,
     return p @ c, p.T @ q
 
 
+def retrieval_rank_bounds(q, c, pos_index, temperature=None, candidate_sampling_probability=None, eps=1e-5):
+    """(lo, hi) bounds of rank_i = #{j != pos_i : s_ij > s_i,pos_i} in f64: lo counts logits above pos + eps,
+    hi those above pos - eps, so an f32 evaluation must land in [lo, hi]."""
+    q = np.asarray(q, dtype=np.float64)
+    c = np.asarray(c, dtype=np.float64)
+    s = retrieval_logits(q, c, temperature, candidate_sampling_probability)
+    n = s.shape[0]
+    pos = s[np.arange(n), pos_index]
+    s[np.arange(n), pos_index] = -np.inf
+    return (s > (pos + eps)[:, None]).sum(1), (s > (pos - eps)[:, None]).sum(1)
+
+
 # --------------------------------------------------------------------------- a5
 def dedup_sum(ids, grads):
     """IndexedSlices de-duplication: rows with equal id are summed, in ascending

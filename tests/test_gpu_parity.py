@@ -419,3 +419,25 @@ def test_scatter_rows(dev):
     ref = np.zeros((rows, d), dtype=np.float32)
     ref[idx[idx >= 0]] = src[idx >= 0]
     assert np.array_equal(dst.cpu().numpy(), ref)
+
+
+# ----------------------------------------------------------------------------------- retrieval metrics (rank pass)
+@pytest.mark.parametrize("nq,nc,d,use_p", [(256, 256, 32, False), (1000, 5000, 64, True), (300, 100, 128, False),
+                                           (2048, 50_000, 128, False), (77, 333, 256, True)])
+def test_retrieval_rank_and_topk_metrics(dev, nq, nc, d, use_p):
+    from two_tower_amazon_recommender_amd.metrics import FactorizedTopK
+    q = synth.uniform_f32(71, 1, nq * d, -0.3, 0.6).reshape(nq, d)
+    c = synth.uniform_f32(71, 2, nc * d, -0.3, 0.6).reshape(nc, d)
+    pos = synth.ids_uniform(71, 3, nq, nc)
+    q[::3] += 0.4 * c[pos[::3]]                                    # make a third of the positives rank well
+    p = synth.uniform_f32(71, 4, nc, 0.001, 0.3) if use_p else None
+    m = FactorizedTopK(ks=(1, 5, 10, 100), temperature=0.1)
+    rank = m.update_state(T(q, dev), T(c, dev), T(pos, dev), None if p is None else T(p, dev)).cpu().numpy()
+    lo, hi = tt.retrieval_rank_bounds(q, c, pos, temperature=0.1, candidate_sampling_probability=p)
+    assert (rank >= lo).all() and (rank <= hi).all(), (np.abs(rank - lo).max(), (hi - lo).max())
+    assert (hi - lo).mean() < 0.05                                  # the bounds are tight: this pins the rank
+    res = m.result()
+    for k in (1, 5, 10, 100):
+        assert abs(res[f"recall@{k}"] - (rank < k).mean()) < 1e-12
+        assert abs(res[f"ndcg@{k}"] - ((rank < k) / np.log2(rank + 2.0)).mean()) < 1e-9
+    assert res["recall@100"] >= res["recall@10"] >= res["recall@1"]

@@ -163,3 +163,27 @@ def test_train_cli_synthetic_runs_and_learns(dev, tmp_path):
     assert rc == 0 and ck.exists()
     sd = torch.load(ck, weights_only=True)
     assert sd["user_table"].shape == (2000, 32)
+
+
+def test_evaluate_topk_against_item_corpus(dev):
+    from two_tower_amazon_recommender_amd.metrics import FactorizedTopK
+    cfg, tr, ref = make(dev, 3000, 2500, 64, [64], 512, "adagrad", 13)
+    u, i = tr.synthetic_batch(13, 0, "Z")
+    for _ in range(30):
+        tr.step(u, i)                                               # memorise one batch
+    corpus = tr.item_corpus_embeddings()
+    assert corpus.shape == (2500, 64)
+    m = FactorizedTopK(ks=(1, 10, 100), temperature=0.1)
+    rank = tr.evaluate_topk(u, i, m, corpus)
+    # oracle: same tables/weights pulled from the device, f64 towers
+    ut, it = tr.user_table.cpu().numpy().astype(np.float64), tr.item_table.cpu().numpy().astype(np.float64)
+    q = tt.tower_fwd(ut[u.cpu().numpy()], [w.cpu().numpy().astype(np.float64) for w in tr.user_tower.w],
+                     [b.cpu().numpy().astype(np.float64) for b in tr.user_tower.b])[-1]
+    c = tt.tower_fwd(it, [w.cpu().numpy().astype(np.float64) for w in tr.item_tower.w],
+                     [b.cpu().numpy().astype(np.float64) for b in tr.item_tower.b])[-1]
+    assert np.abs(corpus.cpu().numpy() - c).max() <= 1e-5
+    lo, hi = tt.retrieval_rank_bounds(q, c, i.cpu().numpy(), temperature=0.1, eps=1e-4)
+    r = rank.cpu().numpy()
+    assert (r >= lo).all() and (r <= hi).all()
+    res = m.result()
+    assert res["recall@100"] > 0.3                                  # trained pairs are retrievable

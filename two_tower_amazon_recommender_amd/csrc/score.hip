@@ -34,7 +34,7 @@ constexpr float kLog2e = 1.44269504088896340736f;
 constexpr float kLn2 = 0.69314718055994530942f;
 constexpr float kNegBig = -1.0e30f;   // log2-domain stand-in for -inf (tfrs uses finfo.min/100)
 
-enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2 };
+enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2, MODE_RANK = 3 };
 constexpr float kRescaleThr = 8.0f;   // FUSED: rescale the accumulators only when a row max grows by > 2^8 (p stays <= 256)
 
 struct ScoreArgs {
@@ -55,6 +55,8 @@ struct ScoreArgs {
   float* part_l;            // FWD [nsplit][n_r]
   float* pos2;              // FWD [n_r] positive logit (log2 domain)
   float* slab;              // BWD [nsplit][n_r][D]
+  const int64_t* pos_idx;   // optional [n_r]: explicit positive column per row (else r + diag)
+  int32_t* part_cnt;        // RANK [nsplit][n_r]: columns scoring strictly above the row's threshold a_r
 };
 
 template <int D>
@@ -98,11 +100,11 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void score_kernel(ScoreArg
 #pragma unroll
     for (int g = 0; g < NG; ++g) rf[g] = r_ok ? R4[2 * g] : f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const float ar = (MODE == MODE_BWD && p.a_r != nullptr && r_ok) ? p.a_r[r] : 0.f;
+  const float ar = ((MODE == MODE_BWD || MODE == MODE_RANK) && p.a_r != nullptr && r_ok) ? p.a_r[r] : 0.f;
   const float sr = (MODE == MODE_BWD && p.s_r != nullptr && r_ok) ? p.s_r[r] : 1.f;
   int64_t idr = 0;
   if constexpr (HAS_IDS) idr = r_ok ? p.id_r[r] : (int64_t)-1;
-  const int64_t cpos = r + p.diag;                  // this lane's positive column
+  const int64_t cpos = p.pos_idx != nullptr ? (r_ok ? p.pos_idx[r] : (int64_t)-1) : r + p.diag;   // positive column
 
   // ---- staging (global -> regs -> LDS, one tile ahead).  Thread `tid` moves float4 number
   // tid + 256*j of the tile (row = f / ROW4, col4 = f % ROW4): 32-bit offsets from one running pointer.
@@ -148,9 +150,10 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void score_kernel(ScoreArg
 
   // ---- per-lane state ----
   float run_m = kNegBig, run_l = 0.f, pos = 0.f;
+  int cnt = 0;
   bool have_pos = false;
   f32x16 G[NB];
-  if constexpr (MODE != MODE_FWD) {
+  if constexpr (MODE == MODE_BWD || MODE == MODE_FUSED) {
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void score_kernel(ScoreArg
   for (int t = 0; t < ntiles; ++t) {
     // FWD: prefetch the next tile at the top.  BWD: registers are tight (rf + G + X + coef), so the
     // prefetch is issued just before GEMM2, whose 16*NB MFMAs (>= 1.7 us at D=128) cover its latency.
-    if constexpr (MODE == MODE_FWD) { if (t + 1 < ntiles) load_tile(t + 1); }
+    if constexpr (MODE == MODE_FWD || MODE == MODE_RANK) { if (t + 1 < ntiles) load_tile(t + 1); }
     const float* T = smem + (t & 1) * BUF_F;
     const int64_t c0 = c_begin + 32 * (int64_t)t;
 
@@ -206,7 +209,13 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void score_kernel(ScoreArg
       }
     }
     // wave-uniform: does this tile hold the positive of any row of this wave?
-    const bool diag_tile = (c0 < r0w + p.diag + 32) && (c0 + 32 > r0w + p.diag);
+    bool diag_tile;
+    if (p.pos_idx != nullptr) {
+      const int64_t dd0 = cpos - c0;
+      diag_tile = __any(dd0 >= 0 && dd0 < 32) != 0;
+    } else {
+      diag_tile = (c0 < r0w + p.diag + 32) && (c0 + 32 > r0w + p.diag);
+    }
     // tile-local row (minus the lane half's +4h) of this lane's positive, or a value no row matches
     int dloc = -100;
     if (diag_tile) {
@@ -221,7 +230,14 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void score_kernel(ScoreArg
         dup[reg] = (idc[tt::acc_row(reg, 0)] == idr) && (tt::acc_row(reg, 0) != dloc);
     }
 
-    if constexpr (MODE == MODE_FWD) {
+    if constexpr (MODE == MODE_RANK) {
+      // rank of the positive = number of OTHER columns scoring strictly above the row's threshold (its own logit)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const float v = __builtin_fmaf(X[reg], p.c1, ac[reg]);
+        cnt += (v > ar && tt::acc_row(reg, 0) != dloc) ? 1 : 0;
+      }
+    } else if constexpr (MODE == MODE_FWD) {
       float t2[16];
       float mx = kNegBig;
 #pragma unroll
@@ -344,7 +360,10 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void score_kernel(ScoreArg
       if (have_pos) p.pos2[r] = pos;
     }
   }
-  if constexpr (MODE == MODE_FWD) {
+  if constexpr (MODE == MODE_RANK) {
+    const int total = cnt + __shfl_xor(cnt, 32);
+    if (r_ok && h == 0) p.part_cnt[(int64_t)split * p.n_r + r] = total;
+  } else if constexpr (MODE == MODE_FWD) {
     const float om = __shfl_xor(run_m, 32);
     const float ol = __shfl_xor(run_l, 32);
     const float M = fmaxf(run_m, om);
@@ -462,6 +481,35 @@ __global__ __launch_bounds__(256) void fused_combine_kernel(const float* __restr
   }
 }
 
+// thr[r] = c1 * <q_r, c_pos(r)> + bias[pos(r)]  (log2 domain): the positive's logit, 32 lanes per row
+__global__ __launch_bounds__(256) void pos_logit_kernel(const f32x4* __restrict__ q, const f32x4* __restrict__ c,
+                                                        const int64_t* __restrict__ pos_idx, const float* __restrict__ bias,
+                                                        int64_t nq, int64_t nc, int d4, float c1, float* __restrict__ thr) {
+  const int64_t row = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int lane = threadIdx.x & 31;
+  if (row >= nq) return;
+  const int64_t pc = pos_idx[row];
+  float acc = 0.f;
+  if (pc >= 0 && pc < nc) {
+    for (int k = lane; k < d4; k += 32) {
+      const f32x4 a = q[row * d4 + k], b = c[pc * d4 + k];
+      acc += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+    }
+  }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) thr[row] = (pc >= 0 && pc < nc) ? __builtin_fmaf(acc, c1, bias != nullptr ? bias[pc] : 0.f) : 3.0e38f;
+}
+
+__global__ __launch_bounds__(256) void rank_combine_kernel(const int32_t* __restrict__ part_cnt, int64_t n_r, int nsplit,
+                                                           int32_t* __restrict__ rank) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n_r) return;
+  int tot = 0;
+  for (int s = 0; s < nsplit; ++s) tot += part_cnt[(int64_t)s * n_r + r];
+  rank[r] = tot;
+}
+
 // loss = sum_r per_row[r], fixed order (one workgroup)
 __global__ __launch_bounds__(1024) void sum_rows_kernel(const float* __restrict__ per_row, int64_t n, float* __restrict__ loss) {
   __shared__ float red[1024];
@@ -537,7 +585,7 @@ int launch_score(const ScoreArgs& a, bool has_ids, hipStream_t stream) {
       raised = true;
     }
   }
-  tt::ProfScope prof(MODE == MODE_FWD ? "score_fwd" : (MODE == MODE_BWD ? "score_bwd" : "score_fused"), stream);
+  tt::ProfScope prof(MODE == MODE_FWD ? "score_fwd" : (MODE == MODE_BWD ? "score_bwd" : (MODE == MODE_FUSED ? "score_fused" : "score_rank")), stream);
   if (has_ids)
     hipLaunchKernelGGL((score_kernel<D, MODE, true>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
   else
@@ -749,4 +797,46 @@ extern "C" int tt_retrieval_fwd_bwd_f32(const float* q, const float* c, int64_t 
     if ((rc = tt::check_launch("reduce_slabs(dc)")) != TT_OK) return rc;
   }
   return TT_OK;
+}
+
+// Retrieval metric support (configs/data_config.yaml:71 top_k_eval): rank of each query's true
+// candidate among ALL nc candidates = number of other candidates with a strictly larger logit.  One fused pass over
+// the [nq, nc] logits (never materialised); Recall@K / NDCG@K follow from rank < K on the host side.
+extern "C" int tt_retrieval_rank_f32(const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
+                                     float inv_temperature, const float* cand_prob, const int64_t* pos_index,
+                                     void* workspace, int64_t workspace_bytes, int32_t* rank, tt_stream_t stream_) {
+  int rc = check_common("tt_retrieval_rank_f32", q, c, nq, nc, dim, 0, workspace, workspace_bytes);
+  if (rc != TT_OK && !(nq > nc)) return rc;
+  TT_REQUIRE(q && c && workspace && pos_index && rank, "tt_retrieval_rank_f32: null pointer");
+  TT_REQUIRE(nq > 0 && nc > 0, "tt_retrieval_rank_f32: nq and nc must be positive");
+  TT_REQUIRE(dim == 32 || dim == 64 || dim == 128 || dim == 256, "tt_retrieval_rank_f32: dim %d not in {32,64,128,256}", dim);
+  if (workspace_bytes < ws_layout(nq, nc, dim).total)
+    return tt::fail(TT_ERR_WORKSPACE, "tt_retrieval_rank_f32: workspace %lld < %lld bytes", (long long)workspace_bytes,
+                    (long long)ws_layout(nq, nc, dim).total);
+  hipStream_t stream = tt::as_stream(stream_);
+  const WsLayout w = ws_layout(nq, nc, dim);
+  char* ws = static_cast<char*>(workspace);
+  float* bias = reinterpret_cast<float*>(ws + w.off_bias);
+  float* thr = reinterpret_cast<float*>(ws + w.off_aq);
+  int32_t* part_cnt = reinterpret_cast<int32_t*>(ws + w.off_pm);
+  const float c1 = kLog2e * inv_temperature;
+  if (cand_prob != nullptr) {
+    hipLaunchKernelGGL(prob_bias_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, stream, cand_prob, bias, nc);
+    if ((rc = tt::check_launch("prob_bias")) != TT_OK) return rc;
+  }
+  const float* biasp = cand_prob != nullptr ? bias : nullptr;
+  hipLaunchKernelGGL(pos_logit_kernel, dim3((unsigned)((nq + 7) / 8)), dim3(256), 0, stream, reinterpret_cast<const f32x4*>(q),
+                     reinterpret_cast<const f32x4*>(c), pos_index, biasp, nq, nc, dim / 4, c1, thr);
+  if ((rc = tt::check_launch("pos_logit")) != TT_OK) return rc;
+  ScoreArgs a{};
+  a.R = q; a.K = c; a.n_r = nq; a.n_c = nc; a.diag = 0;
+  a.c1 = c1;
+  a.a_r = thr; a.a_c = biasp;
+  a.pos_idx = pos_index;
+  a.nsplit = w.ns_q;
+  a.c_per_split = align_up((nc + a.nsplit - 1) / a.nsplit, 32);
+  a.part_cnt = part_cnt;
+  if ((rc = dispatch_score<MODE_RANK>(dim, a, false, stream)) != TT_OK) return rc;
+  hipLaunchKernelGGL(rank_combine_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, part_cnt, nq, a.nsplit, rank);
+  return tt::check_launch("rank_combine");
 }

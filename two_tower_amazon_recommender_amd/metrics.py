@@ -1,0 +1,48 @@
+"""Retrieval metrics over a candidate corpus — the role of ``tfrs.metrics.FactorizedTopK`` for the keys the
+reference names (``/root/reference/configs/data_config.yaml:71`` ``top_k_eval: [1, 5, 10, 20, 50, 100]``;
+``README.md:80`` quotes Recall@10 / NDCG@10).  The rank of every query's true candidate is computed by one fused
+pass of the scorer kernel over all candidates (``tt_retrieval_rank_f32``): no [queries x corpus] score matrix and
+no top-k extraction — Recall@K = mean(rank < K), NDCG@K = mean([rank < K] / log2(rank + 2)).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+class FactorizedTopK:
+    def __init__(self, ks=(1, 5, 10, 20, 50, 100), temperature: float | None = None):
+        self.ks = tuple(int(k) for k in ks)
+        self.inv_t = 1.0 if temperature is None else 1.0 / temperature
+        self.reset_state()
+
+    def reset_state(self):
+        self._n = 0
+        self._hits = None
+        self._dcg = None
+
+    def update_state(self, query_embeddings: torch.Tensor, candidate_embeddings: torch.Tensor,
+                     true_candidate_index: torch.Tensor, candidate_sampling_probability=None) -> torch.Tensor:
+        """Accumulates the metrics of one query batch against the candidate corpus; returns the int32 ranks."""
+        rank = ops.retrieval_rank(query_embeddings.contiguous(), candidate_embeddings.contiguous(), self.inv_t,
+                                  true_candidate_index.contiguous(), cand_prob=candidate_sampling_probability)
+        r = rank.to(torch.float64)
+        ks = torch.tensor(self.ks, dtype=torch.float64, device=r.device)
+        inside = (r[:, None] < ks[None, :]).to(torch.float64)                   # [nq, len(ks)]
+        gain = 1.0 / torch.log2(r + 2.0)
+        hits, dcg = inside.sum(0), (inside * gain[:, None]).sum(0)
+        self._hits = hits if self._hits is None else self._hits + hits
+        self._dcg = dcg if self._dcg is None else self._dcg + dcg
+        self._n += r.numel()
+        return rank
+
+    def result(self) -> dict:
+        if not self._n:
+            return {}
+        hits, dcg = (self._hits / self._n).tolist(), (self._dcg / self._n).tolist()
+        out = {}
+        for k, h, d in zip(self.ks, hits, dcg):
+            out[f"recall@{k}"] = h
+            out[f"ndcg@{k}"] = d          # one relevant item per query: the ideal DCG is 1
+        return out

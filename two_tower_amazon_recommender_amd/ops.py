@@ -295,3 +295,21 @@ def retrieval_fwd_bwd(q, c, inv_temperature: float, workspace, lse, per_row, los
                                             workspace.numel(), _p(lse), _p(per_row), _p(loss), _p(dq), _p(dc), _stream()),
                "tt_retrieval_fwd_bwd_f32")
     return loss
+
+
+def retrieval_rank(q, c, inv_temperature: float, pos_index, workspace=None, cand_prob=None, out=None):
+    """rank[i] = #candidates scoring strictly above query i's true candidate ``pos_index[i]`` (int32 [nq])."""
+    _chk(q, torch.float32, "query_embeddings", 2)
+    _chk(c, torch.float32, "candidate_embeddings", 2)
+    _chk(pos_index, torch.int64, "pos_index", 1)
+    if cand_prob is not None:
+        _chk(cand_prob, torch.float32, "candidate_sampling_probability", 1)
+    nq, nc, d = q.shape[0], c.shape[0], q.shape[1]
+    if workspace is None:
+        workspace = torch.empty(retrieval_workspace_bytes(nq, nc, d), dtype=torch.uint8, device=q.device)
+    if out is None:
+        out = torch.empty(nq, dtype=torch.int32, device=q.device)
+    lib = _lib.load()
+    _lib.check(lib.tt_retrieval_rank_f32(_p(q), _p(c), nq, nc, d, inv_temperature, _p(cand_prob), _p(pos_index),
+                                         _p(workspace), workspace.numel(), _p(out), _stream()), "tt_retrieval_rank_f32")
+    return out

@@ -233,6 +233,31 @@ class TwoTowerTrainer:
                   cand_ids=loss_kw.get("candidate_ids"))
         return ops.retrieval_fwd(q, c, 1.0 / cfg.temperature, self.ws, self.lse, self.per_row, self.loss, **kw)
 
+    # ------------------------------------------------------------------ retrieval metrics
+    @torch.no_grad()
+    def item_corpus_embeddings(self) -> torch.Tensor:
+        """Item-tower output for EVERY item row ([n_items, scorer_dim]), computed batch by batch on the tower's buffers."""
+        it, b = self.item_tower, self.cfg.batch_size
+        n = self.cfg.n_items
+        out = torch.empty(n, it.dims[-1], device=self.dev)
+        for s in range(0, n, b):
+            e = min(s + b, n)
+            it.acts[0][:e - s].copy_(self.item_table[s:e])
+            it.forward()
+            out[s:e].copy_(it.acts[-1][:e - s])
+        return out
+
+    @torch.no_grad()
+    def evaluate_topk(self, user_ids: torch.Tensor, item_ids: torch.Tensor, metric, corpus: torch.Tensor | None = None):
+        """Updates ``metric`` (metrics.FactorizedTopK) with one batch of (user, true item) pairs scored against the
+        whole item corpus; returns the ranks."""
+        if corpus is None:
+            corpus = self.item_corpus_embeddings()
+        ut = self.user_tower
+        ops.embedding_gather(self.user_table, user_ids, out=ut.acts[0], oob_flag=self.oob)
+        q = ut.forward()
+        return metric.update_state(q, corpus, item_ids)
+
     # ------------------------------------------------------------------ checkpoint (SURVEY.md §8f row 4)
     def state_dict(self) -> dict:
         sd = {"config": dict(self.cfg.__dict__), "user_table": self.user_table, "item_table": self.item_table,
