@@ -107,27 +107,60 @@ class ShardedEmbedding:
         self.flags = torch.zeros(2, dtype=torch.int32, device=device)   # [oob, overflow]
 
     def _a2a(self, out, inp):
+        """Asynchronous all-to-all (returns the work handle; None on one rank).  ``wait()`` on an NCCL work makes the
+        current stream wait for the collective without blocking the host, so independent kernels issued before
+        the wait overlap the transfer."""
         if self.world > 1:
-            dist.all_to_all_single(out, inp, group=self.group)
+            return dist.all_to_all_single(out, inp, group=self.group, async_op=True)
+        return None
 
-    # ---------------------------------------------------------------- forward / backward
+    @staticmethod
+    def _wait(work):
+        if work is not None:
+            work.wait()
+
+    # ---------------------------------------------------------------- forward, in three phases (so that the two
+    # tables' exchanges and the towers can be interleaved by the caller)
+    def lookup_start(self, ids: torch.Tensor):
+        """route + C1 (ids to their owners)."""
+        self.backend.route(ids, self.world, self.num_rows, self.cap, self.send_ids, self.pos_flat, self.flags)
+        self._w = self._a2a(self.recv_ids, self.send_ids)                          # C1
+
+    def lookup_rows(self):
+        """owner side: sort plan (side stream), K1 gather, C2 (rows back to the requesters)."""
+        self._wait(self._w)
+        be = self.backend
+        be.plan(self.recv_ids, self.table.shape[0])
+        be.gather(self.table, self.recv_ids, self.rows_out, self.flags[0:1])       # K1
+        self._w = self._a2a(self.rows_in, self.rows_out)                           # C2
+
+    def lookup_finish(self, out: torch.Tensor):
+        """K1': rows of this rank's positions."""
+        self._wait(self._w)
+        self.backend.gather(self.rows_in, self.pos_flat, out, None)
+        return out
+
     def lookup(self, ids: torch.Tensor, out: torch.Tensor):
         """out[p, :] = T[ids[p], :] for this rank's batch (route, C1, K1, C2, K1')."""
-        be = self.backend
-        be.route(ids, self.world, self.num_rows, self.cap, self.send_ids, self.pos_flat, self.flags)
-        self._a2a(self.recv_ids, self.send_ids)                                   # C1
-        be.plan(self.recv_ids, self.table.shape[0])                               # owner's sort, off the critical path
-        be.gather(self.table, self.recv_ids, self.rows_out, self.flags[0:1])      # K1 on the owner
-        self._a2a(self.rows_in, self.rows_out)                                    # C2
-        be.gather(self.rows_in, self.pos_flat, out, None)                         # K1': rows of my positions
-        return out
+        self.lookup_start(ids)
+        self.lookup_rows()
+        return self.lookup_finish(out)
+
+    # ---------------------------------------------------------------- backward, in two phases
+    def grads_start(self, grads: torch.Tensor):
+        """K2' + C3: per-position gradient rows to the owners (padding slots are never read)."""
+        self.backend.scatter_rows(grads, self.pos_flat, self.rows_in)
+        self._w = self._a2a(self.rows_out, self.rows_in)                           # C3
+
+    def grads_finish(self, opt: str, lr: float, eps: float = 1e-7):
+        """K2: fused sparse update on the owner (duplicates summed first, in (source rank, position) order)."""
+        self._wait(self._w)
+        self.backend.apply(opt, self.table, self.accum, self.recv_ids, self.rows_out, lr, eps)
 
     def apply_gradients(self, grads: torch.Tensor, opt: str, lr: float, eps: float = 1e-7):
         """grads[p, :] = dLoss/d(out[p, :]) of the last lookup (K2', C3, K2)."""
-        be = self.backend
-        be.scatter_rows(grads, self.pos_flat, self.rows_in)                       # K2' (padding slots are never read)
-        self._a2a(self.rows_out, self.rows_in)                                    # C3
-        be.apply(opt, self.table, self.accum, self.recv_ids, self.rows_out, lr, eps)   # K2
+        self.grads_start(grads)
+        self.grads_finish(opt, lr, eps)
 
     def check(self):
         """Host check (synchronises): out-of-range ids (TF's gather raises) and exchange-buffer overflow."""
@@ -233,10 +266,16 @@ class ShardedTwoTowerTrainer:
         """One train step on this rank's batch; returns this rank's (device, unsynchronised) loss."""
         cfg, ops, ut, it = self.cfg, self.ops, self.user_tower, self.item_tower
         b, w = cfg.batch_size, self.world
-        self.user_emb.lookup(user_ids, ut.acts[0])
-        self.item_emb.lookup(item_ids, it.acts[0])
+        ue, ie = self.user_emb, self.item_emb
+        # both tables' exchanges are in flight together; the item rows travel while the user tower computes
+        ue.lookup_start(user_ids)
+        ie.lookup_start(item_ids)
+        ue.lookup_rows()
+        ie.lookup_rows()
+        ue.lookup_finish(ut.acts[0])
         row0 = (self.step_index * w + self.rank) * b          # first global batch row of this rank
         q = ut.forward((cfg.dropout_rate, self.dropout_seed, 0, row0))
+        ie.lookup_finish(it.acts[0])
         c = it.forward((cfg.dropout_rate, self.dropout_seed, 1, row0))
         inv_t = 1.0 / cfg.temperature
         if self.negatives == "local" or w == 1:
@@ -248,16 +287,21 @@ class ShardedTwoTowerTrainer:
                                   diag_offset=off)
             dist.reduce_scatter_tensor(it.dz[-1], self.dc_all, op=dist.ReduceOp.SUM, group=self.group)   # C5
         ut.backward(cfg.dropout_rate)
+        ue.grads_start(ut.demb)                               # user gradient rows travel during the item tower's backward
         it.backward(cfg.dropout_rate)
+        ie.grads_start(it.demb)
         self.step_index += 1
         if w == 1:
             ops.dense_update_(self._segs_reduce, cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon, apply=True)
+            ue.grads_finish(cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon)
+            ie.grads_finish(cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon)
         else:
             ops.dense_update_(self._segs_reduce, cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon, apply=False)
-            dist.all_reduce(self.dense_grad, op=dist.ReduceOp.SUM, group=self.group)           # C6
+            ar = dist.all_reduce(self.dense_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)   # C6
+            ue.grads_finish(cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon)
+            ie.grads_finish(cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon)
+            ar.wait()
             ops.dense_update_(self._segs_apply, cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon, apply=True)
-        self.user_emb.apply_gradients(ut.demb, cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon)
-        self.item_emb.apply_gradients(it.demb, cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon)
         return self.loss
 
     def check_ids(self):
