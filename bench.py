@@ -62,6 +62,16 @@ def cpu_share() -> int:
     return max(1, min(n, 16))
 
 
+def pmc_traffic(tag):
+    """HBM bytes per launch of kernel `tag` from the committed rocprofv3 --pmc summary (collected in separate passes,
+    MI355X_MICROARCH.md §HBM corrections applied; scratch/prof_pmc.sh + scratch/pmc_summary.py), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_cfg3_sgd.json")
+    try:
+        return json.load(open(path))["kernels"][tag].get("hbm_bytes_per_launch")
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def mean(xs):
     return sum(xs) / max(len(xs), 1)
 
@@ -158,6 +168,8 @@ def main():
 
     r_fused = roof(f"score_kernel<{sd},FUSED> (loss + dq pass; 1 launch/step; algorithmic 4*B^2*D)", 4.0 * b2d, t_fused)
     r_bwd = roof(f"score_kernel<{sd},BWD> (dc pass; 1 launch/step; algorithmic 2*B^2*D)", 2.0 * b2d, t_bwd)
+    if args.config == "cfg3" and args.optimizer == "sgd":          # the configuration the PMC passes were collected on
+        r_fused["traffic"], r_bwd["traffic"] = pmc_traffic("score_fused"), pmc_traffic("score_bwd")
     dominant, other = (r_fused, r_bwd) if t_fused >= t_bwd else (r_bwd, r_fused)
     dominant["other_pass"] = other
     if t_fused > 0 and t_bwd > 0:
@@ -179,7 +191,9 @@ def main():
         "roofline_hbm": {"bound": "hbm", "kernel": "gather2 + sparse_update2 (K1 + K2 apply; both tables; hipEvent brackets add "
                                                    "~3 us to kernels this short, see profiles/ for rocprof durations)",
                          "achieved": gs_bytes / t_gs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gs_bytes / t_gs / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "frac": gs_bytes / t_gs / 1e9 / HBM_PEAK_GBS,
+                         "traffic": ((pmc_traffic("gather") or 0) + (pmc_traffic("sparse_apply") or 0)) or None
+                         if (args.config == "cfg3" and args.optimizer == "sgd") else None,
                          "gather_us": mean(prof["gather"]) * 1e3, "sparse_apply_us": mean(prof["sparse_apply"]) * 1e3,
                          "sparse_plan_us_each_side_stream": mean(prof["sparse_plan"]) * 1e3, "algorithmic_bytes": gs_bytes},
         "loss_per_pair": loss / batch,

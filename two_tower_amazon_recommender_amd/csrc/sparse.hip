@@ -56,20 +56,24 @@ __global__ __launch_bounds__(256) void sparse_apply_kernel(ApplyArgs a, int dim4
 
   for (int c = l; c < dim4; c += lpr) {
     f32x4 g = grads[(int64_t)order[k] * dim4 + c];
-    // walk the run; two rows in flight
+    // walk the run in ascending position order (the f32 sum is sequential: bit-equal to np.add.at); eight independent
+    // row loads are in flight while a long run lasts (sorted ids: sid[j+7] == id implies the whole octet is the run)
     int64_t j = k + 1;
+    while (j + 7 < n_ids && sid[j + 7] == id) {
+      f32x4 r[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) r[u] = grads[(int64_t)order[j + u] * dim4 + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = __fadd_rn(g[e], r[u][e]);
+      j += 8;
+    }
     while (j < n_ids && sid[j] == id) {
-      const bool two = (j + 1 < n_ids) && (sid[j + 1] == id);
       const f32x4 g1 = grads[(int64_t)order[j] * dim4 + c];
-      f32x4 g2 = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (two) g2 = grads[(int64_t)order[j + 1] * dim4 + c];
 #pragma unroll
       for (int e = 0; e < 4; ++e) g[e] = __fadd_rn(g[e], g1[e]);
-      if (two) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) g[e] = __fadd_rn(g[e], g2[e]);
-      }
-      j += two ? 2 : 1;
+      ++j;
     }
     f32x4 w = table[id * dim4 + c];
     if constexpr (OPT == TT_OPT_SGD) {
