@@ -96,26 +96,31 @@ int tt_embedding_gather2_f32(const float* table_a, int64_t rows_a, const int64_t
  * Only the ids are needed, so the plan can run before / beside the forward pass.
  *
  * tt_sparse_{sgd,adagrad}_f32: for every distinct id u (rows >= num_rows are skipped):
- *   g  = sum of grads[p, :] over the positions p of u, in ascending p, sequential f32 adds
+ *   g  = sum of grads[p, :] over the positions p of u in ascending p.  Order of the f32 adds: the run of u in
+ *        the sorted list is cut at global multiples of 64 sorted slots; each piece is summed sequentially, then
+ *        the pieces are added in order (a run inside one 64-slot block is a plain sequential sum).
+ *   apply_ws: tt_sparse_apply_workspace_bytes(n_ids, dim) bytes per table, 256-byte aligned (piece sums).
  *   SGD:      w[u] = w[u] - fl(lr*g)
  *   Adagrad:  acc[u] += g*g ; w[u] -= fl(lr*g) / sqrt(acc[u] + eps)      (Keras 2.15)
  * In place.  The `2` forms update the user and the item table in one launch.             */
 int64_t tt_sparse_plan_workspace_bytes(int64_t n_ids);
+int64_t tt_sparse_apply_workspace_bytes(int64_t n_ids, int32_t dim);
 int tt_sparse_plan(const int64_t* ids, int64_t n_ids, int64_t num_rows,
                    void* workspace, int64_t workspace_bytes,
                    int64_t* sorted_ids, int32_t* order, tt_stream_t stream);
 int tt_sparse_sgd_f32(float* table, int64_t num_rows, int32_t dim,
                       const float* grads, const int64_t* sorted_ids, const int32_t* order,
-                      int64_t n_ids, float lr, tt_stream_t stream);
+                      int64_t n_ids, float lr, void* apply_ws, tt_stream_t stream);
 int tt_sparse_adagrad_f32(float* table, float* accum, int64_t num_rows, int32_t dim,
                           const float* grads, const int64_t* sorted_ids, const int32_t* order,
-                          int64_t n_ids, float lr, float eps, tt_stream_t stream);
+                          int64_t n_ids, float lr, float eps, void* apply_ws, tt_stream_t stream);
 int tt_sparse_update2_f32(int32_t opt,
                           float* table_a, float* accum_a, int64_t rows_a, const float* grads_a,
                           const int64_t* sorted_ids_a, const int32_t* order_a,
                           float* table_b, float* accum_b, int64_t rows_b, const float* grads_b,
                           const int64_t* sorted_ids_b, const int32_t* order_b,
-                          int32_t dim, int64_t n_ids, float lr, float eps, tt_stream_t stream);
+                          int32_t dim, int64_t n_ids, float lr, float eps,
+                          void* apply_ws_a, void* apply_ws_b, tt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Row-sharded tables (multi-GPU): requester-side routing for the all-to-all exchange.

@@ -154,16 +154,31 @@ def retrieval_rank_bounds(q, c, pos_index, temperature=None, candidate_sampling_
 
 
 # --------------------------------------------------------------------------- a5
+PIECE = 64      # sorted slots per piece (csrc/sparse.hip kPiece)
+
+
 def dedup_sum(ids, grads):
-    """IndexedSlices de-duplication: rows with equal id are summed, in ascending
-    position order (sequential accumulation in the array's dtype), exactly what
-    np.add.at does.  Returns (unique_ids ascending, summed rows)."""
+    """IndexedSlices de-duplication: rows with equal id are summed.  Order of the additions (it matters in f32, and
+    the GPU kernel is bit-exact against this): stable-sort the positions by id; the run of an id occupies
+    consecutive sorted slots; cut it at global multiples of PIECE slots; sum each piece sequentially in slot
+    (= ascending position) order; add the pieces in order.  A run inside one 64-slot block is a plain sequential
+    sum over ascending positions (what np.add.at alone would do).  Returns (unique_ids ascending, summed rows)."""
     ids = np.asarray(ids)
-    uniq, inv = np.unique(ids, return_inverse=True)
-    out = np.zeros((uniq.shape[0], grads.shape[1]), dtype=grads.dtype)
-    # first occurrence initialises (0 + g == g exactly), later ones accumulate in order
-    np.add.at(out, inv, grads)
-    return uniq, out
+    n = len(ids)
+    if n == 0:
+        return ids[:0], grads[:0]
+    order = np.argsort(ids, kind="stable")
+    sid = ids[order]
+    head = np.ones(n, dtype=bool)
+    head[1:] = sid[1:] != sid[:-1]
+    run_idx = np.cumsum(head) - 1
+    piece_start = head | (np.arange(n) % PIECE == 0)
+    piece_idx = np.cumsum(piece_start) - 1
+    psum = np.zeros((piece_idx[-1] + 1, grads.shape[1]), dtype=grads.dtype)
+    np.add.at(psum, piece_idx, grads[order])             # sequential inside a piece (0 + g == g exactly)
+    out = np.zeros((run_idx[-1] + 1, grads.shape[1]), dtype=grads.dtype)
+    np.add.at(out, run_idx[piece_start], psum)           # pieces in order
+    return sid[head], out
 
 
 def sparse_sgd(table, ids, grads, lr):

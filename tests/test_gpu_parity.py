@@ -142,6 +142,30 @@ def test_sparse_update2_both_tables_one_launch(dev):
             assert np.allclose(da.cpu().numpy(), ra, rtol=3e-7, atol=0) and np.allclose(db.cpu().numpy(), rb, rtol=3e-7, atol=0)
 
 
+@pytest.mark.parametrize("opt", ["sgd", "adagrad"])
+def test_sparse_heavy_hitters_are_split_into_pieces_bit_exact(dev, opt):
+    """One id repeated thousands of times (runs far longer than 64 sorted slots, starting mid-block, several in a row)
+    must give exactly the oracle's piecewise sum — and fast (many lane groups work on one run)."""
+    rows, dim, n = 1000, 128, 20000
+    rng = np.random.default_rng(11)
+    ids = np.concatenate([np.full(7000, 17), np.full(129, 18), np.full(64, 400), np.full(5000, 999),
+                          rng.integers(0, rows, n - 7000 - 129 - 64 - 5000)]).astype(np.int64)
+    rng.shuffle(ids)
+    table = synth.embedding_table(25, 1, rows, dim)
+    grads = synth.uniform_f32(25, 9, n * dim, -1.0, 2.0).reshape(n, dim)
+    d_table = T(table, dev)
+    d_acc = torch.full_like(d_table, 0.1)
+    plan = ops.SparsePlan(n, dev).run(T(ids, dev), rows)
+    if opt == "sgd":
+        ops.sparse_sgd_(d_table, T(grads, dev), plan, lr=0.001)
+        ref = tt.sparse_sgd(table.copy(), ids, grads, 0.001)
+    else:
+        ops.sparse_adagrad_(d_table, d_acc, T(grads, dev), plan, lr=0.001)
+        ref, racc = tt.sparse_adagrad(table.copy(), np.full_like(table, np.float32(0.1)), ids, grads, 0.001)
+        assert np.array_equal(d_acc.cpu().numpy(), racc)
+    assert np.array_equal(d_table.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+
+
 def test_sparse_update_is_run_to_run_deterministic(dev):
     rows, dim, n = 1000, 128, 8192                     # heavy duplication
     table = synth.embedding_table(24, 1, rows, dim)

@@ -150,6 +150,32 @@ def test_sparse_optimizers_sum_duplicates_before_update():
     assert not np.allclose(a2[3], wrong)
 
 
+def test_dedup_sum_order_is_sequential_inside_a_block_and_piecewise_across():
+    rng = np.random.default_rng(7)
+    ids = np.concatenate([np.full(3, 5), np.full(200, 9), rng.integers(20, 40, 100)]).astype(np.int64)
+    rng.shuffle(ids)
+    g = rng.normal(size=(len(ids), 3)).astype(np.float32)
+    uniq, s = tt.dedup_sum(ids, g)
+    assert np.array_equal(uniq, np.unique(ids))
+    order = np.argsort(ids, kind="stable")
+    sid = ids[order]
+    # id 5: three rows, all inside sorted slots [0, 64): plain sequential sum in position order
+    p5 = np.flatnonzero(ids == 5)
+    assert np.array_equal(s[uniq == 5][0], (g[p5[0]] + g[p5[1]]) + g[p5[2]])
+    # id 9: 200 rows starting at sorted slot 3: pieces [3,64) [64,128) [128,192) [192,203)
+    slots = np.flatnonzero(sid == 9)
+    assert slots[0] == 3 and len(slots) == 200
+    pieces = [slots[(slots // 64) == b] for b in range(4)]
+    tot = None
+    for pc in pieces:
+        acc = g[order[pc[0]]].copy()
+        for k in pc[1:]:
+            acc = acc + g[order[k]]
+        tot = acc if tot is None else tot + acc
+    assert np.array_equal(s[uniq == 9][0], tot)
+    assert np.allclose(s[uniq == 9][0], g[ids == 9].astype(np.float64).sum(0), rtol=1e-5)
+
+
 def test_train_step_decreases_loss_cfg1_shape():
     st = tt.synthetic_state(seed=1001, n_users=1000, n_items=1000, emb_dim=32, tower_dims=[32], dtype=np.float64)
     uid = synth.ids_uniform(1001, synth.TID_USER_IDS, 256, 1000)

@@ -47,9 +47,10 @@ SIGNATURES = {
     "tt_scatter_rows_f32": (C.c_int, [_p, _p, _i64, _i32, _p, _i64, _p]),
     "tt_sparse_plan_workspace_bytes": (_i64, [_i64]),
     "tt_sparse_plan": (C.c_int, [_p, _i64, _i64, _p, _i64, _p, _p, _p]),
-    "tt_sparse_sgd_f32": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _i64, _f, _p]),
-    "tt_sparse_adagrad_f32": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _i64, _f, _f, _p]),
-    "tt_sparse_update2_f32": (C.c_int, [_i32, _p, _p, _i64, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _i32, _i64, _f, _f, _p]),
+    "tt_sparse_apply_workspace_bytes": (_i64, [_i64, _i32]),
+    "tt_sparse_sgd_f32": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _i64, _f, _p, _p]),
+    "tt_sparse_adagrad_f32": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _i64, _f, _f, _p, _p]),
+    "tt_sparse_update2_f32": (C.c_int, [_i32, _p, _p, _i64, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _i32, _i64, _f, _f, _p, _p, _p]),
     "tt_dense_fwd_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _i32, _p]),
     "tt_dense_fwd_dropout_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _i32, _f, _u64, _u64, _u64, _p]),
     "tt_dense_bwd_scaled_f32": (C.c_int, [_p, _p, _p, _p, _p, _f, _p, _p, _i64, _i32, _i32, _p]),

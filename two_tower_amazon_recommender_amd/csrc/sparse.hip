@@ -3,11 +3,13 @@
 // plan  : stable LSD radix sort of (id, position) by id (rocPRIM device radix sort — integer index
 //         plumbing; only the ids are needed, so it runs before / beside the forward pass).
 // apply : one group of dim/4 lanes per sorted slot.  A slot that starts a run of equal ids walks the
-//         run, summing the gradient rows in ascending position order (sequential f32 adds: the
-//         IndexedSlices de-duplication Keras performs before the update; bitwise reproducible and
-//         bit-equal to the oracle's np.add.at), then read-modify-writes the table row (and the
-//         Adagrad accumulator row) once.  Other slots exit.  No float atomics: Adagrad is
-//         non-linear in g, so duplicates MUST be summed first.
+//         run, summing the gradient rows in ascending position order (the IndexedSlices
+//         de-duplication Keras performs before the update; bitwise reproducible), then
+//         read-modify-writes the table row (and the Adagrad accumulator row) once.  Runs are cut
+//         into pieces at global multiples of 64 sorted slots so that a hot id is summed by many lane
+//         groups in parallel (pieces sequential inside, added in order by a small second launch);
+//         a run inside one 64-slot block is a plain sequential sum, bit-equal to np.add.at.
+//         No float atomics: Adagrad is non-linear in g, so duplicates MUST be summed first.
 // HBM-bound.  Algorithmic bytes per distinct row: 4*dim (grad) + 4*dim (row read) + 4*dim (row write)
 // [+ 8*dim accumulator read/write for Adagrad] + 12 (sorted id + position).
 #include "common.h"
@@ -25,6 +27,8 @@ int id_bits(int64_t num_rows) {
   return bits;
 }
 
+constexpr int kPiece = 64;   // sorted slots per piece: runs are cut at global multiples of 64 slots
+
 struct ApplyArgs {
   float* table[2];
   float* accum[2];
@@ -32,8 +36,36 @@ struct ApplyArgs {
   const int64_t* sorted_ids[2];
   const int32_t* order[2];
   int64_t rows[2];
+  // per-table piece workspace (tt_sparse_apply_workspace_bytes): sums of the pieces of runs that cross a 64-slot boundary
+  float* p_sum[2];      // [nblk][dim]  first piece of a run that continues past its block (head in block j)
+  float* s_sum[2];      // [nblk][dim]  piece starting exactly at slot 64*j
+  int32_t* p_flag[2];   // [nblk]       1 = block j holds the head of a deferred run
 };
 
+template <int OPT>
+__device__ __forceinline__ void update_row(f32x4* __restrict__ table, f32x4* __restrict__ accum, int64_t off, const f32x4& g,
+                                           float lr, float eps) {
+  f32x4 w = table[off];
+  if constexpr (OPT == TT_OPT_SGD) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = __fsub_rn(w[e], __fmul_rn(lr, g[e]));
+  } else {
+    f32x4 acc = accum[off];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc[e] = __fadd_rn(acc[e], __fmul_rn(g[e], g[e]));
+      const float den = sqrtf(__fadd_rn(acc[e], eps));
+      w[e] = __fsub_rn(w[e], __fdiv_rn(__fmul_rn(lr, g[e]), den));
+    }
+    accum[off] = acc;
+  }
+  table[off] = w;
+}
+
+// Summation order (the oracle's dedup_sum restates it): a run of equal ids occupies consecutive sorted slots; it is cut
+// into PIECES at global multiples of 64 slots; every piece is summed sequentially in slot (= ascending position) order,
+// then the pieces are added in order.  A run inside one 64-slot block — the common case — is a plain sequential sum
+// (bit-equal to np.add.at).  A hot id repeated thousands of times is summed by many lane groups in parallel.
 template <int OPT>
 __global__ __launch_bounds__(256) void sparse_apply_kernel(ApplyArgs a, int dim4, int lpr_log2, int64_t n_ids, float lr,
                                                            float eps) {
@@ -51,15 +83,19 @@ __global__ __launch_bounds__(256) void sparse_apply_kernel(ApplyArgs a, int dim4
   const int l = threadIdx.x & (lpr - 1);
   if (k >= n_ids) return;
   const int64_t id = sid[k];
-  if (k > 0 && sid[k - 1] == id) return;          // not the head of its run
-  if (id < 0 || id >= rows) return;               // out-of-range ids are skipped (flagged by the gather)
+  const bool run_head = (k == 0) || (sid[k - 1] != id);
+  const bool boundary = (k % kPiece) == 0;
+  if (!run_head && !boundary) return;             // inside a piece
+  if (id < 0 || id >= rows) return;               // out-of-range / padding ids are skipped (flagged by the gather)
+  int64_t pend = (k / kPiece + 1) * kPiece;       // this piece ends at the next 64-slot boundary at the latest
+  if (pend > n_ids) pend = n_ids;
+  const bool continues = (pend < n_ids) && (sid[pend] == id) && (sid[pend - 1] == id);
 
   for (int c = l; c < dim4; c += lpr) {
     f32x4 g = grads[(int64_t)order[k] * dim4 + c];
-    // walk the run in ascending position order (the f32 sum is sequential: bit-equal to np.add.at); eight independent
-    // row loads are in flight while a long run lasts (sorted ids: sid[j+7] == id implies the whole octet is the run)
+    // sequential walk; eight independent row loads in flight (sorted ids: sid[j+7] == id implies the whole octet)
     int64_t j = k + 1;
-    while (j + 7 < n_ids && sid[j + 7] == id) {
+    while (j + 7 < pend && sid[j + 7] == id) {
       f32x4 r[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) r[u] = grads[(int64_t)order[j + u] * dim4 + c];
@@ -69,31 +105,65 @@ __global__ __launch_bounds__(256) void sparse_apply_kernel(ApplyArgs a, int dim4
         for (int e = 0; e < 4; ++e) g[e] = __fadd_rn(g[e], r[u][e]);
       j += 8;
     }
-    while (j < n_ids && sid[j] == id) {
+    while (j < pend && sid[j] == id) {
       const f32x4 g1 = grads[(int64_t)order[j] * dim4 + c];
 #pragma unroll
       for (int e = 0; e < 4; ++e) g[e] = __fadd_rn(g[e], g1[e]);
       ++j;
     }
-    f32x4 w = table[id * dim4 + c];
-    if constexpr (OPT == TT_OPT_SGD) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) w[e] = __fsub_rn(w[e], __fmul_rn(lr, g[e]));
+    if (run_head && !continues) {
+      update_row<OPT>(table, accum, id * dim4 + c, g, lr, eps);           // whole run summed: fused update
+    } else if (run_head) {
+      reinterpret_cast<f32x4*>(a.p_sum[t])[(k / kPiece) * dim4 + c] = g;  // first piece of a long run
     } else {
-      f32x4 acc = accum[id * dim4 + c];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        acc[e] = __fadd_rn(acc[e], __fmul_rn(g[e], g[e]));
-        const float den = sqrtf(__fadd_rn(acc[e], eps));
-        w[e] = __fsub_rn(w[e], __fdiv_rn(__fmul_rn(lr, g[e]), den));
-      }
-      accum[id * dim4 + c] = acc;
+      reinterpret_cast<f32x4*>(a.s_sum[t])[(k / kPiece) * dim4 + c] = g;  // later piece (starts at slot 64*(k/64))
     }
-    table[id * dim4 + c] = w;
+  }
+  if (run_head && continues && l == 0) a.p_flag[t][k / kPiece] = 1;
+}
+
+// second launch: one lane group per 64-slot block; a block that holds the head of a deferred run adds the run's pieces in
+// order and applies the update.  (Almost always nothing to do.)
+template <int OPT>
+__global__ __launch_bounds__(256) void sparse_finish_kernel(ApplyArgs a, int dim4, int lpr_log2, int64_t n_ids, int64_t nblk,
+                                                            float lr, float eps) {
+  const int t = blockIdx.y;
+  const int lpr = 1 << lpr_log2;
+  const int groups = 256 >> lpr_log2;
+  const int64_t j = (int64_t)blockIdx.x * groups + (threadIdx.x >> lpr_log2);   // block index
+  const int l = threadIdx.x & (lpr - 1);
+  if (j >= nblk || a.p_flag[t][j] == 0) return;
+  const int64_t* __restrict__ sid = a.sorted_ids[t];
+  const int64_t id = sid[(j + 1) * kPiece - 1];   // the deferred run reaches the end of block j
+  const f32x4* __restrict__ P = reinterpret_cast<const f32x4*>(a.p_sum[t]);
+  const f32x4* __restrict__ S = reinterpret_cast<const f32x4*>(a.s_sum[t]);
+  for (int c = l; c < dim4; c += lpr) {
+    f32x4 g = P[j * dim4 + c];
+    for (int64_t m = j + 1; m < nblk && sid[m * kPiece] == id; ++m) {
+      const f32x4 s = S[m * dim4 + c];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] = __fadd_rn(g[e], s[e]);
+    }
+    update_row<OPT>(reinterpret_cast<f32x4*>(a.table[t]), reinterpret_cast<f32x4*>(a.accum[t]), id * dim4 + c, g, lr, eps);
   }
 }
 
-int launch_apply(int opt, const ApplyArgs& a, int n_tables, int32_t dim, int64_t n_ids, float lr, float eps,
+int64_t align_up(int64_t x, int64_t a);
+
+struct PieceWs {
+  int64_t nblk, off_p, off_s, off_flag, total;
+};
+PieceWs piece_ws(int64_t n_ids, int32_t dim) {
+  PieceWs w{};
+  w.nblk = (n_ids + kPiece - 1) / kPiece;
+  w.off_flag = 0;
+  w.off_p = align_up(w.nblk * 4, 256);
+  w.off_s = w.off_p + align_up(w.nblk * (int64_t)dim * 4, 256);
+  w.total = w.off_s + align_up(w.nblk * (int64_t)dim * 4, 256);
+  return w;
+}
+
+int launch_apply(int opt, ApplyArgs a, void* const ws[2], int n_tables, int32_t dim, int64_t n_ids, float lr, float eps,
                  hipStream_t stream, const char* what) {
   if (n_ids == 0) return TT_OK;
   const int dim4 = dim / 4;
@@ -102,13 +172,29 @@ int launch_apply(int opt, const ApplyArgs& a, int n_tables, int32_t dim, int64_t
   const int groups = 256 >> lpr_log2;
   const int64_t blocks = (n_ids + groups - 1) / groups;
   TT_REQUIRE(blocks <= 0x7fffffff, "%s: n_ids too large", what);
+  const PieceWs w = piece_ws(n_ids, dim);
+  for (int t = 0; t < n_tables; ++t) {
+    TT_REQUIRE(ws[t] != nullptr && (reinterpret_cast<uintptr_t>(ws[t]) & 255u) == 0, "%s: apply workspace must be non-null, 256-byte aligned", what);
+    char* base = static_cast<char*>(ws[t]);
+    a.p_flag[t] = reinterpret_cast<int32_t*>(base + w.off_flag);
+    a.p_sum[t] = reinterpret_cast<float*>(base + w.off_p);
+    a.s_sum[t] = reinterpret_cast<float*>(base + w.off_s);
+    if (hipMemsetAsync(a.p_flag[t], 0, (size_t)w.nblk * 4, stream) != hipSuccess)
+      return tt::fail(TT_ERR_LAUNCH, "%s: hipMemsetAsync failed", what);
+  }
+  const int64_t fblocks = (w.nblk + groups - 1) / groups;
   tt::ProfScope prof("sparse_apply", stream);
-  if (opt == TT_OPT_SGD)
+  if (opt == TT_OPT_SGD) {
     hipLaunchKernelGGL(sparse_apply_kernel<TT_OPT_SGD>, dim3((unsigned)blocks, n_tables), dim3(256), 0, stream, a, dim4,
                        lpr_log2, n_ids, lr, eps);
-  else
+    hipLaunchKernelGGL(sparse_finish_kernel<TT_OPT_SGD>, dim3((unsigned)fblocks, n_tables), dim3(256), 0, stream, a, dim4,
+                       lpr_log2, n_ids, w.nblk, lr, eps);
+  } else {
     hipLaunchKernelGGL(sparse_apply_kernel<TT_OPT_ADAGRAD>, dim3((unsigned)blocks, n_tables), dim3(256), 0, stream, a,
                        dim4, lpr_log2, n_ids, lr, eps);
+    hipLaunchKernelGGL(sparse_finish_kernel<TT_OPT_ADAGRAD>, dim3((unsigned)fblocks, n_tables), dim3(256), 0, stream, a,
+                       dim4, lpr_log2, n_ids, w.nblk, lr, eps);
+  }
   return tt::check_launch(what);
 }
 
@@ -125,6 +211,11 @@ size_t sort_temp_bytes(int64_t n_ids) {
 }
 
 }  // namespace
+
+extern "C" int64_t tt_sparse_apply_workspace_bytes(int64_t n_ids, int32_t dim) {
+  if (n_ids <= 0 || dim <= 0) return 256;
+  return piece_ws(n_ids, dim).total;
+}
 
 extern "C" int64_t tt_sparse_plan_workspace_bytes(int64_t n_ids) {
   if (n_ids <= 0) return 256;
@@ -155,18 +246,19 @@ extern "C" int tt_sparse_plan(const int64_t* ids, int64_t n_ids, int64_t num_row
 }
 
 extern "C" int tt_sparse_sgd_f32(float* table, int64_t num_rows, int32_t dim, const float* grads, const int64_t* sorted_ids,
-                                 const int32_t* order, int64_t n_ids, float lr, tt_stream_t stream) {
+                                 const int32_t* order, int64_t n_ids, float lr, void* apply_ws, tt_stream_t stream) {
   TT_REQUIRE(n_ids >= 0 && num_rows > 0 && dim > 0 && dim % 4 == 0, "tt_sparse_sgd_f32: bad n_ids/num_rows/dim");
   TT_REQUIRE(n_ids == 0 || (table && grads && sorted_ids && order), "tt_sparse_sgd_f32: null pointer");
   TT_REQUIRE(tt::aligned16(table) && tt::aligned16(grads), "tt_sparse_sgd_f32: table/grads must be 16-byte aligned");
   ApplyArgs a{};
   a.table[0] = table; a.grads[0] = grads; a.sorted_ids[0] = sorted_ids; a.order[0] = order; a.rows[0] = num_rows;
-  return launch_apply(TT_OPT_SGD, a, 1, dim, n_ids, lr, 0.f, tt::as_stream(stream), "tt_sparse_sgd_f32");
+  void* const ws[2] = {apply_ws, nullptr};
+  return launch_apply(TT_OPT_SGD, a, ws, 1, dim, n_ids, lr, 0.f, tt::as_stream(stream), "tt_sparse_sgd_f32");
 }
 
 extern "C" int tt_sparse_adagrad_f32(float* table, float* accum, int64_t num_rows, int32_t dim, const float* grads,
                                      const int64_t* sorted_ids, const int32_t* order, int64_t n_ids, float lr, float eps,
-                                     tt_stream_t stream) {
+                                     void* apply_ws, tt_stream_t stream) {
   TT_REQUIRE(n_ids >= 0 && num_rows > 0 && dim > 0 && dim % 4 == 0, "tt_sparse_adagrad_f32: bad n_ids/num_rows/dim");
   TT_REQUIRE(n_ids == 0 || (table && accum && grads && sorted_ids && order), "tt_sparse_adagrad_f32: null pointer");
   TT_REQUIRE(tt::aligned16(table) && tt::aligned16(accum) && tt::aligned16(grads),
@@ -174,14 +266,15 @@ extern "C" int tt_sparse_adagrad_f32(float* table, float* accum, int64_t num_row
   ApplyArgs a{};
   a.table[0] = table; a.accum[0] = accum; a.grads[0] = grads; a.sorted_ids[0] = sorted_ids; a.order[0] = order;
   a.rows[0] = num_rows;
-  return launch_apply(TT_OPT_ADAGRAD, a, 1, dim, n_ids, lr, eps, tt::as_stream(stream), "tt_sparse_adagrad_f32");
+  void* const ws[2] = {apply_ws, nullptr};
+  return launch_apply(TT_OPT_ADAGRAD, a, ws, 1, dim, n_ids, lr, eps, tt::as_stream(stream), "tt_sparse_adagrad_f32");
 }
 
 extern "C" int tt_sparse_update2_f32(int32_t opt, float* table_a, float* accum_a, int64_t rows_a, const float* grads_a,
                                      const int64_t* sorted_ids_a, const int32_t* order_a, float* table_b, float* accum_b,
                                      int64_t rows_b, const float* grads_b, const int64_t* sorted_ids_b,
                                      const int32_t* order_b, int32_t dim, int64_t n_ids, float lr, float eps,
-                                     tt_stream_t stream) {
+                                     void* apply_ws_a, void* apply_ws_b, tt_stream_t stream) {
   TT_REQUIRE(opt == TT_OPT_SGD || opt == TT_OPT_ADAGRAD, "tt_sparse_update2_f32: unknown optimizer %d", opt);
   TT_REQUIRE(n_ids >= 0 && rows_a > 0 && rows_b > 0 && dim > 0 && dim % 4 == 0, "tt_sparse_update2_f32: bad sizes");
   TT_REQUIRE(n_ids == 0 || (table_a && grads_a && sorted_ids_a && order_a && table_b && grads_b && sorted_ids_b && order_b),
@@ -193,5 +286,6 @@ extern "C" int tt_sparse_update2_f32(int32_t opt, float* table_a, float* accum_a
   ApplyArgs a{};
   a.table[0] = table_a; a.accum[0] = accum_a; a.grads[0] = grads_a; a.sorted_ids[0] = sorted_ids_a; a.order[0] = order_a; a.rows[0] = rows_a;
   a.table[1] = table_b; a.accum[1] = accum_b; a.grads[1] = grads_b; a.sorted_ids[1] = sorted_ids_b; a.order[1] = order_b; a.rows[1] = rows_b;
-  return launch_apply(opt, a, 2, dim, n_ids, lr, eps, tt::as_stream(stream), "tt_sparse_update2_f32");
+  void* const ws[2] = {apply_ws_a, apply_ws_b};
+  return launch_apply(opt, a, ws, 2, dim, n_ids, lr, eps, tt::as_stream(stream), "tt_sparse_update2_f32");
 }

@@ -138,6 +138,14 @@ class SparsePlan:
         self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
         self.sorted_ids = torch.empty(n_ids, dtype=torch.int64, device=device)
         self.order = torch.empty(n_ids, dtype=torch.int32, device=device)
+        self._apply_ws = None
+
+    def apply_ws(self, dim: int) -> torch.Tensor:
+        """Piece-sum workspace of the apply kernels for rows of ``dim`` floats (allocated once)."""
+        need = int(_lib.load().tt_sparse_apply_workspace_bytes(self.n_ids, dim))
+        if self._apply_ws is None or self._apply_ws.numel() < need:
+            self._apply_ws = torch.empty(need, dtype=torch.uint8, device=self.sorted_ids.device)
+        return self._apply_ws
 
     def run(self, ids: torch.Tensor, num_rows: int) -> "SparsePlan":
         _chk(ids, torch.int64, "ids", 1)
@@ -154,7 +162,8 @@ def sparse_sgd_(table, grads, plan: SparsePlan, lr: float):
     _chk(grads, torch.float32, "grads", 2)
     lib = _lib.load()
     _lib.check(lib.tt_sparse_sgd_f32(_p(table), table.shape[0], table.shape[1], _p(grads), _p(plan.sorted_ids),
-                                     _p(plan.order), plan.n_ids, lr, _stream()), "tt_sparse_sgd_f32")
+                                     _p(plan.order), plan.n_ids, lr, _p(plan.apply_ws(table.shape[1])), _stream()),
+               "tt_sparse_sgd_f32")
     return table
 
 
@@ -164,8 +173,8 @@ def sparse_adagrad_(table, accum, grads, plan: SparsePlan, lr: float, eps: float
     _chk(grads, torch.float32, "grads", 2)
     lib = _lib.load()
     _lib.check(lib.tt_sparse_adagrad_f32(_p(table), _p(accum), table.shape[0], table.shape[1], _p(grads),
-                                         _p(plan.sorted_ids), _p(plan.order), plan.n_ids, lr, eps, _stream()),
-               "tt_sparse_adagrad_f32")
+                                         _p(plan.sorted_ids), _p(plan.order), plan.n_ids, lr, eps,
+                                         _p(plan.apply_ws(table.shape[1])), _stream()), "tt_sparse_adagrad_f32")
     return table
 
 
@@ -177,8 +186,8 @@ def sparse_update2_(opt: str, table_a, accum_a, grads_a, plan_a: SparsePlan,
                                          _p(plan_a.sorted_ids), _p(plan_a.order),
                                          _p(table_b), _p(accum_b), table_b.shape[0], _p(grads_b),
                                          _p(plan_b.sorted_ids), _p(plan_b.order),
-                                         table_a.shape[1], plan_a.n_ids, lr, eps, _stream()),
-               "tt_sparse_update2_f32")
+                                         table_a.shape[1], plan_a.n_ids, lr, eps, _p(plan_a.apply_ws(table_a.shape[1])),
+                                         _p(plan_b.apply_ws(table_b.shape[1])), _stream()), "tt_sparse_update2_f32")
 
 
 # ----------------------------------------------------------------------------- a2 dense layers

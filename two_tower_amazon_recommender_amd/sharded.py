@@ -29,11 +29,6 @@ import torch
 import torch.distributed as dist
 
 
-class _PlanView:
-    def __init__(self, sorted_ids, order):
-        self.sorted_ids, self.order, self.n_ids = sorted_ids, order, sorted_ids.numel()
-
-
 class HipRowBackend:
     """The product's row kernels (C ABI of include/twotower_hip.h).  No fallback."""
 
