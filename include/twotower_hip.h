@@ -99,7 +99,8 @@ int tt_embedding_gather2_f32(const float* table_a, int64_t rows_a, const int64_t
  *   g  = sum of grads[p, :] over the positions p of u in ascending p.  Order of the f32 adds: the run of u in
  *        the sorted list is cut at global multiples of 64 sorted slots; each piece is summed sequentially, then
  *        the pieces are added in order (a run inside one 64-slot block is a plain sequential sum).
- *   apply_ws: tt_sparse_apply_workspace_bytes(n_ids, dim) bytes per table, 256-byte aligned (piece sums).
+ *   apply_ws: tt_sparse_apply_workspace_bytes(n_ids, dim) bytes per table, 256-byte aligned (piece sums);
+ *        ZERO it once after allocation — the kernels leave it zeroed.
  *   SGD:      w[u] = w[u] - fl(lr*g)
  *   Adagrad:  acc[u] += g*g ; w[u] -= fl(lr*g) / sqrt(acc[u] + eps)      (Keras 2.15)
  * In place.  The `2` forms update the user and the item table in one launch.             */

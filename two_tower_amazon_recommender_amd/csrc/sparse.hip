@@ -67,7 +67,7 @@ __device__ __forceinline__ void update_row(f32x4* __restrict__ table, f32x4* __r
 // then the pieces are added in order.  A run inside one 64-slot block — the common case — is a plain sequential sum
 // (bit-equal to np.add.at).  A hot id repeated thousands of times is summed by many lane groups in parallel.
 template <int OPT>
-__global__ __launch_bounds__(256) void sparse_apply_kernel(ApplyArgs a, int dim4, int lpr_log2, int64_t n_ids, float lr,
+__global__ __launch_bounds__(256, 8) void sparse_apply_kernel(ApplyArgs a, int dim4, int lpr_log2, int64_t n_ids, float lr,
                                                            float eps) {
   const int t = blockIdx.y;
   f32x4* __restrict__ table = reinterpret_cast<f32x4*>(a.table[t]);
@@ -89,23 +89,33 @@ __global__ __launch_bounds__(256) void sparse_apply_kernel(ApplyArgs a, int dim4
   if (id < 0 || id >= rows) return;               // out-of-range / padding ids are skipped (flagged by the gather)
   int64_t pend = (k / kPiece + 1) * kPiece;       // this piece ends at the next 64-slot boundary at the latest
   if (pend > n_ids) pend = n_ids;
-  const bool continues = (pend < n_ids) && (sid[pend] == id) && (sid[pend - 1] == id);
+  int64_t e = k + 1;                              // end of this piece: one id load for the usual run of length 1,
+  if (e < pend && sid[e] == id) {                 // else a binary search (sorted ids): <= 6 dependent loads per piece
+    int64_t lo = e + 1, hi = pend;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (sid[mid] == id) lo = mid + 1; else hi = mid;
+    }
+    e = lo;
+  }
+  const bool continues = (e == pend) && (pend < n_ids) && (sid[pend] == id);
 
   for (int c = l; c < dim4; c += lpr) {
     f32x4 g = grads[(int64_t)order[k] * dim4 + c];
-    // sequential walk; eight independent row loads in flight (sorted ids: sid[j+7] == id implies the whole octet)
+    // sequential walk over [k, e); four independent row loads in flight (more would cost a wave of occupancy,
+    // which the random single-row case — almost every slot — needs more)
     int64_t j = k + 1;
-    while (j + 7 < pend && sid[j + 7] == id) {
-      f32x4 r[8];
+    while (j + 3 < e) {
+      f32x4 r[4];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) r[u] = grads[(int64_t)order[j + u] * dim4 + c];
+      for (int u = 0; u < 4; ++u) r[u] = grads[(int64_t)order[j + u] * dim4 + c];
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
+      for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) g[e] = __fadd_rn(g[e], r[u][e]);
-      j += 8;
+        for (int q = 0; q < 4; ++q) g[q] = __fadd_rn(g[q], r[u][q]);
+      j += 4;
     }
-    while (j < pend && sid[j] == id) {
+    while (j < e) {
       const f32x4 g1 = grads[(int64_t)order[j] * dim4 + c];
 #pragma unroll
       for (int e = 0; e < 4; ++e) g[e] = __fadd_rn(g[e], g1[e]);
@@ -133,6 +143,7 @@ __global__ __launch_bounds__(256) void sparse_finish_kernel(ApplyArgs a, int dim
   const int64_t j = (int64_t)blockIdx.x * groups + (threadIdx.x >> lpr_log2);   // block index
   const int l = threadIdx.x & (lpr - 1);
   if (j >= nblk || a.p_flag[t][j] == 0) return;
+  if (l == 0) a.p_flag[t][j] = 0;                  // leave the workspace zeroed for the next call
   const int64_t* __restrict__ sid = a.sorted_ids[t];
   const int64_t id = sid[(j + 1) * kPiece - 1];   // the deferred run reaches the end of block j
   const f32x4* __restrict__ P = reinterpret_cast<const f32x4*>(a.p_sum[t]);
@@ -179,8 +190,6 @@ int launch_apply(int opt, ApplyArgs a, void* const ws[2], int n_tables, int32_t 
     a.p_flag[t] = reinterpret_cast<int32_t*>(base + w.off_flag);
     a.p_sum[t] = reinterpret_cast<float*>(base + w.off_p);
     a.s_sum[t] = reinterpret_cast<float*>(base + w.off_s);
-    if (hipMemsetAsync(a.p_flag[t], 0, (size_t)w.nblk * 4, stream) != hipSuccess)
-      return tt::fail(TT_ERR_LAUNCH, "%s: hipMemsetAsync failed", what);
   }
   const int64_t fblocks = (w.nblk + groups - 1) / groups;
   tt::ProfScope prof("sparse_apply", stream);

@@ -144,7 +144,7 @@ class SparsePlan:
         """Piece-sum workspace of the apply kernels for rows of ``dim`` floats (allocated once)."""
         need = int(_lib.load().tt_sparse_apply_workspace_bytes(self.n_ids, dim))
         if self._apply_ws is None or self._apply_ws.numel() < need:
-            self._apply_ws = torch.empty(need, dtype=torch.uint8, device=self.sorted_ids.device)
+            self._apply_ws = torch.zeros(need, dtype=torch.uint8, device=self.sorted_ids.device)   # contract: zeroed once
         return self._apply_ws
 
     def run(self, ids: torch.Tensor, num_rows: int) -> "SparsePlan":
