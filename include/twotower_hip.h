@@ -52,7 +52,7 @@ const char* tt_last_error(void);
  * tt_profile_enable("score_bwd,gather", 4096) makes every launch of the kernels carrying one
  * of those tags record a hipEvent pair on ITS OWN stream (capacity = launches kept per tag);
  * tags: fill, gather, sparse_plan, sparse_apply, dense_fwd, dense_bwd_dx, dense_bwd_dw,
- * dense_update, score_fwd, score_bwd, score_fused, score_rank, score_aux, route, scatter_rows.  An empty string (or NULL) disables it.
+ * dense_update, score_fwd, score_bwd, score_fused, score_rank, score_aux, route, scatter_rows, encode_ids.  An empty string (or NULL) disables it.
  * tt_profile_read synchronises on the recorded events, writes up to `cap` durations in
  * milliseconds (launch order) to the HOST array `ms`, stores the number of launches seen in
  * *count (HOST) and clears the tag.  Disabled = one predictable branch per launch.           */
@@ -72,6 +72,16 @@ int tt_fill_uniform_rows_f32(float* dst, int64_t n_rows, int32_t dim, int64_t ro
 /* ids in [0,num_rows): variant TT_IDS_UNIFORM or TT_IDS_POWERLAW (floor(N*u^4)).        */
 int tt_fill_ids_i64(int64_t* dst, int64_t n, uint64_t seed, uint64_t tensor_id,
                     int64_t start, int64_t num_rows, int32_t variant, tt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a6/a7 — id encoding (scripts/data_processing/prepare_training_data.py:113-123,209-210 sorted(unique)+enumerate+map;
+ * src/data/preprocessor.py:478-491 LabelEncoder().fit_transform): codes[i] = rank of string i among the sorted
+ * DISTINCT strings, int64.  `rows` is an [n, width] uint8 matrix of UTF-8 bytes, zero-padded on the right, width a
+ * multiple of 8, no NUL inside a string (Python str order = code-point order = UTF-8 byte order; a shorter string
+ * that is a prefix sorts first, like the zero padding).  *n_unique (device int32, may be NULL) receives the vocabulary size. */
+int64_t tt_encode_ids_workspace_bytes(int64_t n);
+int tt_encode_ids_u8(const uint8_t* rows, int64_t n, int32_t width, void* workspace, int64_t workspace_bytes,
+                     int64_t* codes, int32_t* n_unique, tt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * a1 — embedding lookup (Keras Embedding / tf.gather; configs/data_config.yaml:55).

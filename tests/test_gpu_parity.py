@@ -465,3 +465,35 @@ def test_retrieval_rank_and_topk_metrics(dev, nq, nc, d, use_p):
         assert abs(res[f"recall@{k}"] - (rank < k).mean()) < 1e-12
         assert abs(res[f"ndcg@{k}"] - ((rank < k) / np.log2(rank + 2.0)).mean()) < 1e-9
     assert res["recall@100"] >= res["recall@10"] >= res["recall@1"]
+
+
+# ----------------------------------------------------------------------------------- a6/a7 id encoding on the GPU
+def test_gpu_id_encoder_reproduces_the_reference_golden(dev):
+    """PINNED: the golden file was produced by the reference's own create_user_item_mappings / LabelEncoder
+    (tests/golden/make_id_encoding_golden.py); the GPU encoder must reproduce it bit for bit."""
+    import pathlib
+    g = np.load(pathlib.Path(__file__).resolve().parent / "golden" / "id_encoding_small.npz")
+    for col, want in (("user_id", "user_idx"), ("parent_asin", "item_idx")):
+        vals = g[col].tolist()
+        codes, nuniq = ops.encode_ids(ops.strings_to_padded_bytes(vals).to(dev))
+        assert codes.dtype == torch.int64
+        assert np.array_equal(codes.cpu().numpy(), g[want])
+        assert np.array_equal(codes.cpu().numpy(), g[want.replace("idx", "id_encoded") if col == "user_id" else "item_id_encoded"])
+        assert nuniq.item() == len(set(vals))
+    cats = ["Unknown" if c == "<NaN>" else c for c in g["main_category"].tolist()]      # preprocessor.py:487 fillna("Unknown")
+    codes, _ = ops.encode_ids(ops.strings_to_padded_bytes(cats).to(dev))
+    assert np.array_equal(codes.cpu().numpy(), g["category_encoded"])
+
+
+def test_gpu_id_encoder_large_and_edge_cases(dev):
+    from oracle import id_encoding
+    rng = np.random.default_rng(3)
+    alphabet = list("ABCDEFGHJKLMNPQRSTUVWXYZ0123456789") + ["é", "中", "Ω"]
+    vocab = ["".join(rng.choice(alphabet, size=int(rng.integers(1, 30)))) for _ in range(20000)]
+    vocab += ["A", "AA", "AAA", "AAAAAAAA", "AAAAAAAAA", "B" * 40]                        # prefixes, chunk boundaries
+    vals = [vocab[i] for i in rng.integers(0, len(vocab), 300_000)]
+    want, voc = id_encoding.encode_ids(vals)
+    codes, nuniq = ops.encode_ids(ops.strings_to_padded_bytes(vals).to(dev))
+    assert np.array_equal(codes.cpu().numpy(), want) and nuniq.item() == len(voc)
+    codes, nuniq = ops.encode_ids(ops.strings_to_padded_bytes(["solo"]).to(dev))
+    assert codes.tolist() == [0] and nuniq.item() == 1

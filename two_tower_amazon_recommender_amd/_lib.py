@@ -41,6 +41,8 @@ SIGNATURES = {
     "tt_fill_uniform_f32": (C.c_int, [_p, _i64, _u64, _u64, _i64, _f, _f, _p]),
     "tt_fill_uniform_rows_f32": (C.c_int, [_p, _i64, _i32, _i64, _i64, _u64, _u64, _f, _f, _p]),
     "tt_fill_ids_i64": (C.c_int, [_p, _i64, _u64, _u64, _i64, _i64, _i32, _p]),
+    "tt_encode_ids_workspace_bytes": (_i64, [_i64]),
+    "tt_encode_ids_u8": (C.c_int, [_p, _i64, _i32, _p, _i64, _p, _p, _p]),
     "tt_embedding_gather_f32": (C.c_int, [_p, _i64, _i32, _p, _i64, _p, _p, _p]),
     "tt_embedding_gather2_f32": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _p, _p, _i32, _i64, _p, _p]),
     "tt_route_by_owner_i64": (C.c_int, [_p, _i64, _i32, _i64, _i32, _p, _p, _p, _p]),

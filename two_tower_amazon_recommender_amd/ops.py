@@ -70,6 +70,34 @@ def fill_ids_(dst: torch.Tensor, seed: int, tensor_id: int, num_rows: int, varia
     return dst
 
 
+# ----------------------------------------------------------------------------- a6/a7 id encoding
+def strings_to_padded_bytes(values) -> "torch.Tensor":
+    """Host helper: list of str -> zero-padded [n, width] uint8 matrix of UTF-8 bytes (width a multiple of 8)."""
+    import numpy as np
+    enc = [v.encode("utf-8") for v in values]
+    width = max(8, (max((len(b) for b in enc), default=1) + 7) // 8 * 8)
+    mat = np.zeros((len(enc), width), dtype=np.uint8)
+    for i, b in enumerate(enc):
+        if b"\0" in b:
+            raise ValueError("id strings must not contain NUL bytes")
+        mat[i, :len(b)] = np.frombuffer(b, dtype=np.uint8)
+    return torch.from_numpy(mat)
+
+
+def encode_ids(rows_u8: torch.Tensor):
+    """codes[i] = rank of row i among the sorted distinct rows (the reference's sorted-enumerate / LabelEncoder ids).
+    Returns (int64 codes [n], int32 n_unique [1]) on the device."""
+    _chk(rows_u8, torch.uint8, "rows_u8", 2)
+    n, width = rows_u8.shape
+    lib = _lib.load()
+    ws = torch.empty(int(lib.tt_encode_ids_workspace_bytes(n)), dtype=torch.uint8, device=rows_u8.device)
+    codes = torch.empty(n, dtype=torch.int64, device=rows_u8.device)
+    nuniq = torch.zeros(1, dtype=torch.int32, device=rows_u8.device)
+    _lib.check(lib.tt_encode_ids_u8(_p(rows_u8), n, width, _p(ws), ws.numel(), _p(codes), _p(nuniq), _stream()),
+               "tt_encode_ids_u8")
+    return codes, nuniq
+
+
 # ----------------------------------------------------------------------------- a1 gather
 def embedding_gather(table: torch.Tensor, ids: torch.Tensor, out: torch.Tensor | None = None,
                      oob_flag: torch.Tensor | None = None) -> torch.Tensor:
