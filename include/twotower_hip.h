@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TT_ABI_VERSION 1
+#define TT_ABI_VERSION 2
 
 enum {
   TT_OK = 0,
@@ -216,20 +216,35 @@ int tt_dense_update_f32(const tt_dense_seg* segs, int32_t n_segs, int32_t opt, i
  *
  * q [nq,dim], c [nc,dim] f32 row-major; dim in {32,64,128,256}; nq + diag_offset <= nc.
  * sample_weight [nq], cand_prob [nc], cand_ids [nc] (int64) may each be NULL.
+ * hard_thr [nq] (may be NULL): per-query thresholds from tt_retrieval_hard_negative_thresholds_f32 — only the
+ * positive and the negatives scoring at or above the threshold take part (tfrs num_hard_negatives).
  * Outputs: lse [nq], per_row [nq], loss [1]; dq [nq,dim], dc [nc,dim].
  * Workspace: tt_retrieval_workspace_bytes(nq, nc, dim) bytes, 256-byte aligned.          */
 int64_t tt_retrieval_workspace_bytes(int64_t nq, int64_t nc, int32_t dim);
 int tt_retrieval_fwd_f32(const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
                          int64_t diag_offset, float inv_temperature,
                          const float* sample_weight, const float* cand_prob, const int64_t* cand_ids,
+                         const float* hard_thr,
                          void* workspace, int64_t workspace_bytes,
                          float* lse, float* per_row, float* loss, tt_stream_t stream);
 int tt_retrieval_bwd_f32(const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
                          int64_t diag_offset, float inv_temperature,
                          const float* sample_weight, const float* cand_prob, const int64_t* cand_ids,
-                         const float* lse, float grad_scale,
+                         const float* hard_thr, const float* lse, float grad_scale,
                          void* workspace, int64_t workspace_bytes,
                          float* dq, float* dc, tt_stream_t stream);
+
+/* tfrs.tasks.Retrieval(num_hard_negatives=k) / tfrs.layers.loss.HardNegativeMining: thr[i] separates the k
+ * highest-scoring negatives of query i (after temperature, sampling-probability correction and accidental-hit
+ * removal) from the rest (midpoint between the k-th and the next lower logit; ties at the k-th value are all kept;
+ * fewer than k negatives: everything is kept).  scratch: nq*nc floats — the one place logits are materialised.    */
+int tt_retrieval_hard_negative_thresholds_f32(const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
+                                              int64_t diag_offset, float inv_temperature,
+                                              const float* cand_prob, const int64_t* cand_ids,
+                                              int32_t num_hard_negatives,
+                                              void* workspace, int64_t workspace_bytes,
+                                              float* scratch, int64_t scratch_bytes,
+                                              float* thr, tt_stream_t stream);
 
 /* Fused training form: loss AND both gradients in two passes over the logits instead of three
  * (pass 1: online softmax with the candidate-weighted sum -> lse, per_row, loss, dq;  pass 2: dc).
@@ -237,7 +252,7 @@ int tt_retrieval_bwd_f32(const float* q, const float* c, int64_t nq, int64_t nc,
 int tt_retrieval_fwd_bwd_f32(const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
                              int64_t diag_offset, float inv_temperature,
                              const float* sample_weight, const float* cand_prob, const int64_t* cand_ids,
-                             float grad_scale, void* workspace, int64_t workspace_bytes,
+                             const float* hard_thr, float grad_scale, void* workspace, int64_t workspace_bytes,
                              float* lse, float* per_row, float* loss, float* dq, float* dc,
                              tt_stream_t stream);
 

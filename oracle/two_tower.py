@@ -81,7 +81,7 @@ def tower_bwd(acts, weights, dy, masks=None, scale=1.0):
 
 # ------------------------------------------------------------------------ a3+a4
 def retrieval_logits(q, c, temperature=None, candidate_sampling_probability=None,
-                     candidate_ids=None, remove_accidental_hits=False, diag_offset=0):
+                     candidate_ids=None, remove_accidental_hits=False, diag_offset=0, num_hard_negatives=None):
     """Logits exactly as tfrs.tasks.Retrieval builds them.  Positive of query i
     is candidate ``i + diag_offset`` (diag_offset != 0 only for the sharded
     multi-GPU slab, where local queries face all-gathered candidates)."""
@@ -100,17 +100,32 @@ def retrieval_logits(q, c, temperature=None, candidate_sampling_probability=None
         dup = (cid[pos][:, None] == cid[None, :])
         dup[np.arange(nq), pos] = False
         s = np.where(dup, s + MIN_FLOAT, s)
+    if num_hard_negatives is not None:
+        # tfrs.layers.loss.HardNegativeMining: keep the positive and the k highest-scoring negatives of every row;
+        # everything else leaves the softmax (here: -inf).  Negatives tied with the k-th are all kept.
+        nq = s.shape[0]
+        pos = np.arange(nq) + diag_offset
+        neg = s.copy()
+        neg[np.arange(nq), pos] = -np.inf
+        if remove_accidental_hits:
+            neg[dup] = -np.inf
+        k = num_hard_negatives
+        if k < neg.shape[1]:
+            kth = np.partition(neg, neg.shape[1] - k, axis=1)[:, neg.shape[1] - k]      # k-th largest negative per row
+            drop = neg < kth[:, None]
+            drop[np.arange(nq), pos] = False
+            s = np.where(drop, -np.inf, s)
     return s
 
 
 def retrieval_loss(q, c, temperature=None, sample_weight=None,
                    candidate_sampling_probability=None, candidate_ids=None,
-                   remove_accidental_hits=False, diag_offset=0, dtype=np.float64):
+                   remove_accidental_hits=False, diag_offset=0, dtype=np.float64, num_hard_negatives=None):
     """Returns (loss_sum, per_row_loss, lse).  loss = sum_i w_i (lse_i - s_ii)."""
     q = np.asarray(q, dtype=dtype)
     c = np.asarray(c, dtype=dtype)
     s = retrieval_logits(q, c, temperature, candidate_sampling_probability,
-                         candidate_ids, remove_accidental_hits, diag_offset)
+                         candidate_ids, remove_accidental_hits, diag_offset, num_hard_negatives)
     nq = s.shape[0]
     m = s.max(axis=1, keepdims=True)
     lse = (m + np.log(np.exp(s - m).sum(axis=1, keepdims=True)))[:, 0]
@@ -123,12 +138,12 @@ def retrieval_loss(q, c, temperature=None, sample_weight=None,
 
 def retrieval_grad(q, c, temperature=None, sample_weight=None,
                    candidate_sampling_probability=None, candidate_ids=None,
-                   remove_accidental_hits=False, diag_offset=0, dtype=np.float64):
+                   remove_accidental_hits=False, diag_offset=0, dtype=np.float64, num_hard_negatives=None):
     """d(loss_sum)/dq, d(loss_sum)/dc."""
     q = np.asarray(q, dtype=dtype)
     c = np.asarray(c, dtype=dtype)
     s = retrieval_logits(q, c, temperature, candidate_sampling_probability,
-                         candidate_ids, remove_accidental_hits, diag_offset)
+                         candidate_ids, remove_accidental_hits, diag_offset, num_hard_negatives)
     nq = s.shape[0]
     m = s.max(axis=1, keepdims=True)
     p = np.exp(s - m)

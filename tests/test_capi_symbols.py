@@ -37,7 +37,7 @@ def test_invalid_args_return_codes_without_gpu():
     rc = lib.tt_embedding_gather_f32(None, 10, 6, None, 4, None, None, None)   # dim % 4 != 0
     assert rc == _lib.TT_ERR_INVALID_ARG
     assert b"multiple of 4" in lib.tt_last_error()
-    rc = lib.tt_retrieval_fwd_f32(None, None, 4, 4, 128, 0, 10.0, None, None, None, None, 0, None, None, None, None)
+    rc = lib.tt_retrieval_fwd_f32(None, None, 4, 4, 128, 0, 10.0, None, None, None, None, None, 0, None, None, None, None)
     assert rc == _lib.TT_ERR_INVALID_ARG
     rc = lib.tt_dense_fwd_f32(None, None, None, None, 8, 6, 8, 0, None)
     assert rc == _lib.TT_ERR_INVALID_ARG

@@ -62,8 +62,8 @@ def test_parquet_reader_accepts_both_reference_encodings(tmp_path):
 
 
 def test_retrieval_task_argument_errors_mirror_tfrs():
-    with pytest.raises(NotImplementedError):
-        Retrieval(num_hard_negatives=5)
+    with pytest.raises(ValueError):
+        Retrieval(num_hard_negatives=0)
     with pytest.raises(NotImplementedError):
         Retrieval(metrics=object())
     with pytest.raises(ValueError):

@@ -97,6 +97,25 @@ def test_retrieval_loss_and_grad_match_torch_cpu(opts):
     assert np.allclose(dq, tdq, rtol=1e-9, atol=1e-12) and np.allclose(dc, tdc, rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.parametrize("k", [1, 5, 40])
+def test_hard_negative_mining_matches_topk_restatement(k):
+    """tfrs.layers.loss.HardNegativeMining restated with torch.topk: logits + labels*MAX, top (k+1), gather, CE."""
+    rng = np.random.default_rng(4)
+    nq, nc, d, T = 23, 31, 8, 0.2
+    q, c = rng.normal(size=(nq, d)), rng.normal(size=(nc, d))
+    loss, per_row, _ = tt.retrieval_loss(q, c, temperature=T, num_hard_negatives=k)
+    dq, dc = tt.retrieval_grad(q, c, temperature=T, num_hard_negatives=k)
+    tq = torch.tensor(q, requires_grad=True); tc = torch.tensor(c, requires_grad=True)
+    s = tq @ tc.T / T
+    labels = torch.eye(nq, nc, dtype=torch.float64)
+    _, idx = torch.topk(s + labels * 1e30, k=min(k + 1, nc), dim=1, sorted=False)
+    sl, ll = torch.gather(s, 1, idx), torch.gather(labels, 1, idx)
+    tl = -(ll * torch.log_softmax(sl, dim=1)).sum()
+    tl.backward()
+    assert abs(loss - tl.item()) <= 1e-9 * abs(tl.item())
+    assert np.allclose(dq, tq.grad.numpy(), atol=1e-10) and np.allclose(dc, tc.grad.numpy(), atol=1e-10)
+
+
 def test_accidental_hits_require_ids():
     q = np.zeros((4, 8)); c = np.zeros((4, 8))
     with pytest.raises(ValueError, match="candidate ids must be supplied"):

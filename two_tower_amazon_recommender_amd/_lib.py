@@ -14,7 +14,7 @@ import threading
 
 _PKG = pathlib.Path(__file__).resolve().parent
 LIB_PATH = _PKG / "libtwotower_hip.so"
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 TT_OK, TT_ERR_INVALID_ARG, TT_ERR_LAUNCH, TT_ERR_UNSUPPORTED, TT_ERR_WORKSPACE = range(5)
 TT_OPT_SGD, TT_OPT_ADAGRAD = 0, 1
@@ -60,10 +60,11 @@ SIGNATURES = {
     "tt_dense_bwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
     "tt_dense_update_f32": (C.c_int, [C.POINTER(DenseSeg), _i32, _i32, _i32, _f, _f, _p]),
     "tt_retrieval_workspace_bytes": (_i64, [_i64, _i64, _i32]),
-    "tt_retrieval_fwd_f32": (C.c_int, [_p, _p, _i64, _i64, _i32, _i64, _f, _p, _p, _p, _p, _i64, _p, _p, _p, _p]),
-    "tt_retrieval_fwd_bwd_f32": (C.c_int, [_p, _p, _i64, _i64, _i32, _i64, _f, _p, _p, _p, _f, _p, _i64, _p, _p, _p, _p, _p, _p]),
+    "tt_retrieval_fwd_f32": (C.c_int, [_p, _p, _i64, _i64, _i32, _i64, _f, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p]),
+    "tt_retrieval_fwd_bwd_f32": (C.c_int, [_p, _p, _i64, _i64, _i32, _i64, _f, _p, _p, _p, _p, _f, _p, _i64, _p, _p, _p, _p, _p, _p]),
+    "tt_retrieval_hard_negative_thresholds_f32": (C.c_int, [_p, _p, _i64, _i64, _i32, _i64, _f, _p, _p, _i32, _p, _i64, _p, _i64, _p, _p]),
     "tt_retrieval_rank_f32": (C.c_int, [_p, _p, _i64, _i64, _i32, _f, _p, _p, _p, _i64, _p, _p]),
-    "tt_retrieval_bwd_f32": (C.c_int, [_p, _p, _i64, _i64, _i32, _i64, _f, _p, _p, _p, _p, _f, _p, _i64, _p, _p, _p]),
+    "tt_retrieval_bwd_f32": (C.c_int, [_p, _p, _i64, _i64, _i32, _i64, _f, _p, _p, _p, _p, _p, _f, _p, _i64, _p, _p, _p]),
 }
 
 _lock = threading.Lock()

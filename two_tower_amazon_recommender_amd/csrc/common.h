@@ -30,6 +30,8 @@ struct ProfScope {
   ~ProfScope() { if (g_prof_on) prof_record(tag, stream, true); }
 };
 
+int gemm_nt(const float* a, const float* b, float* c, int64_t m, int64_t n, int64_t k, hipStream_t stream);   // gemm.hip
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 #define TT_REQUIRE(cond, ...) do { if (!(cond)) return ::tt::fail(TT_ERR_INVALID_ARG, __VA_ARGS__); } while (0)

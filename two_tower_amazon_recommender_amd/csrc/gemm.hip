@@ -196,6 +196,16 @@ static uint64_t dropout_stream_key(uint64_t seed, uint64_t tensor_id) {
   return tt::splitmix_host(tt::splitmix_host(seed) ^ (tensor_id * 0xD6E8FEB86659FD93ull));
 }
 
+// c[m][n] = sum_k a[m][k] * b[n][k]   (both operands k-contiguous; used by the hard-negative threshold search)
+namespace tt {
+int gemm_nt(const float* a, const float* b, float* c, int64_t m, int64_t n, int64_t k, hipStream_t stream) {
+  GemmArgs g{};
+  g.A = a; g.B = b; g.C = c; g.M = m; g.N = n; g.K = k; g.lda = k; g.ldb = k; g.ldc = n;
+  g.mask_scale = 1.f; g.k_per_split = (k + BK - 1) / BK * BK;
+  return launch<true, true, false>(g, 1, stream, "gemm_nt", "score_aux");
+}
+}  // namespace tt
+
 extern "C" int tt_dense_fwd_f32(const float* x, const float* w, const float* b, float* y, int64_t m, int32_t k,
                                 int32_t n, int32_t relu, tt_stream_t stream) {
   return tt_dense_fwd_dropout_f32(x, w, b, y, m, k, n, relu, 0.f, 0, 0, 0, stream);

@@ -55,6 +55,8 @@ struct ScoreArgs {
   float* part_l;            // FWD [nsplit][n_r]
   float* pos2;              // FWD [n_r] positive logit (log2 domain)
   float* slab;              // BWD [nsplit][n_r][D]
+  const float* h_r;         // optional [n_r]: hard-negative threshold per row   (element kept iff t >= h or positive)
+  const float* h_c;         // optional [n_c]: hard-negative threshold per column (same domain as the masked value t)
   const int64_t* pos_idx;   // optional [n_r]: explicit positive column per row (else r + diag)
   int32_t* part_cnt;        // RANK [nsplit][n_r]: columns scoring strictly above the row's threshold a_r
 };
@@ -65,12 +67,12 @@ struct Geo {
   static constexpr int NG = D / 8;             // GEMM1 k-groups of 8 (4 per lane half)
   static constexpr int NB = D / 32;            // GEMM2 d-blocks (d = NB*lane_row + b)
   static constexpr int TILE_F = 32 * LS;
-  static constexpr int BUF_F = TILE_F + 128;   // + a_c[32] + s_c[32] + id_c[32] (int64)
+  static constexpr int BUF_F = TILE_F + 160;   // + a_c[32] + s_c[32] + id_c[32] (int64) + h_c[32]
   static constexpr int NV = (32 * D / 4) / 256 > 0 ? (32 * D / 4) / 256 : 1;   // staged float4 per thread
   static constexpr int LDS_BYTES = 2 * BUF_F * 4;
 };
 
-template <int D, int MODE, bool HAS_IDS>
+template <int D, int MODE, bool HAS_IDS, bool HAS_HN>
 __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void score_kernel(ScoreArgs p) {
   using G_ = Geo<D>;
   constexpr int LS = G_::LS, NG = G_::NG, NB = G_::NB, TILE_F = G_::TILE_F, BUF_F = G_::BUF_F, NV = G_::NV;
@@ -109,7 +111,10 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void score_kernel(ScoreArg
   // ---- staging (global -> regs -> LDS, one tile ahead).  Thread `tid` moves float4 number
   // tid + 256*j of the tile (row = f / ROW4, col4 = f % ROW4): 32-bit offsets from one running pointer.
   f32x4 st[NV];
-  float st_a = 0.f, st_s = 0.f;
+  float st_a = 0.f, st_s = 0.f, st_h = -3.0e38f;
+  constexpr bool hn = HAS_HN;                                        // hard-negative mining compiled in
+  const float hr = (HAS_HN && p.h_r != nullptr && r_ok) ? p.h_r[r] : -3.0e38f;
+  const float* hcp = (HAS_HN && p.h_c != nullptr) ? p.h_c + c_begin + tid : nullptr;
   int64_t st_id = -2;
   constexpr int RPJ = 256 / ROW4;                   // tile rows between a thread's consecutive float4s
   const int st_row = tid / ROW4, st_col4 = tid % ROW4;
@@ -131,6 +136,7 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void score_kernel(ScoreArg
     if (tid < 32) {
       const bool ok = tid < nvalid;
       st_a = ok ? (acp != nullptr ? acp[32 * t] : 0.f) : kNegBig;
+      if constexpr (HAS_HN) st_h = (ok && hcp != nullptr) ? hcp[32 * t] : -3.0e38f;
       st_s = ok ? (scp != nullptr ? scp[32 * t] : 1.f) : 0.f;
       if constexpr (HAS_IDS) st_id = ok ? idp[32 * t] : (int64_t)-2;
     }
@@ -144,6 +150,7 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void score_kernel(ScoreArg
     if (tid < 32) {
       T[TILE_F + tid] = st_a;
       T[TILE_F + 32 + tid] = st_s;
+      if constexpr (HAS_HN) T[TILE_F + 128 + tid] = st_h;
       if constexpr (HAS_IDS) reinterpret_cast<int64_t*>(T + TILE_F + 64)[tid] = st_id;
     }
   };
@@ -208,6 +215,15 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void score_kernel(ScoreArg
         for (int i = 0; i < 4; ++i) sc[4 * q + i] = vs[i];
       }
     }
+    float hth[16];                                   // per-element hard-negative threshold: max(row's, column's)
+    if constexpr (hn) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 vh = *reinterpret_cast<const f32x4*>(T + TILE_F + 128 + 8 * q + 4 * h);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hth[4 * q + i] = fmaxf(vh[i], hr);
+      }
+    }
     // wave-uniform: does this tile hold the positive of any row of this wave?
     bool diag_tile;
     if (p.pos_idx != nullptr) {
@@ -244,6 +260,7 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void score_kernel(ScoreArg
       for (int reg = 0; reg < 16; ++reg) {
         float v = __builtin_fmaf(X[reg], p.c1, ac[reg]);
         if constexpr (HAS_IDS) v = dup[reg] ? kNegBig : v;
+        if constexpr (hn) v = (v < hth[reg] && tt::acc_row(reg, 0) != dloc) ? kNegBig : v;
         t2[reg] = v;
         mx = fmaxf(mx, v);
       }
@@ -264,7 +281,9 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void score_kernel(ScoreArg
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
           const float w = sc[reg] * sr;
-          float e = __builtin_amdgcn_exp2f(__builtin_fmaf(X[reg], p.c1, ac[reg]) + ar) * w;
+          float tv = __builtin_fmaf(X[reg], p.c1, ac[reg]) + ar;
+          if constexpr (hn) tv = (tv < hth[reg] && tt::acc_row(reg, 0) != dloc) ? kNegBig : tv;
+          float e = __builtin_amdgcn_exp2f(tv) * w;
           if constexpr (HAS_IDS) e = dup[reg] ? 0.f : e;
           coef[reg] = e;
         }
@@ -282,6 +301,7 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void score_kernel(ScoreArg
         for (int reg = 0; reg < 16; ++reg) {
           float v = __builtin_fmaf(X[reg], p.c1, ac[reg]);
           if constexpr (HAS_IDS) v = dup[reg] ? kNegBig : v;
+          if constexpr (hn) v = (v < hth[reg] && tt::acc_row(reg, 0) != dloc) ? kNegBig : v;
           coef[reg] = v;
           mx = fmaxf(mx, v);
         }
@@ -510,6 +530,90 @@ __global__ __launch_bounds__(256) void rank_combine_kernel(const int32_t* __rest
   rank[r] = tot;
 }
 
+// ---- hard-negative mining (tfrs.layers.loss.HardNegativeMining): per query keep the positive and the k highest-scoring
+// negatives.  The kernels only need a per-row THRESHOLD; it is found on a materialised row of raw dot products
+// (scratch [nq][nc], written by the tiled GEMM) with a 4-pass MSB-first radix select (8-bit digits, LDS histogram) of
+// the k-th largest negative logit, then the largest value below it; thr = their midpoint, so the later comparisons
+// inside the fused kernels cannot flip on rounding.  Ties AT the k-th value are all kept.  One workgroup per row.
+__device__ __forceinline__ uint32_t f2key(float v) {
+  const uint32_t u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);       // monotone: larger float -> larger key
+}
+__device__ __forceinline__ float key2f(uint32_t k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+__global__ __launch_bounds__(256) void hardneg_select_kernel(const float* __restrict__ S, int64_t nc, float c1,
+                                                            const float* __restrict__ bias2, const int64_t* __restrict__ ids,
+                                                            int64_t diag, int k, float* __restrict__ thr) {
+  __shared__ int hist[256];
+  __shared__ uint32_t sh_prefix, sh_mask, sh_lower;
+  __shared__ int sh_remaining, sh_valid;
+  const int tid = threadIdx.x;
+  const int64_t row = blockIdx.x;
+  const int64_t pos = row + diag;
+  const float* srow = S + row * nc;
+  const int64_t idpos = ids != nullptr ? ids[pos] : 0;
+  auto valid = [&](int64_t j) { return j != pos && !(ids != nullptr && ids[j] == idpos); };
+  auto keyof = [&](int64_t j) { return f2key(__builtin_fmaf(srow[j], c1, bias2 != nullptr ? bias2[j] : 0.f)); };
+  if (tid == 0) { sh_prefix = 0; sh_mask = 0; sh_remaining = k; sh_valid = 0; sh_lower = 0; }
+  __syncthreads();
+  int nv = 0;
+  for (int64_t j = tid; j < nc; j += 256) nv += valid(j) ? 1 : 0;
+  atomicAdd(&sh_valid, nv);
+  __syncthreads();
+  if (k >= sh_valid) {                                       // fewer negatives than k: keep everything
+    if (tid == 0) thr[row] = -3.0e38f;
+    return;
+  }
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    hist[tid] = 0;
+    __syncthreads();
+    const uint32_t prefix = sh_prefix, mask = sh_mask;
+    for (int64_t j = tid; j < nc; j += 256) {
+      if (!valid(j)) continue;
+      const uint32_t key = keyof(j);
+      if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int cum = 0, rem = sh_remaining;
+      for (int b = 255; b >= 0; --b) {
+        if (cum + hist[b] >= rem) {
+          sh_prefix = prefix | ((uint32_t)b << shift);
+          sh_mask = mask | (255u << shift);
+          sh_remaining = rem - cum;
+          break;
+        }
+        cum += hist[b];
+      }
+    }
+    __syncthreads();
+  }
+  const uint32_t key_k = sh_prefix;                          // exact key of the k-th largest negative
+  uint32_t lower = 0;
+  for (int64_t j = tid; j < nc; j += 256) {
+    if (!valid(j)) continue;
+    const uint32_t key = keyof(j);
+    if (key < key_k && key > lower) lower = key;
+  }
+  atomicMax(&sh_lower, lower);
+  __syncthreads();
+  if (tid == 0) {
+    const float vk = key2f(key_k);
+    const float vn = sh_lower != 0 ? key2f(sh_lower) : vk - 1.0f;
+    thr[row] = 0.5f * vk + 0.5f * vn;
+  }
+}
+
+// hq = thr + aq : the threshold in the domain of the BWD passes (logit2 - lse2)
+__global__ __launch_bounds__(256) void hn_shift_kernel(const float* __restrict__ thr, const float* __restrict__ aq,
+                                                       float* __restrict__ hq, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) hq[i] = thr[i] + aq[i];
+}
+
 // loss = sum_r per_row[r], fixed order (one workgroup)
 __global__ __launch_bounds__(1024) void sum_rows_kernel(const float* __restrict__ per_row, int64_t n, float* __restrict__ loss) {
   __shared__ float red[1024];
@@ -548,7 +652,7 @@ int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
 struct WsLayout {
   int ns_q, ns_c;           // splits for the passes whose stationary side is q / c
-  int64_t off_bias, off_aq, off_sq, off_pm, off_pl, off_pos, off_slab, total;
+  int64_t off_bias, off_aq, off_sq, off_hq, off_pm, off_pl, off_pos, off_slab, total;
 };
 
 WsLayout ws_layout(int64_t nq, int64_t nc, int32_t dim) {
@@ -559,6 +663,7 @@ WsLayout ws_layout(int64_t nq, int64_t nc, int32_t dim) {
   w.off_bias = o; o = align_up(o + nc * 4, 256);
   w.off_aq = o;   o = align_up(o + nq * 4, 256);
   w.off_sq = o;   o = align_up(o + nq * 4, 256);
+  w.off_hq = o;   o = align_up(o + nq * 4, 256);
   w.off_pm = o;   o = align_up(o + (int64_t)w.ns_q * nq * 4, 256);
   w.off_pl = o;   o = align_up(o + (int64_t)w.ns_q * nq * 4, 256);
   w.off_pos = o;  o = align_up(o + nq * 4, 256);
@@ -574,23 +679,20 @@ int launch_score(const ScoreArgs& a, bool has_ids, hipStream_t stream) {
   const int64_t nrb = (a.n_r + 127) / 128;
   const int64_t blocks = nrb * a.nsplit;
   const int lds = Geo<D>::LDS_BYTES;
-  if constexpr (Geo<D>::LDS_BYTES > 64 * 1024) {   // above the 64 KiB default the limit must be raised once
-    static bool raised = false;
-    if (!raised) {
-      hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&score_kernel<D, MODE, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&score_kernel<D, MODE, false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      if (e1 != hipSuccess || e2 != hipSuccess) return tt::fail(TT_ERR_LAUNCH, "hipFuncSetAttribute(LDS %d) failed", lds);
-      raised = true;
+  const bool has_hn = (a.h_r != nullptr) || (a.h_c != nullptr);
+  auto go = [&](auto kern) -> int {
+    if constexpr (Geo<D>::LDS_BYTES > 64 * 1024) {   // above the 64 KiB default the limit must be raised (cheap, idempotent)
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        return tt::fail(TT_ERR_LAUNCH, "hipFuncSetAttribute(LDS %d) failed", lds);
     }
-  }
-  tt::ProfScope prof(MODE == MODE_FWD ? "score_fwd" : (MODE == MODE_BWD ? "score_bwd" : (MODE == MODE_FUSED ? "score_fused" : "score_rank")), stream);
-  if (has_ids)
-    hipLaunchKernelGGL((score_kernel<D, MODE, true>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
-  else
-    hipLaunchKernelGGL((score_kernel<D, MODE, false>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
-  return tt::check_launch(MODE == MODE_FWD ? "score_fwd" : (MODE == MODE_BWD ? "score_bwd" : "score_fused"));
+    tt::ProfScope prof(MODE == MODE_FWD ? "score_fwd" : (MODE == MODE_BWD ? "score_bwd" : (MODE == MODE_FUSED ? "score_fused" : "score_rank")), stream);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    return tt::check_launch(MODE == MODE_FWD ? "score_fwd" : (MODE == MODE_BWD ? "score_bwd" : "score_fused"));
+  };
+  if (has_ids && has_hn) return go(score_kernel<D, MODE, true, true>);
+  if (has_ids) return go(score_kernel<D, MODE, true, false>);
+  if (has_hn) return go(score_kernel<D, MODE, false, true>);
+  return go(score_kernel<D, MODE, false, false>);
 }
 
 template <int MODE>
@@ -627,8 +729,8 @@ extern "C" int64_t tt_retrieval_workspace_bytes(int64_t nq, int64_t nc, int32_t 
 
 extern "C" int tt_retrieval_fwd_f32(const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
                                     int64_t diag_offset, float inv_temperature, const float* sample_weight,
-                                    const float* cand_prob, const int64_t* cand_ids, void* workspace,
-                                    int64_t workspace_bytes, float* lse, float* per_row, float* loss,
+                                    const float* cand_prob, const int64_t* cand_ids, const float* hard_thr,
+                                    void* workspace, int64_t workspace_bytes, float* lse, float* per_row, float* loss,
                                     tt_stream_t stream_) {
   int rc = check_common("tt_retrieval_fwd_f32", q, c, nq, nc, dim, diag_offset, workspace, workspace_bytes);
   if (rc != TT_OK) return rc;
@@ -647,6 +749,7 @@ extern "C" int tt_retrieval_fwd_f32(const float* q, const float* c, int64_t nq, 
   a.a_c = cand_prob != nullptr ? bias : nullptr;
   a.id_r = cand_ids != nullptr ? cand_ids + diag_offset : nullptr;
   a.id_c = cand_ids;
+  a.h_r = hard_thr;
   a.nsplit = w.ns_q;
   a.c_per_split = align_up((nc + a.nsplit - 1) / a.nsplit, 32);
   a.part_m = reinterpret_cast<float*>(ws + w.off_pm);
@@ -661,9 +764,9 @@ extern "C" int tt_retrieval_fwd_f32(const float* q, const float* c, int64_t nq, 
 
 extern "C" int tt_retrieval_bwd_f32(const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
                                     int64_t diag_offset, float inv_temperature, const float* sample_weight,
-                                    const float* cand_prob, const int64_t* cand_ids, const float* lse,
-                                    float grad_scale, void* workspace, int64_t workspace_bytes, float* dq, float* dc,
-                                    tt_stream_t stream_) {
+                                    const float* cand_prob, const int64_t* cand_ids, const float* hard_thr,
+                                    const float* lse, float grad_scale, void* workspace, int64_t workspace_bytes,
+                                    float* dq, float* dc, tt_stream_t stream_) {
   int rc = check_common("tt_retrieval_bwd_f32", q, c, nq, nc, dim, diag_offset, workspace, workspace_bytes);
   if (rc != TT_OK) return rc;
   TT_REQUIRE(lse && dq && dc, "tt_retrieval_bwd_f32: null lse/dq/dc");
@@ -683,6 +786,12 @@ extern "C" int tt_retrieval_bwd_f32(const float* q, const float* c, int64_t nq, 
                      sq, nq, inv_temperature * grad_scale);
   if ((rc = tt::check_launch("bwd_prep")) != TT_OK) return rc;
   const float* biasp = cand_prob != nullptr ? bias : nullptr;
+  float* hq = nullptr;
+  if (hard_thr != nullptr) {
+    hq = reinterpret_cast<float*>(ws + w.off_hq);
+    hipLaunchKernelGGL(hn_shift_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, hard_thr, aq, hq, nq);
+    if ((rc = tt::check_launch("hn_shift")) != TT_OK) return rc;
+  }
 
   // dq: stationary q, stream c
   {
@@ -690,6 +799,7 @@ extern "C" int tt_retrieval_bwd_f32(const float* q, const float* c, int64_t nq, 
     a.R = q; a.K = c; a.n_r = nq; a.n_c = nc; a.diag = diag_offset;
     a.c1 = kLog2e * inv_temperature;
     a.a_r = aq; a.s_r = sq; a.a_c = biasp; a.s_c = nullptr;
+    a.h_r = hq;
     a.id_r = cand_ids != nullptr ? cand_ids + diag_offset : nullptr;
     a.id_c = cand_ids;
     a.nsplit = w.ns_q;
@@ -711,6 +821,7 @@ extern "C" int tt_retrieval_bwd_f32(const float* q, const float* c, int64_t nq, 
     a.R = c; a.K = q; a.n_r = nc; a.n_c = nq; a.diag = -diag_offset;
     a.c1 = kLog2e * inv_temperature;
     a.a_r = biasp; a.s_r = nullptr; a.a_c = aq; a.s_c = sq;
+    a.h_c = hq;
     a.id_r = cand_ids;
     a.id_c = cand_ids != nullptr ? cand_ids + diag_offset : nullptr;
     a.nsplit = w.ns_c;
@@ -734,9 +845,9 @@ extern "C" int tt_retrieval_bwd_f32(const float* q, const float* c, int64_t nq, 
 //   pass 2 (R = c, K = q, MODE_BWD)  : recompute with the final lse -> dc
 extern "C" int tt_retrieval_fwd_bwd_f32(const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
                                         int64_t diag_offset, float inv_temperature, const float* sample_weight,
-                                        const float* cand_prob, const int64_t* cand_ids, float grad_scale, void* workspace,
-                                        int64_t workspace_bytes, float* lse, float* per_row, float* loss, float* dq,
-                                        float* dc, tt_stream_t stream_) {
+                                        const float* cand_prob, const int64_t* cand_ids, const float* hard_thr,
+                                        float grad_scale, void* workspace, int64_t workspace_bytes, float* lse,
+                                        float* per_row, float* loss, float* dq, float* dc, tt_stream_t stream_) {
   int rc = check_common("tt_retrieval_fwd_bwd_f32", q, c, nq, nc, dim, diag_offset, workspace, workspace_bytes);
   if (rc != TT_OK) return rc;
   TT_REQUIRE(lse && per_row && loss && dq && dc, "tt_retrieval_fwd_bwd_f32: null output pointer");
@@ -758,6 +869,7 @@ extern "C" int tt_retrieval_fwd_bwd_f32(const float* q, const float* c, int64_t 
     a.R = q; a.K = c; a.n_r = nq; a.n_c = nc; a.diag = diag_offset;
     a.c1 = kLog2e * inv_temperature;
     a.a_c = biasp;
+    a.h_r = hard_thr;
     a.id_r = cand_ids != nullptr ? cand_ids + diag_offset : nullptr;
     a.id_c = cand_ids;
     a.nsplit = w.ns_q;
@@ -778,11 +890,18 @@ extern "C" int tt_retrieval_fwd_bwd_f32(const float* q, const float* c, int64_t 
       if ((rc = tt::check_launch("sum_rows")) != TT_OK) return rc;
     }
   }
+  float* hq = nullptr;
+  if (hard_thr != nullptr) {
+    hq = reinterpret_cast<float*>(ws + w.off_hq);
+    hipLaunchKernelGGL(hn_shift_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, hard_thr, aq, hq, nq);
+    if ((rc = tt::check_launch("hn_shift")) != TT_OK) return rc;
+  }
   {
     ScoreArgs a{};
     a.R = c; a.K = q; a.n_r = nc; a.n_c = nq; a.diag = -diag_offset;
     a.c1 = kLog2e * inv_temperature;
     a.a_r = biasp; a.s_r = nullptr; a.a_c = aq; a.s_c = sq;
+    a.h_c = hq;
     a.id_r = cand_ids;
     a.id_c = cand_ids != nullptr ? cand_ids + diag_offset : nullptr;
     a.nsplit = w.ns_c;
@@ -839,4 +958,33 @@ extern "C" int tt_retrieval_rank_f32(const float* q, const float* c, int64_t nq,
   if ((rc = dispatch_score<MODE_RANK>(dim, a, false, stream)) != TT_OK) return rc;
   hipLaunchKernelGGL(rank_combine_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, part_cnt, nq, a.nsplit, rank);
   return tt::check_launch("rank_combine");
+}
+
+// Hard-negative thresholds (tfrs.tasks.Retrieval(num_hard_negatives=k)): thr[i] separates the k highest-scoring negatives
+// of query i (after temperature, sampling-probability correction and accidental-hit removal) from the rest; pass it as
+// `hard_thr` to tt_retrieval_{fwd,bwd,fwd_bwd}_f32.  scratch: nq*nc floats (the only place logits are materialised).
+extern "C" int tt_retrieval_hard_negative_thresholds_f32(const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
+                                                         int64_t diag_offset, float inv_temperature, const float* cand_prob,
+                                                         const int64_t* cand_ids, int32_t num_hard_negatives, void* workspace,
+                                                         int64_t workspace_bytes, float* scratch, int64_t scratch_bytes,
+                                                         float* thr, tt_stream_t stream_) {
+  int rc = check_common("tt_retrieval_hard_negative_thresholds_f32", q, c, nq, nc, dim, diag_offset, workspace, workspace_bytes);
+  if (rc != TT_OK) return rc;
+  TT_REQUIRE(num_hard_negatives >= 1, "tt_retrieval_hard_negative_thresholds_f32: num_hard_negatives must be >= 1");
+  TT_REQUIRE(scratch && thr, "tt_retrieval_hard_negative_thresholds_f32: null scratch/thr");
+  if (scratch_bytes < nq * nc * 4)
+    return tt::fail(TT_ERR_WORKSPACE, "tt_retrieval_hard_negative_thresholds_f32: scratch %lld < %lld bytes",
+                    (long long)scratch_bytes, (long long)(nq * nc * 4));
+  hipStream_t stream = tt::as_stream(stream_);
+  const WsLayout w = ws_layout(nq, nc, dim);
+  float* bias = reinterpret_cast<float*>(static_cast<char*>(workspace) + w.off_bias);
+  if (cand_prob != nullptr) {
+    hipLaunchKernelGGL(prob_bias_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, stream, cand_prob, bias, nc);
+    if ((rc = tt::check_launch("prob_bias")) != TT_OK) return rc;
+  }
+  if ((rc = tt::gemm_nt(q, c, scratch, nq, nc, dim, stream)) != TT_OK) return rc;
+  tt::ProfScope prof("score_aux", stream);
+  hipLaunchKernelGGL(hardneg_select_kernel, dim3((unsigned)nq), dim3(256), 0, stream, scratch, nc, kLog2e * inv_temperature,
+                     cand_prob != nullptr ? bias : nullptr, cand_ids, diag_offset, num_hard_negatives, thr);
+  return tt::check_launch("hardneg_select");
 }

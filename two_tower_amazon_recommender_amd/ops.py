@@ -285,7 +285,7 @@ def retrieval_workspace_bytes(nq: int, nc: int, dim: int) -> int:
 
 
 def retrieval_fwd(q, c, inv_temperature: float, workspace, lse, per_row, loss, sample_weight=None,
-                  cand_prob=None, cand_ids=None, diag_offset: int = 0):
+                  cand_prob=None, cand_ids=None, diag_offset: int = 0, hard_thr=None):
     _chk(q, torch.float32, "query_embeddings", 2)
     _chk(c, torch.float32, "candidate_embeddings", 2)
     if q.shape[1] != c.shape[1]:
@@ -298,23 +298,23 @@ def retrieval_fwd(q, c, inv_temperature: float, workspace, lse, per_row, loss, s
         _chk(cand_ids, torch.int64, "candidate_ids", 1)
     lib = _lib.load()
     _lib.check(lib.tt_retrieval_fwd_f32(_p(q), _p(c), q.shape[0], c.shape[0], q.shape[1], diag_offset, inv_temperature,
-                                        _p(sample_weight), _p(cand_prob), _p(cand_ids), _p(workspace), workspace.numel(),
-                                        _p(lse), _p(per_row), _p(loss), _stream()), "tt_retrieval_fwd_f32")
+                                        _p(sample_weight), _p(cand_prob), _p(cand_ids), _p(hard_thr), _p(workspace),
+                                        workspace.numel(), _p(lse), _p(per_row), _p(loss), _stream()), "tt_retrieval_fwd_f32")
     return loss
 
 
 def retrieval_bwd(q, c, inv_temperature: float, workspace, lse, dq, dc, sample_weight=None, cand_prob=None,
-                  cand_ids=None, diag_offset: int = 0, grad_scale: float = 1.0):
+                  cand_ids=None, diag_offset: int = 0, grad_scale: float = 1.0, hard_thr=None):
     lib = _lib.load()
     _lib.check(lib.tt_retrieval_bwd_f32(_p(q), _p(c), q.shape[0], c.shape[0], q.shape[1], diag_offset, inv_temperature,
-                                        _p(sample_weight), _p(cand_prob), _p(cand_ids), _p(lse), grad_scale,
+                                        _p(sample_weight), _p(cand_prob), _p(cand_ids), _p(hard_thr), _p(lse), grad_scale,
                                         _p(workspace), workspace.numel(), _p(dq), _p(dc), _stream()),
                "tt_retrieval_bwd_f32")
     return dq, dc
 
 
 def retrieval_fwd_bwd(q, c, inv_temperature: float, workspace, lse, per_row, loss, dq, dc, sample_weight=None,
-                      cand_prob=None, cand_ids=None, diag_offset: int = 0, grad_scale: float = 1.0):
+                      cand_prob=None, cand_ids=None, diag_offset: int = 0, grad_scale: float = 1.0, hard_thr=None):
     """Loss and both gradients in two fused passes (training form)."""
     _chk(q, torch.float32, "query_embeddings", 2)
     _chk(c, torch.float32, "candidate_embeddings", 2)
@@ -328,7 +328,7 @@ def retrieval_fwd_bwd(q, c, inv_temperature: float, workspace, lse, per_row, los
         _chk(cand_ids, torch.int64, "candidate_ids", 1)
     lib = _lib.load()
     _lib.check(lib.tt_retrieval_fwd_bwd_f32(_p(q), _p(c), q.shape[0], c.shape[0], q.shape[1], diag_offset, inv_temperature,
-                                            _p(sample_weight), _p(cand_prob), _p(cand_ids), grad_scale, _p(workspace),
+                                            _p(sample_weight), _p(cand_prob), _p(cand_ids), _p(hard_thr), grad_scale, _p(workspace),
                                             workspace.numel(), _p(lse), _p(per_row), _p(loss), _p(dq), _p(dc), _stream()),
                "tt_retrieval_fwd_bwd_f32")
     return loss
@@ -349,4 +349,22 @@ def retrieval_rank(q, c, inv_temperature: float, pos_index, workspace=None, cand
     lib = _lib.load()
     _lib.check(lib.tt_retrieval_rank_f32(_p(q), _p(c), nq, nc, d, inv_temperature, _p(cand_prob), _p(pos_index),
                                          _p(workspace), workspace.numel(), _p(out), _stream()), "tt_retrieval_rank_f32")
+    return out
+
+
+def retrieval_hard_negative_thresholds(q, c, inv_temperature: float, k: int, workspace, cand_prob=None, cand_ids=None,
+                                       diag_offset: int = 0, scratch=None, out=None):
+    """Per-query thresholds for ``num_hard_negatives = k`` (pass as ``hard_thr`` to the loss entry points)."""
+    _chk(q, torch.float32, "query_embeddings", 2)
+    _chk(c, torch.float32, "candidate_embeddings", 2)
+    nq, nc, d = q.shape[0], c.shape[0], q.shape[1]
+    if scratch is None:
+        scratch = torch.empty(nq * nc, dtype=torch.float32, device=q.device)
+    if out is None:
+        out = torch.empty(nq, dtype=torch.float32, device=q.device)
+    lib = _lib.load()
+    _lib.check(lib.tt_retrieval_hard_negative_thresholds_f32(_p(q), _p(c), nq, nc, d, diag_offset, inv_temperature,
+                                                             _p(cand_prob), _p(cand_ids), k, _p(workspace), workspace.numel(),
+                                                             _p(scratch), scratch.numel() * 4, _p(out), _stream()),
+               "tt_retrieval_hard_negative_thresholds_f32")
     return out

@@ -6,8 +6,10 @@ HIP kernels (csrc/score.hip): the [num_queries, num_candidates] logits never rea
 
 Differences from TFRS, all loud:
   * ``loss`` must be None (the TFRS default: CategoricalCrossentropy(from_logits=True, reduction=SUM));
-  * ``metrics`` / ``batch_metrics`` / ``loss_metrics`` (FactorizedTopK ...) and ``num_hard_negatives``
-    are not implemented yet (SURVEY.md §8f rows 2-3) and raise NotImplementedError when requested;
+  * ``metrics`` / ``batch_metrics`` / ``loss_metrics`` objects are not accepted by the task (use
+    ``metrics.FactorizedTopK`` directly: it runs the fused rank pass) and raise NotImplementedError;
+  * ``num_hard_negatives=k`` keeps the positive and the k highest-scoring negatives per query
+    (tfrs.layers.loss.HardNegativeMining); negatives tied with the k-th are all kept;
   * ``candidate_ids`` must be an int64 tensor (the reference's ids are int64:
     ``prepare_training_data.py:209-210``).
 """
@@ -21,6 +23,7 @@ from . import ops
 class _RetrievalLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, c, sample_weight, cand_prob, cand_ids, inv_t, diag_offset, task):
+        k = task._num_hard_negatives
         q = q.contiguous()
         c = c.contiguous()
         nq, nc, d = q.shape[0], c.shape[0], q.shape[1]
@@ -28,21 +31,25 @@ class _RetrievalLoss(torch.autograd.Function):
         lse = torch.empty(nq, dtype=torch.float32, device=q.device)
         per_row = torch.empty(nq, dtype=torch.float32, device=q.device)
         loss = torch.empty(1, dtype=torch.float32, device=q.device)
+        thr = None
+        if k is not None:       # non-differentiable selection of the k hardest negatives per query (as in TFRS)
+            thr = ops.retrieval_hard_negative_thresholds(q, c, inv_t, k, ws, cand_prob=cand_prob, cand_ids=cand_ids,
+                                                         diag_offset=diag_offset)
         ops.retrieval_fwd(q, c, inv_t, ws, lse, per_row, loss, sample_weight=sample_weight, cand_prob=cand_prob,
-                          cand_ids=cand_ids, diag_offset=diag_offset)
-        ctx.save_for_backward(q, c, lse, sample_weight, cand_prob, cand_ids)
+                          cand_ids=cand_ids, diag_offset=diag_offset, hard_thr=thr)
+        ctx.save_for_backward(q, c, lse, sample_weight, cand_prob, cand_ids, thr)
         ctx.inv_t, ctx.diag_offset, ctx.task = inv_t, diag_offset, task
         task.last_per_example_loss = per_row
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, grad_out):
-        q, c, lse, sample_weight, cand_prob, cand_ids = ctx.saved_tensors
+        q, c, lse, sample_weight, cand_prob, cand_ids, thr = ctx.saved_tensors
         ws = ctx.task._workspace(q.shape[0], c.shape[0], q.shape[1], q.device)
         dq = torch.empty_like(q)
         dc = torch.empty_like(c)
         ops.retrieval_bwd(q, c, ctx.inv_t, ws, lse, dq, dc, sample_weight=sample_weight, cand_prob=cand_prob,
-                          cand_ids=cand_ids, diag_offset=ctx.diag_offset)
+                          cand_ids=cand_ids, diag_offset=ctx.diag_offset, hard_thr=thr)
         # upstream gradient of the scalar loss stays on the device (no host sync)
         return dq * grad_out, dc * grad_out, None, None, None, None, None, None
 
@@ -57,11 +64,12 @@ class Retrieval:
                                       "from logits, SUM reduction) is implemented in the HIP path")
         if metrics is not None or batch_metrics is not None or loss_metrics is not None:
             raise NotImplementedError("Retrieval metrics (FactorizedTopK etc.) are not implemented yet (SURVEY.md §8f)")
-        if num_hard_negatives is not None:
-            raise NotImplementedError("num_hard_negatives is not implemented in the HIP path yet (SURVEY.md §8f)")
+        if num_hard_negatives is not None and num_hard_negatives < 1:
+            raise ValueError("num_hard_negatives must be a positive integer")
         if temperature is not None and temperature <= 0:
             raise ValueError("temperature must be positive")
         self._temperature = temperature
+        self._num_hard_negatives = num_hard_negatives
         self._remove_accidental_hits = remove_accidental_hits
         self.name = name
         self._ws = {}
