@@ -30,6 +30,10 @@ CONFIGS = {
     "cfg1": (10_000, 10_000, 32, [32], 256),
     "cfg2": (1_000_000, 1_000_000, 64, [64], 4096),
     "cfg3": (5_000_000, 10_000_000, 128, [256, 128], 8192),
+    # BASELINE configs[3] / [4] are 8-GPU configurations; their tables also fit ONE MI355X (288 GB), so they can be
+    # measured un-sharded too (the N>1 driver runs use bench_dist.py's per-GPU cfg3 family instead)
+    "cfg4": (5_000_000, 100_000_000, 128, [256, 128], 16384),
+    "cfg5": (54_000_000, 48_000_000, 256, [512, 256], 32768),
 }
 MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32-input MFMA dense peak
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
