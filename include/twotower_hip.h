@@ -182,6 +182,23 @@ int tt_dense_bwd_scaled_f32(const float* x, const float* w, const float* dz,
                             float* dw_slabs, float* db_slabs,
                             int64_t m, int32_t k, int32_t n, tt_stream_t stream);
 
+/* Batched forms: the same layer of the user AND the item tower (identical shapes) in one launch each —
+ * fwd: 1 launch, bwd: 2 launches (dx, dw+db) — instead of twice as many half-size launches.
+ * `probs` is a HOST array of n_probs (1 or 2) entries.                                                     */
+typedef struct tt_dense_fwd_args {
+  const float* x; const float* w; const float* b; float* y;
+  uint64_t dropout_tensor_id;       /* counter stream of this problem's dropout mask (ignored at rate 0) */
+} tt_dense_fwd_args;
+typedef struct tt_dense_bwd_args {
+  const float* x; const float* w; const float* dz; float* dx; const float* dx_relu_src;
+  float* dw_slabs; float* db_slabs;
+} tt_dense_bwd_args;
+int tt_dense_fwd_batched_f32(const tt_dense_fwd_args* probs, int32_t n_probs, int64_t m, int32_t k, int32_t n,
+                             int32_t relu, float drop_rate, uint64_t seed, uint64_t counter_offset,
+                             tt_stream_t stream);
+int tt_dense_bwd_batched_f32(const tt_dense_bwd_args* probs, int32_t n_probs, float dx_scale,
+                             int64_t m, int32_t k, int32_t n, tt_stream_t stream);
+
 /* Dense parameter update over up to TT_MAX_DENSE_SEGS segments in one launch.
  *   g = sum_s grad_slabs[s*slab_stride + i] (s ascending) + 2*l2*w[i]
  *   SGD: w -= fl(lr*g);  Adagrad: acc += g*g; w -= fl(lr*g)/sqrt(acc+eps)

@@ -22,6 +22,17 @@ TT_IDS_UNIFORM, TT_IDS_POWERLAW = 0, 1
 TT_MAX_DENSE_SEGS = 16
 
 
+class DenseFwdArgs(C.Structure):
+    """Mirror of ``tt_dense_fwd_args``."""
+    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("b", C.c_void_p), ("y", C.c_void_p), ("dropout_tensor_id", C.c_uint64)]
+
+
+class DenseBwdArgs(C.Structure):
+    """Mirror of ``tt_dense_bwd_args``."""
+    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("dz", C.c_void_p), ("dx", C.c_void_p), ("dx_relu_src", C.c_void_p),
+                ("dw_slabs", C.c_void_p), ("db_slabs", C.c_void_p)]
+
+
 class DenseSeg(C.Structure):
     """Mirror of ``tt_dense_seg`` (include/twotower_hip.h)."""
     _fields_ = [
@@ -56,6 +67,8 @@ SIGNATURES = {
     "tt_dense_fwd_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _i32, _p]),
     "tt_dense_fwd_dropout_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _i32, _f, _u64, _u64, _u64, _p]),
     "tt_dense_bwd_scaled_f32": (C.c_int, [_p, _p, _p, _p, _p, _f, _p, _p, _i64, _i32, _i32, _p]),
+    "tt_dense_fwd_batched_f32": (C.c_int, [C.POINTER(DenseFwdArgs), _i32, _i64, _i32, _i32, _i32, _f, _u64, _u64, _p]),
+    "tt_dense_bwd_batched_f32": (C.c_int, [C.POINTER(DenseBwdArgs), _i32, _f, _i64, _i32, _i32, _p]),
     "tt_dense_bwd_num_slabs": (_i32, [_i64]),
     "tt_dense_bwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
     "tt_dense_update_f32": (C.c_int, [C.POINTER(DenseSeg), _i32, _i32, _i32, _f, _f, _p]),

@@ -93,8 +93,17 @@ __device__ __forceinline__ f32x4 read_operand(const float* T, int row, int g, in
   }
 }
 
+// up to two independent problems of identical shape per launch (the user and the item tower's layer l):
+// blockIdx.z = problem * splits + split
+struct GemmBatch {
+  GemmArgs a[2];
+  int splits;
+};
+
 template <bool A_KC, bool B_KC, bool COLSUM>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
+__global__ __launch_bounds__(256) void gemm_kernel(GemmBatch pb) {
+  const int zsplit = blockIdx.z % pb.splits;
+  const GemmArgs& p = pb.a[blockIdx.z / pb.splits];
   __shared__ __attribute__((aligned(16))) float smem[2 * 2 * TILE_F];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -102,7 +111,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int64_t m0 = (int64_t)blockIdx.x * BM;
   const int64_t n0 = (int64_t)blockIdx.y * BN;
-  const int64_t kbeg = (int64_t)blockIdx.z * p.k_per_split;
+  const int64_t kbeg = (int64_t)zsplit * p.k_per_split;
   int64_t kend = kbeg + p.k_per_split;
   if (kend > p.K) kend = p.K;
   const int nk = kend > kbeg ? (int)((kend - kbeg + BK - 1) / BK) : 0;
@@ -155,7 +164,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     }
   }
 
-  float* C = p.C + (int64_t)blockIdx.z * p.slab_stride;
+  float* C = p.C + (int64_t)zsplit * p.slab_stride;
   const int64_t n = n0 + wn * 32 + ln;
   if (n < p.N) {
     const float bias = p.bias != nullptr ? p.bias[n] : 0.f;
@@ -175,18 +184,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     }
   }
   if constexpr (COLSUM) {
-    if (blockIdx.x == 0 && tid < BN && n0 + tid < p.N) p.db_slabs[(int64_t)blockIdx.z * p.N + n0 + tid] = colsum;
+    if (blockIdx.x == 0 && tid < BN && n0 + tid < p.N) p.db_slabs[(int64_t)zsplit * p.N + n0 + tid] = colsum;
   }
 }
 
 template <bool A_KC, bool B_KC, bool COLSUM>
-int launch(const GemmArgs& a_in, int splits, hipStream_t stream, const char* what, const char* tag) {
-  const int64_t gm = (a_in.M + BM - 1) / BM, gn = (a_in.N + BN - 1) / BN;
-  TT_REQUIRE(gm <= 0x7fffffff && gn <= 65535 && splits <= 65535, "%s: grid too large", what);
-  const GemmArgs& a = a_in;
+int launch(const GemmArgs* probs, int nprob, int splits, hipStream_t stream, const char* what, const char* tag) {
+  const GemmArgs& a0 = probs[0];
+  const int64_t gm = (a0.M + BM - 1) / BM, gn = (a0.N + BN - 1) / BN;
+  TT_REQUIRE(nprob >= 1 && nprob <= 2, "%s: 1 or 2 problems per launch", what);
+  TT_REQUIRE(gm <= 0x7fffffff && gn <= 65535 && (int64_t)splits * nprob <= 65535, "%s: grid too large", what);
+  GemmBatch pb{};
+  for (int i = 0; i < nprob; ++i) pb.a[i] = probs[i];
+  pb.splits = splits;
   tt::ProfScope prof(tag, stream);
-  hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, COLSUM>), dim3((unsigned)gm, (unsigned)gn, (unsigned)splits), dim3(256), 0,
-                     stream, a);
+  hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, COLSUM>), dim3((unsigned)gm, (unsigned)gn, (unsigned)(splits * nprob)), dim3(256), 0,
+                     stream, pb);
   return tt::check_launch(what);
 }
 
@@ -202,33 +215,45 @@ int gemm_nt(const float* a, const float* b, float* c, int64_t m, int64_t n, int6
   GemmArgs g{};
   g.A = a; g.B = b; g.C = c; g.M = m; g.N = n; g.K = k; g.lda = k; g.ldb = k; g.ldc = n;
   g.mask_scale = 1.f; g.k_per_split = (k + BK - 1) / BK * BK;
-  return launch<true, true, false>(g, 1, stream, "gemm_nt", "score_aux");
+  return launch<true, true, false>(&g, 1, 1, stream, "gemm_nt", "score_aux");
 }
 }  // namespace tt
 
+extern "C" int tt_dense_fwd_batched_f32(const tt_dense_fwd_args* probs, int32_t n_probs, int64_t m, int32_t k, int32_t n,
+                                        int32_t relu, float drop_rate, uint64_t seed, uint64_t counter_offset,
+                                        tt_stream_t stream) {
+  TT_REQUIRE(probs != nullptr && n_probs >= 1 && n_probs <= 2, "tt_dense_fwd_batched_f32: 1 or 2 problems");
+  TT_REQUIRE(drop_rate >= 0.f && drop_rate < 1.f, "tt_dense_fwd_batched_f32: drop_rate must be in [0,1)");
+  TT_REQUIRE(m > 0 && k > 0 && n > 0 && k % 4 == 0 && n % 4 == 0, "tt_dense_fwd_f32: need m>0, k%%4==0, n%%4==0 (m=%lld k=%d n=%d)",
+             (long long)m, k, n);
+  GemmArgs a[2] = {};
+  for (int i = 0; i < n_probs; ++i) {
+    const tt_dense_fwd_args& q = probs[i];
+    TT_REQUIRE(q.x && q.w && q.y, "tt_dense_fwd_f32: null pointer");
+    TT_REQUIRE(tt::aligned16(q.x) && tt::aligned16(q.w) && tt::aligned16(q.y), "tt_dense_fwd_f32: pointers must be 16-byte aligned");
+    a[i].A = q.x; a[i].B = q.w; a[i].C = q.y; a[i].M = m; a[i].N = n; a[i].K = k; a[i].lda = k; a[i].ldb = n; a[i].ldc = n;
+    a[i].bias = q.b; a[i].relu = relu; a[i].mask_scale = 1.f; a[i].k_per_split = (k + BK - 1) / BK * BK;
+    if (drop_rate > 0.f) {
+      a[i].drop_p24 = (uint32_t)((double)drop_rate * 16777216.0 + 0.5);
+      a[i].drop_scale = 1.0f / (1.0f - drop_rate);
+      a[i].drop_key = dropout_stream_key(seed, q.dropout_tensor_id);
+      a[i].drop_offset = counter_offset;
+    }
+  }
+  return launch<true, false, false>(a, n_probs, 1, tt::as_stream(stream), "tt_dense_fwd_f32", "dense_fwd");
+}
+
 extern "C" int tt_dense_fwd_f32(const float* x, const float* w, const float* b, float* y, int64_t m, int32_t k,
                                 int32_t n, int32_t relu, tt_stream_t stream) {
-  return tt_dense_fwd_dropout_f32(x, w, b, y, m, k, n, relu, 0.f, 0, 0, 0, stream);
+  const tt_dense_fwd_args q{x, w, b, y, 0};
+  return tt_dense_fwd_batched_f32(&q, 1, m, k, n, relu, 0.f, 0, 0, stream);
 }
 
 extern "C" int tt_dense_fwd_dropout_f32(const float* x, const float* w, const float* b, float* y, int64_t m, int32_t k,
                                         int32_t n, int32_t relu, float drop_rate, uint64_t seed, uint64_t tensor_id,
                                         uint64_t counter_offset, tt_stream_t stream) {
-  TT_REQUIRE(x && w && y, "tt_dense_fwd_f32: null pointer");
-  TT_REQUIRE(drop_rate >= 0.f && drop_rate < 1.f, "tt_dense_fwd_dropout_f32: drop_rate must be in [0,1)");
-  TT_REQUIRE(m > 0 && k > 0 && n > 0 && k % 4 == 0 && n % 4 == 0, "tt_dense_fwd_f32: need m>0, k%%4==0, n%%4==0 (m=%lld k=%d n=%d)",
-             (long long)m, k, n);
-  TT_REQUIRE(tt::aligned16(x) && tt::aligned16(w) && tt::aligned16(y), "tt_dense_fwd_f32: pointers must be 16-byte aligned");
-  GemmArgs a{};
-  a.A = x; a.B = w; a.C = y; a.M = m; a.N = n; a.K = k; a.lda = k; a.ldb = n; a.ldc = n;
-  a.bias = b; a.relu = relu; a.k_per_split = (k + BK - 1) / BK * BK;
-  if (drop_rate > 0.f) {
-    a.drop_p24 = (uint32_t)((double)drop_rate * 16777216.0 + 0.5);
-    a.drop_scale = 1.0f / (1.0f - drop_rate);
-    a.drop_key = dropout_stream_key(seed, tensor_id);
-    a.drop_offset = counter_offset;
-  }
-  return launch<true, false, false>(a, 1, tt::as_stream(stream), "tt_dense_fwd_f32", "dense_fwd");
+  const tt_dense_fwd_args q{x, w, b, y, tensor_id};
+  return tt_dense_fwd_batched_f32(&q, 1, m, k, n, relu, drop_rate, seed, counter_offset, stream);
 }
 
 extern "C" int32_t tt_dense_bwd_num_slabs(int64_t m) {
@@ -236,6 +261,37 @@ extern "C" int32_t tt_dense_bwd_num_slabs(int64_t m) {
   if (s < 1) s = 1;
   if (s > 32) s = 32;
   return (int32_t)s;
+}
+
+extern "C" int tt_dense_bwd_batched_f32(const tt_dense_bwd_args* probs, int32_t n_probs, float dx_scale, int64_t m, int32_t k,
+                                        int32_t n, tt_stream_t stream_) {
+  TT_REQUIRE(probs != nullptr && n_probs >= 1 && n_probs <= 2, "tt_dense_bwd_batched_f32: 1 or 2 problems");
+  TT_REQUIRE(m > 0 && k > 0 && n > 0 && k % 4 == 0 && n % 4 == 0, "tt_dense_bwd_f32: need m>0, k%%4==0, n%%4==0 (m=%lld k=%d n=%d)",
+             (long long)m, k, n);
+  hipStream_t stream = tt::as_stream(stream_);
+  GemmArgs ax[2] = {}, aw[2] = {};
+  const int splits = tt_dense_bwd_num_slabs(m);
+  const bool want_dx = probs[0].dx != nullptr;
+  for (int i = 0; i < n_probs; ++i) {
+    const tt_dense_bwd_args& q = probs[i];
+    TT_REQUIRE(q.x && q.w && q.dz && q.dw_slabs && q.db_slabs, "tt_dense_bwd_f32: null pointer");
+    TT_REQUIRE((q.dx != nullptr) == want_dx, "tt_dense_bwd_batched_f32: dx must be given for all problems or for none");
+    TT_REQUIRE(tt::aligned16(q.x) && tt::aligned16(q.w) && tt::aligned16(q.dz) && tt::aligned16(q.dw_slabs) &&
+                   (q.dx == nullptr || tt::aligned16(q.dx)),
+               "tt_dense_bwd_f32: pointers must be 16-byte aligned");
+    // dx[m][k] = sum_n dz[m][n] * w[k][n]
+    ax[i].A = q.dz; ax[i].B = q.w; ax[i].C = q.dx; ax[i].M = m; ax[i].N = k; ax[i].K = n; ax[i].lda = n; ax[i].ldb = n; ax[i].ldc = k;
+    ax[i].mask_src = q.dx_relu_src; ax[i].mask_scale = dx_scale; ax[i].k_per_split = (n + BK - 1) / BK * BK;
+    // dw[k][n] = sum_b x[b][k] * dz[b][n], split over the batch into slabs; db rides along
+    aw[i].A = q.x; aw[i].B = q.dz; aw[i].C = q.dw_slabs; aw[i].M = k; aw[i].N = n; aw[i].K = m; aw[i].lda = k; aw[i].ldb = n; aw[i].ldc = n;
+    aw[i].k_per_split = ((m + splits - 1) / splits + BK - 1) / BK * BK;
+    aw[i].slab_stride = (int64_t)k * n;
+    aw[i].db_slabs = q.db_slabs;
+    aw[i].mask_scale = 1.f;
+  }
+  int rc;
+  if (want_dx && (rc = launch<true, true, false>(ax, n_probs, 1, stream, "tt_dense_bwd_f32(dx)", "dense_bwd_dx")) != TT_OK) return rc;
+  return launch<false, false, true>(aw, n_probs, splits, stream, "tt_dense_bwd_f32(dw)", "dense_bwd_dw");
 }
 
 extern "C" int tt_dense_bwd_f32(const float* x, const float* w, const float* dz, float* dx, const float* dx_relu_src,
@@ -246,30 +302,6 @@ extern "C" int tt_dense_bwd_f32(const float* x, const float* w, const float* dz,
 extern "C" int tt_dense_bwd_scaled_f32(const float* x, const float* w, const float* dz, float* dx, const float* dx_relu_src,
                                        float dx_scale, float* dw_slabs, float* db_slabs, int64_t m, int32_t k, int32_t n,
                                        tt_stream_t stream_) {
-  TT_REQUIRE(x && w && dz && dw_slabs && db_slabs, "tt_dense_bwd_f32: null pointer");
-  TT_REQUIRE(m > 0 && k > 0 && n > 0 && k % 4 == 0 && n % 4 == 0, "tt_dense_bwd_f32: need m>0, k%%4==0, n%%4==0 (m=%lld k=%d n=%d)",
-             (long long)m, k, n);
-  TT_REQUIRE(tt::aligned16(x) && tt::aligned16(w) && tt::aligned16(dz) && tt::aligned16(dw_slabs) &&
-                 (dx == nullptr || tt::aligned16(dx)),
-             "tt_dense_bwd_f32: pointers must be 16-byte aligned");
-  hipStream_t stream = tt::as_stream(stream_);
-  int rc;
-  if (dx != nullptr) {
-    // dx[m][k] = sum_n dz[m][n] * w[k][n]
-    GemmArgs a{};
-    a.A = dz; a.B = w; a.C = dx; a.M = m; a.N = k; a.K = n; a.lda = n; a.ldb = n; a.ldc = k;
-    a.mask_src = dx_relu_src; a.mask_scale = dx_scale; a.k_per_split = (n + BK - 1) / BK * BK;
-    if ((rc = launch<true, true, false>(a, 1, stream, "tt_dense_bwd_f32(dx)", "dense_bwd_dx")) != TT_OK) return rc;
-  }
-  {
-    // dw[k][n] = sum_b x[b][k] * dz[b][n], split over the batch into slabs; db rides along
-    const int splits = tt_dense_bwd_num_slabs(m);
-    GemmArgs a{};
-    a.A = x; a.B = dz; a.C = dw_slabs; a.M = k; a.N = n; a.K = m; a.lda = k; a.ldb = n; a.ldc = n;
-    a.k_per_split = ((m + splits - 1) / splits + BK - 1) / BK * BK;
-    a.slab_stride = (int64_t)k * n;
-    a.db_slabs = db_slabs;
-    if ((rc = launch<false, false, true>(a, splits, stream, "tt_dense_bwd_f32(dw)", "dense_bwd_dw")) != TT_OK) return rc;
-  }
-  return TT_OK;
+  const tt_dense_bwd_args q{x, w, dz, dx, dx_relu_src, dw_slabs, db_slabs};
+  return tt_dense_bwd_batched_f32(&q, 1, dx_scale, m, k, n, stream_);
 }

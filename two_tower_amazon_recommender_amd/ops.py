@@ -268,6 +268,25 @@ def dense_bwd(x, w, dz, dx, dx_relu_src, dw_slabs, db_slabs, dx_scale: float = 1
     return ns
 
 
+def dense_fwd2(xs, ws, bs, ys, relu: bool, dropout=None):
+    """Layer l of both towers in one launch: ys[i] = act(xs[i] @ ws[i] + bs[i]).  dropout = (rate, seed, (tid_a, tid_b), offset)."""
+    m, k = xs[0].shape
+    n = ws[0].shape[1]
+    rate, seed, tids, off = dropout if dropout is not None else (0.0, 0, (0, 0), 0)
+    arr = (_lib.DenseFwdArgs * 2)(*[_lib.DenseFwdArgs(_p(xs[i]), _p(ws[i]), _p(bs[i]), _p(ys[i]), tids[i]) for i in range(2)])
+    _lib.check(_lib.load().tt_dense_fwd_batched_f32(arr, 2, m, k, n, int(relu), rate, seed, off, _stream()),
+               "tt_dense_fwd_batched_f32")
+
+
+def dense_bwd2(xs, ws, dzs, dxs, dx_relu_srcs, dw_slabs, db_slabs, dx_scale: float = 1.0):
+    """Backward of layer l of both towers: two launches (dx for both, dw+db for both)."""
+    m, k = xs[0].shape
+    n = ws[0].shape[1]
+    arr = (_lib.DenseBwdArgs * 2)(*[_lib.DenseBwdArgs(_p(xs[i]), _p(ws[i]), _p(dzs[i]), _p(dxs[i]), _p(dx_relu_srcs[i]),
+                                                     _p(dw_slabs[i]), _p(db_slabs[i])) for i in range(2)])
+    _lib.check(_lib.load().tt_dense_bwd_batched_f32(arr, 2, dx_scale, m, k, n, _stream()), "tt_dense_bwd_batched_f32")
+
+
 def dense_update_(segs: list[DenseSeg], opt: str, lr: float, eps: float = 1e-7, apply: bool = True):
     arr = (DenseSeg * len(segs))(*segs)
     lib = _lib.load()

@@ -126,6 +126,33 @@ class Tower:
         return segs
 
 
+def towers_forward(ut: "Tower", it: "Tower", dropout=None):
+    """Both towers layer by layer, one launch per layer (the towers have identical shapes).
+    dropout = (rate, seed, first_global_row) in training, None at inference."""
+    for l in range(ut.n_layers):
+        hidden = l < ut.n_layers - 1
+        d = None
+        if dropout is not None and hidden and dropout[0] > 0.0:
+            rate, seed, row0 = dropout
+            d = (rate, seed, (TID_DROPOUT_BASE + 2 * l, TID_DROPOUT_BASE + 2 * l + 1), row0 * ut.dims[l + 1])
+        ops.dense_fwd2((ut.acts[l], it.acts[l]), (ut.w[l], it.w[l]), (ut.b[l], it.b[l]), (ut.acts[l + 1], it.acts[l + 1]),
+                       relu=hidden, dropout=d)
+    return ut.acts[-1], it.acts[-1]
+
+
+def towers_backward(ut: "Tower", it: "Tower", dropout_rate: float = 0.0):
+    """Backward of both towers, two launches per layer (dx of both, dw+db of both)."""
+    scale = 1.0
+    if dropout_rate > 0.0:
+        one = torch.ones((), dtype=torch.float32)
+        scale = (one / (one - torch.tensor(dropout_rate, dtype=torch.float32))).item()
+    for l in range(ut.n_layers - 1, -1, -1):
+        dxs = (ut.dz[l - 1], it.dz[l - 1]) if l > 0 else (ut.demb, it.demb)
+        masks = (ut.acts[l], it.acts[l]) if l > 0 else (None, None)
+        ops.dense_bwd2((ut.acts[l], it.acts[l]), (ut.w[l], it.w[l]), (ut.dz[l], it.dz[l]), dxs, masks,
+                       (ut.dw_slabs[l], it.dw_slabs[l]), (ut.db_slabs[l], it.db_slabs[l]), dx_scale=scale if l > 0 else 1.0)
+
+
 class TwoTowerTrainer:
     def __init__(self, cfg: TwoTowerConfig, device="cuda:0", seed: int | None = None):
         cfg.validate()
@@ -191,14 +218,12 @@ class TwoTowerTrainer:
         cfg, ut, it = self.cfg, self.user_tower, self.item_tower
         ops.embedding_gather2(self.user_table, user_ids, ut.acts[0], self.item_table, item_ids, it.acts[0], self.oob)
         row0 = self.step_index * cfg.batch_size
-        q = ut.forward((cfg.dropout_rate, self.dropout_seed, 0, row0))
-        c = it.forward((cfg.dropout_rate, self.dropout_seed, 1, row0))
+        q, c = towers_forward(ut, it, (cfg.dropout_rate, self.dropout_seed, row0))
         kw = dict(sample_weight=sample_weight, cand_prob=candidate_sampling_probability, cand_ids=candidate_ids)
         # loss + dq + dc in two fused passes over the logits (never materialised)
         ops.retrieval_fwd_bwd(q, c, 1.0 / cfg.temperature, self.ws, self.lse, self.per_row, self.loss,
                               ut.dz[-1], it.dz[-1], **kw)
-        ut.backward(cfg.dropout_rate)
-        it.backward(cfg.dropout_rate)
+        towers_backward(ut, it, cfg.dropout_rate)
         self.step_index += 1
         return self.loss
 
@@ -228,7 +253,7 @@ class TwoTowerTrainer:
         """Forward only (validation loss, SUM over the batch); device tensor, unsynchronised."""
         cfg, ut, it = self.cfg, self.user_tower, self.item_tower
         ops.embedding_gather2(self.user_table, user_ids, ut.acts[0], self.item_table, item_ids, it.acts[0], self.oob)
-        q, c = ut.forward(), it.forward()
+        q, c = towers_forward(ut, it)
         kw = dict(sample_weight=loss_kw.get("sample_weight"), cand_prob=loss_kw.get("candidate_sampling_probability"),
                   cand_ids=loss_kw.get("candidate_ids"))
         return ops.retrieval_fwd(q, c, 1.0 / cfg.temperature, self.ws, self.lse, self.per_row, self.loss, **kw)
