@@ -37,6 +37,8 @@ def test_synthetic_init_is_bit_identical_to_oracle(dev):
     ("cfg3-small-adagrad", (50_000, 100_000, 128, [256, 128], 2048), "adagrad", "Z"),
     ("ref-config-towers", (5_000, 5_000, 128, [512, 256, 128], 1024), "sgd", "U"),
     ("ref-config-dropout0.1", (5_000, 5_000, 128, [512, 256, 128], 1024), "adagrad", "Z"),
+    ("ragged-batch-777", (3_000, 2_000, 64, [96, 64], 777), "adagrad", "Z"),
+    ("cfg5-dims-256", (4_000, 4_000, 256, [512, 256], 1536), "adagrad", "U"),
 ])
 def test_train_steps_match_oracle(dev, name, shape, opt, variant):
     n_users, n_items, dim, tower_dims, batch = shape
@@ -187,3 +189,16 @@ def test_evaluate_topk_against_item_corpus(dev):
     assert (r >= lo).all() and (r <= hi).all()
     res = m.result()
     assert res["recall@100"] > 0.3                                  # trained pairs are retrievable
+
+
+def test_two_tower_model_facade(dev):
+    from two_tower_amazon_recommender_amd.model import TwoTowerModel
+    cfg = TwoTowerConfig(n_users=500, n_items=400, embedding_dim=32, tower_dims=[32], batch_size=128, optimizer="sgd")
+    m = TwoTowerModel(cfg, dev, seed=3)
+    u, i = m.trainer.synthetic_batch(3, 0)
+    out = m.train_step({"user_idx": u, "item_idx": i})
+    assert out["loss"].item() > 0
+    val = m.test_step({"user_id_encoded": u, "item_id_encoded": i})      # the preprocessor's column names work too
+    assert val["loss"].item() > 0
+    with pytest.raises(KeyError):
+        m.train_step({"user": u, "item": i})

