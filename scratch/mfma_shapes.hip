@@ -31,8 +31,8 @@ int main() {
   float h[1024]; for (int i = 0; i < 1024; ++i) h[i] = (float)rand() / RAND_MAX - 0.5f;
   hipMemcpy(in, h, 4096, hipMemcpyHostToDevice);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  const int iters = 20000, blocks = 2048;          // 8 waves per CU
-  for (int rep = 0; rep < 3; ++rep) {
+  const int iters = 40000, blocks = 512;            // 2 workgroups per CU = 2 waves per SIMD (the score kernel's occupancy)
+  for (int rep = 0; rep < 8; ++rep) {
     for (int which = 0; which < 2; ++which) {
       hipEventRecord(e0);
       if (which == 0) hipLaunchKernelGGL(k32, dim3(blocks), dim3(256), 0, 0, in, out, iters);

@@ -68,15 +68,16 @@ struct Geo {
   static constexpr int NB = D / 32;            // GEMM2 d-blocks (d = NB*lane_row + b)
   static constexpr int TILE_F = 32 * LS;
   static constexpr int BUF_F = TILE_F + 160;   // + a_c[32] + s_c[32] + id_c[32] (int64) + h_c[32]
-  static constexpr int NV = (32 * D / 4) / 256 > 0 ? (32 * D / 4) / 256 : 1;   // staged float4 per thread
-  static constexpr int LDS_BYTES = 2 * BUF_F * 4;
+  static constexpr int LDS_BYTES = 2 * BUF_F * 4;      // 4-wave schedule: 2 buffers
 };
 
-template <int D, int MODE, bool HAS_IDS, bool HAS_HN>
-__global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void score_kernel(ScoreArgs p) {
+template <int D, int MODE, bool HAS_IDS, bool HAS_HN, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? 2 : 1))) void score_kernel(ScoreArgs p) {
   using G_ = Geo<D>;
-  constexpr int LS = G_::LS, NG = G_::NG, NB = G_::NB, TILE_F = G_::TILE_F, BUF_F = G_::BUF_F, NV = G_::NV;
+  constexpr int LS = G_::LS, NG = G_::NG, NB = G_::NB, TILE_F = G_::TILE_F, BUF_F = G_::BUF_F;
   constexpr int ROW4 = D / 4;                       // float4 per K row
+  constexpr int THREADS = WAVES * 64;
+  constexpr int NV = (32 * ROW4 + THREADS - 1) / THREADS;   // staged float4 per thread
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x;
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void score_kernel(ScoreArg
 
   const int split = blockIdx.x % p.nsplit;
   const int64_t rblk = blockIdx.x / p.nsplit;
-  const int64_t r0w = rblk * 128 + wave * 32;       // first row of this wave
+  const int64_t r0w = rblk * (WAVES * 32) + wave * 32;   // first row of this wave
   const int64_t r = r0w + ln;                       // this lane's row (both halves)
   const bool r_ok = r < p.n_r;
   const int64_t c_begin = (int64_t)split * p.c_per_split;
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void score_kernel(ScoreArg
   const float hr = (HAS_HN && p.h_r != nullptr && r_ok) ? p.h_r[r] : -3.0e38f;
   const float* hcp = (HAS_HN && p.h_c != nullptr) ? p.h_c + c_begin + tid : nullptr;
   int64_t st_id = -2;
-  constexpr int RPJ = 256 / ROW4;                   // tile rows between a thread's consecutive float4s
+  constexpr int RPJ = THREADS / ROW4 > 0 ? THREADS / ROW4 : 1;   // tile rows between a thread's consecutive float4s
   const int st_row = tid / ROW4, st_col4 = tid % ROW4;
   const f32x4* kp = reinterpret_cast<const f32x4*>(p.K) + c_begin * ROW4 + tid;   // tile 0
   const float* acp = p.a_c != nullptr ? p.a_c + c_begin + tid : nullptr;
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void score_kernel(ScoreArg
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       const int row = st_row + j * RPJ;
-      st[j] = (row < 32 && row < nvalid) ? src[256 * j] : f32x4{0.f, 0.f, 0.f, 0.f};
+      st[j] = (row < 32 && row < nvalid) ? src[THREADS * j] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if (tid < 32) {
       const bool ok = tid < nvalid;
@@ -172,15 +173,8 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void score_kernel(ScoreArg
     store_tile(0);
   }
   __syncthreads();
-
-  for (int t = 0; t < ntiles; ++t) {
-    // FWD: prefetch the next tile at the top.  BWD: registers are tight (rf + G + X + coef), so the
-    // prefetch is issued just before GEMM2, whose 16*NB MFMAs (>= 1.7 us at D=128) cover its latency.
-    if constexpr (MODE == MODE_FWD || MODE == MODE_RANK) { if (t + 1 < ntiles) load_tile(t + 1); }
-    const float* T = smem + (t & 1) * BUF_F;
-    const int64_t c0 = c_begin + 32 * (int64_t)t;
-
-    // ---- GEMM1: X[c][r] ----
+  // ---- GEMM1: X[c][r] = sum_d K[c][d] R[r][d] ----
+  auto gemm1 = [&](const float* T) -> f32x16 {
     f32x16 X;
 #pragma unroll
     for (int i = 0; i < 16; ++i) X[i] = 0.f;
@@ -201,7 +195,12 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void score_kernel(ScoreArg
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    return X;
+  };
 
+  // ---- per-tile softmax math on the accumulator: statistics (FWD/RANK/FUSED) and the GEMM2 coefficients (BWD/FUSED) ----
+  auto epilogue = [&](const float* T, int t, const f32x16& X, float (&coef)[16]) {
+    const int64_t c0 = c_begin + 32 * (int64_t)t;
     // ---- per-column terms of this lane's 16 accumulator rows: c = c0 + 8*q + 4*h + i ----
     float ac[16], sc[16];
 #pragma unroll
@@ -276,7 +275,6 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void score_kernel(ScoreArg
       run_l = run_l * __builtin_amdgcn_exp2f(run_m - m_new) + sum;
       run_m = m_new;
     } else {
-      float coef[16];
       if constexpr (MODE == MODE_BWD) {
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
@@ -329,7 +327,10 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void score_kernel(ScoreArg
         }
         run_l += sum;
       }
-      if (t + 1 < ntiles) load_tile(t + 1);
+    }
+  };
+
+  auto gemm2 = [&](const float* T, const float (&coef)[16]) {
       // ---- GEMM2: G^T[d = NB*i + b][r] += K[c(reg,h)][d] * coef[reg] ----
       const float* kbase = T + 4 * h * LS + NB * ln;
       f32x4 kc0, kc1;
@@ -363,10 +364,25 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void score_kernel(ScoreArg
         kc0 = kn0; kc1 = kn1;
         __builtin_amdgcn_sched_barrier(0);
       }
-    }
+  };
 
-    if (t + 1 < ntiles) store_tile((t + 1) & 1);
-    __syncthreads();
+  {
+    // ---- every wave runs GEMM1 -> epilogue -> GEMM2 per tile; 2 LDS buffers, one barrier per tile ----
+    for (int t = 0; t < ntiles; ++t) {
+      // FWD/RANK: prefetch the next tile at the top.  BWD/FUSED: registers are tight (rf + G + X + coef), so the
+      // prefetch is issued just before GEMM2, whose 16*NB MFMAs (>= 1.7 us at D=128) cover its latency.
+      if constexpr (MODE == MODE_FWD || MODE == MODE_RANK) { if (t + 1 < ntiles) load_tile(t + 1); }
+      const float* T = smem + (t & 1) * BUF_F;
+      const f32x16 X = gemm1(T);
+      float coef[16];
+      epilogue(T, t, X, coef);
+      if constexpr (MODE == MODE_BWD || MODE == MODE_FUSED) {
+        if (t + 1 < ntiles) load_tile(t + 1);
+        gemm2(T, coef);
+      }
+      if (t + 1 < ntiles) store_tile((t + 1) & 1);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue ----
@@ -674,25 +690,38 @@ WsLayout ws_layout(int64_t nq, int64_t nc, int32_t dim) {
   return w;
 }
 
+// 4 waves (128 rows) per workgroup, two workgroups per CU.  An 8-wave variant whose two wave groups run one phase apart
+// (GEMM1 | GEMM2, epilogue | GEMM1, GEMM2 | epilogue, a barrier per phase) was built and measured: no gain (277 vs 271 us).
+// Ablation on MI355X (B = 8192, D = 128; us per launch): all 272 | no epilogue math 257 | no tile staging 270 |
+// no GEMM1 171 | no GEMM2 171 | neither GEMM 58 | nothing but the loop skeleton 34.  So the two GEMMs together cost
+// 220 us = 156 TF, the f32 MFMA peak; what is left is ~34 us of fixed cost (prologue, per-tile barriers, 33.5 MB of
+// slab stores, drain) and ~20 us around the softmax epilogue that the partner wave's MFMAs do not hide (f32-input
+// MFMA runs at the f32 vector rate; a 25 % cut of the epilogue's VALU instructions changed nothing measurable, so the
+// cost is in the GEMM1 -> epilogue -> GEMM2 dependency hand-offs rather than in VALU throughput).
 template <int D, int MODE>
-int launch_score(const ScoreArgs& a, bool has_ids, hipStream_t stream) {
-  const int64_t nrb = (a.n_r + 127) / 128;
-  const int64_t blocks = nrb * a.nsplit;
+constexpr int waves_for() { return 4; }
+
+template <int D, int MODE>
+int launch_score(const ScoreArgs& a_in, bool has_ids, hipStream_t stream) {
+  constexpr int W = waves_for<D, MODE>();
+  const int64_t nrb = (a_in.n_r + W * 32 - 1) / (W * 32);
+  const int64_t blocks = nrb * a_in.nsplit;
   const int lds = Geo<D>::LDS_BYTES;
-  const bool has_hn = (a.h_r != nullptr) || (a.h_c != nullptr);
+  const bool has_hn = (a_in.h_r != nullptr) || (a_in.h_c != nullptr);
+  const ScoreArgs& a = a_in;
   auto go = [&](auto kern) -> int {
-    if constexpr (Geo<D>::LDS_BYTES > 64 * 1024) {   // above the 64 KiB default the limit must be raised (cheap, idempotent)
+    if (lds > 64 * 1024) {   // above the 64 KiB default the limit must be raised (cheap, idempotent)
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return tt::fail(TT_ERR_LAUNCH, "hipFuncSetAttribute(LDS %d) failed", lds);
     }
     tt::ProfScope prof(MODE == MODE_FWD ? "score_fwd" : (MODE == MODE_BWD ? "score_bwd" : (MODE == MODE_FUSED ? "score_fused" : "score_rank")), stream);
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(W * 64), lds, stream, a);
     return tt::check_launch(MODE == MODE_FWD ? "score_fwd" : (MODE == MODE_BWD ? "score_bwd" : "score_fused"));
   };
-  if (has_ids && has_hn) return go(score_kernel<D, MODE, true, true>);
-  if (has_ids) return go(score_kernel<D, MODE, true, false>);
-  if (has_hn) return go(score_kernel<D, MODE, false, true>);
-  return go(score_kernel<D, MODE, false, false>);
+  if (has_ids && has_hn) return go(score_kernel<D, MODE, true, true, W>);
+  if (has_ids) return go(score_kernel<D, MODE, true, false, W>);
+  if (has_hn) return go(score_kernel<D, MODE, false, true, W>);
+  return go(score_kernel<D, MODE, false, false, W>);
 }
 
 template <int MODE>
