@@ -451,33 +451,21 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__
   }
 }
 
-// lse / per-row loss / total loss from the per-split (max, sum) pairs.  One workgroup: the total is
-// a fixed-order sum (bitwise reproducible).
-__global__ __launch_bounds__(1024) void fwd_combine_kernel(const float* __restrict__ part_m, const float* __restrict__ part_l,
-                                                           const float* __restrict__ pos2, const float* __restrict__ w,
-                                                           int64_t n_r, int nsplit, float* __restrict__ lse,
-                                                           float* __restrict__ per_row, float* __restrict__ loss) {
-  __shared__ float red[1024];
-  float acc = 0.f;
-  for (int64_t r = threadIdx.x; r < n_r; r += 1024) {
-    float M = kNegBig;
-    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, part_m[(int64_t)s * n_r + r]);
-    float L = 0.f;
-    for (int s = 0; s < nsplit; ++s)
-      L += part_l[(int64_t)s * n_r + r] * __builtin_amdgcn_exp2f(part_m[(int64_t)s * n_r + r] - M);
-    const float lse2 = M + __log2f(L);
-    const float row = (lse2 - pos2[r]) * kLn2 * (w != nullptr ? w[r] : 1.0f);
-    lse[r] = lse2 * kLn2;
-    per_row[r] = row;
-    acc += row;
-  }
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  for (int s = 512; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) loss[0] = red[0];
+// lse / per-row loss from the per-split (max, sum) pairs (the total is summed by sum_rows_kernel in a fixed order)
+__global__ __launch_bounds__(256) void fwd_combine_kernel(const float* __restrict__ part_m, const float* __restrict__ part_l,
+                                                          const float* __restrict__ pos2, const float* __restrict__ w,
+                                                          int64_t n_r, int nsplit, float* __restrict__ lse,
+                                                          float* __restrict__ per_row) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n_r) return;
+  float M = kNegBig;
+  for (int s = 0; s < nsplit; ++s) M = fmaxf(M, part_m[(int64_t)s * n_r + r]);
+  float L = 0.f;
+  for (int s = 0; s < nsplit; ++s)
+    L += part_l[(int64_t)s * n_r + r] * __builtin_amdgcn_exp2f(part_m[(int64_t)s * n_r + r] - M);
+  const float lse2 = M + __log2f(L);
+  lse[r] = lse2 * kLn2;
+  per_row[r] = (lse2 - pos2[r]) * kLn2 * (w != nullptr ? w[r] : 1.0f);
 }
 
 // FUSED pass 1 epilogue: per-split (max, sum, G) -> lse, per-row loss, the per-row terms of the dc pass, and
@@ -660,6 +648,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const f32x4* __restri
 int choose_nsplit(int64_t n_r, int64_t n_c) {
   const int64_t nrb = (n_r + 127) / 128;
   int ns = 1;
+  // 512 workgroups = two per CU measured best at B = 8192 (256: 291 us, 512: 272 us, 1024: 283 us, 2048: 294 us per launch)
   while (nrb * ns < 512 && (int64_t)ns * 2 * 64 <= n_c && ns < 64) ns *= 2;
   return ns;
 }
@@ -786,9 +775,11 @@ extern "C" int tt_retrieval_fwd_f32(const float* q, const float* c, int64_t nq, 
   a.pos2 = reinterpret_cast<float*>(ws + w.off_pos);
   if ((rc = dispatch_score<MODE_FWD>(dim, a, cand_ids != nullptr, stream)) != TT_OK) return rc;
   tt::ProfScope prof("score_aux", stream);
-  hipLaunchKernelGGL(fwd_combine_kernel, dim3(1), dim3(1024), 0, stream, a.part_m, a.part_l, a.pos2, sample_weight, nq,
-                     a.nsplit, lse, per_row, loss);
-  return tt::check_launch("fwd_combine");
+  hipLaunchKernelGGL(fwd_combine_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, a.part_m, a.part_l, a.pos2,
+                     sample_weight, nq, a.nsplit, lse, per_row);
+  if ((rc = tt::check_launch("fwd_combine")) != TT_OK) return rc;
+  hipLaunchKernelGGL(sum_rows_kernel, dim3(1), dim3(1024), 0, stream, per_row, nq, loss);
+  return tt::check_launch("sum_rows");
 }
 
 extern "C" int tt_retrieval_bwd_f32(const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
