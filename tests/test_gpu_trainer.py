@@ -202,3 +202,30 @@ def test_two_tower_model_facade(dev):
     assert val["loss"].item() > 0
     with pytest.raises(KeyError):
         m.train_step({"user": u, "item": i})
+
+
+def test_sharded_trainer_global_negatives_world1_equals_local(dev):
+    """negatives="global" (all-gather candidates, diag offset, reduce-scatter dC) degenerates to the local form on one
+    rank; needs a process group, so a single-rank gloo group is created on the fly when none exists."""
+    import torch.distributed as dist
+    from two_tower_amazon_recommender_amd.sharded import ShardedTwoTowerTrainer
+    created = False
+    if not dist.is_initialized():
+        import os
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        created = True
+    try:
+        cfg = TwoTowerConfig(n_users=4000, n_items=3000, embedding_dim=64, tower_dims=[64], batch_size=512, optimizer="sgd",
+                             dropout_rate=0.1)
+        a = ShardedTwoTowerTrainer(TwoTowerConfig(**cfg.__dict__), dev, seed=17, negatives="local")
+        b = ShardedTwoTowerTrainer(TwoTowerConfig(**cfg.__dict__), dev, seed=17, negatives="global")
+        for step in range(2):
+            u, i = a.synthetic_batch(17, step, "Z")
+            la = a.step(u, i).clone(); lb = b.step(u, i).clone()
+            assert torch.equal(la, lb)
+        assert torch.equal(a.user_emb.table, b.user_emb.table) and torch.equal(a.dense_flat, b.dense_flat)
+        a.check_ids(); b.check_ids()
+    finally:
+        if created:
+            dist.destroy_process_group()
