@@ -313,7 +313,7 @@ def train_step(state: ModelState, user_ids, item_ids, lr, optimizer="sgd",
 
 
 def synthetic_state(seed, n_users, n_items, emb_dim, tower_dims, dtype=np.float64,
-                    optimizer="sgd") -> ModelState:
+                    optimizer="sgd", item_tower_dims=None) -> ModelState:
     """Deterministic init shared with the product's ``synthetic`` initialiser
     (oracle.synth tensor-id convention).  ``tower_dims`` = output dims of each
     Dense layer, e.g. [256, 128]; both towers share the shape."""
@@ -323,7 +323,7 @@ def synthetic_state(seed, n_users, n_items, emb_dim, tower_dims, dtype=np.float6
     towers = []
     for t in (0, 1):
         ws, bs, fan_in = [], [], emb_dim
-        for l, fan_out in enumerate(tower_dims):
+        for l, fan_out in enumerate(tower_dims if (t == 0 or item_tower_dims is None) else item_tower_dims):
             ws.append(synth.dense_kernel(seed, synth.dense_tid(t, l), fan_in, fan_out).astype(dtype))
             bs.append(np.zeros(fan_out, dtype=dtype))
             fan_in = fan_out

@@ -229,3 +229,22 @@ def test_sharded_trainer_global_negatives_world1_equals_local(dev):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_asymmetric_towers_match_oracle(dev):
+    """user_tower_dims != item_tower_dims (separate keys in configs/data_config.yaml:56-57): per-tower launches."""
+    n_users, n_items, dim, batch, seed = 3000, 2000, 64, 512, 23
+    cfg = TwoTowerConfig(n_users=n_users, n_items=n_items, embedding_dim=dim, tower_dims=[128, 64], item_tower_dims=[96, 80, 64],
+                         temperature=0.1, l2_regularization=1e-6, learning_rate=0.001, optimizer="adagrad", batch_size=batch)
+    tr = TwoTowerTrainer(cfg, dev, seed=seed)
+    ref = tt.synthetic_state(seed, n_users, n_items, dim, [128, 64], dtype=np.float64, optimizer="adagrad", item_tower_dims=[96, 80, 64])
+    for step in range(2):
+        u, i = tr.synthetic_batch(seed, step, "Z")
+        loss = tr.step(u, i).item()
+        masks = tuple([(t.acts[l + 1] > 0).cpu().numpy() for l in range(t.n_layers - 1)] for t in (tr.user_tower, tr.item_tower))
+        r = tt.train_step(ref, u.cpu().numpy(), i.cpu().numpy(), lr=0.001, optimizer="adagrad", temperature=0.1, l2=1e-6,
+                          relu_masks=masks)
+        assert abs(loss - r["loss"]) <= 1e-4 * abs(r["loss"])
+        assert np.abs(tr.item_tower.demb.cpu().numpy() - r["die"]).max() <= 1e-4 * np.abs(r["die"]).max()
+    assert np.abs(tr.item_tower.w[1].cpu().numpy() - ref.item_tower.weights[1]).max() <= 1e-5
+    assert np.abs(tr.user_table.cpu().numpy() - ref.user_table).max() <= 2e-6

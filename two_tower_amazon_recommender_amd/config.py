@@ -19,9 +19,6 @@ def model_config_from_dict(doc: dict, n_users: int, n_items: int, optimizer: str
     if not isinstance(m, dict):
         raise KeyError("config has no 'model:' block (configs/data_config.yaml:54)")
     user_dims, item_dims = list(m["user_tower_dims"]), list(m["item_tower_dims"])
-    if user_dims != item_dims:
-        raise NotImplementedError(f"user_tower_dims {user_dims} != item_tower_dims {item_dims}: towers of different "
-                                  "shape are not supported yet")
     tr, rt = m.get("training", {}), m.get("retrieval", {})
     sampling = rt.get("candidate_sampling", "in_batch")
     if sampling != "in_batch":
@@ -29,6 +26,7 @@ def model_config_from_dict(doc: dict, n_users: int, n_items: int, optimizer: str
     dropout = float(m.get("dropout_rate", 0.0)) if dropout_override is None else dropout_override
     cfg = TwoTowerConfig(
         n_users=n_users, n_items=n_items, embedding_dim=int(m["embedding_dim"]), tower_dims=user_dims,
+        item_tower_dims=None if item_dims == user_dims else item_dims,
         temperature=float(rt.get("temperature", 1.0)), l2_regularization=float(m.get("l2_regularization", 0.0)),
         learning_rate=float(tr.get("learning_rate", 0.001)), optimizer=optimizer,
         batch_size=int(tr.get("batch_size", 1024)), dropout_rate=dropout)

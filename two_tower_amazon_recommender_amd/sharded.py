@@ -200,12 +200,13 @@ class ShardedTwoTowerTrainer:
         if adagrad:
             self.user_emb.accum = torch.full_like(self.user_emb.table, cfg.adagrad_initial_accumulator)
             self.item_emb.accum = torch.full_like(self.item_emb.table, cfg.adagrad_initial_accumulator)
-        n_tower = Tower.param_count(cfg)
-        self.dense_flat = torch.zeros(2 * n_tower, device=dev)
+        n_tower = Tower.param_count(cfg, cfg.user_dims)
+        n_item = Tower.param_count(cfg, cfg.item_dims)
+        self.dense_flat = torch.zeros(n_tower + n_item, device=dev)
         self.dense_accum = torch.full_like(self.dense_flat, cfg.adagrad_initial_accumulator) if adagrad else None
         self.dense_grad = torch.empty_like(self.dense_flat)
-        self.user_tower = Tower(cfg, self.dense_flat, self.dense_accum, 0, dev)
-        self.item_tower = Tower(cfg, self.dense_flat, self.dense_accum, n_tower, dev)
+        self.user_tower = Tower(cfg, cfg.user_dims, self.dense_flat, self.dense_accum, 0, dev)
+        self.item_tower = Tower(cfg, cfg.item_dims, self.dense_flat, self.dense_accum, n_tower, dev)
         l2 = cfg.l2_regularization
         # pass 1: slabs -> flat gradient (no update); pass 2 (after the all-reduce): update from the flat gradient
         self._segs_reduce = self.user_tower.segments(l2, self.dense_grad, 0) + \

@@ -35,7 +35,8 @@ class TwoTowerConfig:
     n_users: int
     n_items: int
     embedding_dim: int = 128                       # configs/data_config.yaml:55
-    tower_dims: list = field(default_factory=lambda: [512, 256, 128])   # :56-57 (both towers)
+    tower_dims: list = field(default_factory=lambda: [512, 256, 128])   # :56 user_tower_dims (and the item tower's if below is None)
+    item_tower_dims: list | None = None            # :57 item_tower_dims; None = same as tower_dims
     temperature: float = 0.1                       # :70
     l2_regularization: float = 1e-6                # :59
     learning_rate: float = 0.001                   # :63
@@ -45,11 +46,25 @@ class TwoTowerConfig:
     batch_size: int = 1024                         # :62
     dropout_rate: float = 0.0                      # :58 is 0.1; parity/bench runs use 0
 
+    @property
+    def user_dims(self) -> list:
+        return list(self.tower_dims)
+
+    @property
+    def item_dims(self) -> list:
+        return list(self.tower_dims if self.item_tower_dims is None else self.item_tower_dims)
+
+    @property
+    def symmetric(self) -> bool:
+        return self.user_dims == self.item_dims
+
     def validate(self):
         if self.optimizer not in ("sgd", "adagrad"):
             raise ValueError(f"optimizer must be 'sgd' or 'adagrad', got {self.optimizer!r}")
-        if self.embedding_dim % 4 or any(d % 4 for d in self.tower_dims):
+        if self.embedding_dim % 4 or any(d % 4 for d in self.user_dims + self.item_dims):
             raise ValueError("embedding_dim and tower dims must be multiples of 4")
+        if self.user_dims[-1] != self.item_dims[-1]:
+            raise ValueError("both towers must end in the same (scorer) dimension")
         if self.tower_dims[-1] not in (32, 64, 128, 256):
             raise ValueError("the last tower dim (scorer dim) must be one of 32, 64, 128, 256")
         if not 0.0 <= self.dropout_rate < 1.0:
@@ -61,9 +76,9 @@ class TwoTowerConfig:
 class Tower:
     """Dense stack: ReLU on all but the last layer (Keras Dense)."""
 
-    def __init__(self, cfg: TwoTowerConfig, flat: torch.Tensor, flat_acc, offset: int, dev):
-        self.dims = [cfg.embedding_dim] + list(cfg.tower_dims)
-        self.n_layers = len(cfg.tower_dims)
+    def __init__(self, cfg: TwoTowerConfig, tower_dims: list, flat: torch.Tensor, flat_acc, offset: int, dev):
+        self.dims = [cfg.embedding_dim] + list(tower_dims)
+        self.n_layers = len(tower_dims)
         b = cfg.batch_size
         self.w, self.b, self.w_acc, self.b_acc = [], [], [], []
         for l in range(self.n_layers):
@@ -86,9 +101,9 @@ class Tower:
         self.db_slabs = [torch.empty(ns, self.dims[l + 1], device=dev) for l in range(self.n_layers)]
 
     @staticmethod
-    def param_count(cfg: TwoTowerConfig) -> int:
-        dims = [cfg.embedding_dim] + list(cfg.tower_dims)
-        return sum(dims[l] * dims[l + 1] + dims[l + 1] for l in range(len(cfg.tower_dims)))
+    def param_count(cfg: TwoTowerConfig, tower_dims: list) -> int:
+        dims = [cfg.embedding_dim] + list(tower_dims)
+        return sum(dims[l] * dims[l + 1] + dims[l + 1] for l in range(len(tower_dims)))
 
     def forward(self, dropout=None):
         """dropout = (rate, seed, tower_index, first_global_row) in training; None = inference (no dropout).
@@ -166,12 +181,12 @@ class TwoTowerTrainer:
         self.item_table = torch.empty(cfg.n_items, d, device=dev)
         self.user_accum = torch.full_like(self.user_table, cfg.adagrad_initial_accumulator) if adagrad else None
         self.item_accum = torch.full_like(self.item_table, cfg.adagrad_initial_accumulator) if adagrad else None
-        n_tower = Tower.param_count(cfg)
-        self.dense_flat = torch.zeros(2 * n_tower, device=dev)
+        n_user, n_item = Tower.param_count(cfg, cfg.user_dims), Tower.param_count(cfg, cfg.item_dims)
+        self.dense_flat = torch.zeros(n_user + n_item, device=dev)
         self.dense_accum = torch.full_like(self.dense_flat, cfg.adagrad_initial_accumulator) if adagrad else None
         self.dense_grad = torch.empty_like(self.dense_flat)        # summed gradients (multi-GPU all-reduce bucket)
-        self.user_tower = Tower(cfg, self.dense_flat, self.dense_accum, 0, dev)
-        self.item_tower = Tower(cfg, self.dense_flat, self.dense_accum, n_tower, dev)
+        self.user_tower = Tower(cfg, cfg.user_dims, self.dense_flat, self.dense_accum, 0, dev)
+        self.item_tower = Tower(cfg, cfg.item_dims, self.dense_flat, self.dense_accum, n_user, dev)
         sd = cfg.tower_dims[-1]
         self.ws = torch.empty(ops.retrieval_workspace_bytes(b, b, sd), dtype=torch.uint8, device=dev)
         self.lse = torch.empty(b, device=dev)
@@ -218,12 +233,20 @@ class TwoTowerTrainer:
         cfg, ut, it = self.cfg, self.user_tower, self.item_tower
         ops.embedding_gather2(self.user_table, user_ids, ut.acts[0], self.item_table, item_ids, it.acts[0], self.oob)
         row0 = self.step_index * cfg.batch_size
-        q, c = towers_forward(ut, it, (cfg.dropout_rate, self.dropout_seed, row0))
+        if cfg.symmetric:        # same shapes: every layer of both towers in one launch
+            q, c = towers_forward(ut, it, (cfg.dropout_rate, self.dropout_seed, row0))
+        else:
+            q = ut.forward((cfg.dropout_rate, self.dropout_seed, 0, row0))
+            c = it.forward((cfg.dropout_rate, self.dropout_seed, 1, row0))
         kw = dict(sample_weight=sample_weight, cand_prob=candidate_sampling_probability, cand_ids=candidate_ids)
         # loss + dq + dc in two fused passes over the logits (never materialised)
         ops.retrieval_fwd_bwd(q, c, 1.0 / cfg.temperature, self.ws, self.lse, self.per_row, self.loss,
                               ut.dz[-1], it.dz[-1], **kw)
-        towers_backward(ut, it, cfg.dropout_rate)
+        if cfg.symmetric:
+            towers_backward(ut, it, cfg.dropout_rate)
+        else:
+            ut.backward(cfg.dropout_rate)
+            it.backward(cfg.dropout_rate)
         self.step_index += 1
         return self.loss
 
@@ -253,7 +276,7 @@ class TwoTowerTrainer:
         """Forward only (validation loss, SUM over the batch); device tensor, unsynchronised."""
         cfg, ut, it = self.cfg, self.user_tower, self.item_tower
         ops.embedding_gather2(self.user_table, user_ids, ut.acts[0], self.item_table, item_ids, it.acts[0], self.oob)
-        q, c = towers_forward(ut, it)
+        q, c = towers_forward(ut, it) if cfg.symmetric else (ut.forward(), it.forward())
         kw = dict(sample_weight=loss_kw.get("sample_weight"), cand_prob=loss_kw.get("candidate_sampling_probability"),
                   cand_ids=loss_kw.get("candidate_ids"))
         return ops.retrieval_fwd(q, c, 1.0 / cfg.temperature, self.ws, self.lse, self.per_row, self.loss, **kw)
@@ -292,7 +315,7 @@ class TwoTowerTrainer:
         return sd
 
     def load_state_dict(self, sd: dict):
-        for k in ("n_users", "n_items", "embedding_dim", "tower_dims", "optimizer"):
+        for k in ("n_users", "n_items", "embedding_dim", "tower_dims", "item_tower_dims", "optimizer"):
             if sd["config"][k] != getattr(self.cfg, k):
                 raise ValueError(f"checkpoint {k}={sd['config'][k]!r} does not match the trainer's {getattr(self.cfg, k)!r}")
         self.user_table.copy_(sd["user_table"]); self.item_table.copy_(sd["item_table"]); self.dense_flat.copy_(sd["dense"])
