@@ -1,0 +1,134 @@
+"""Two ranks of the row-sharded trainer on ONE GPU (both processes use cuda:0): every HIP kernel of the N>1 path runs
+with world = 2 — routing, owner gather, row/gradient exchange buffers, owner-side sort + fused update with duplicates
+across ranks, dense all-reduce — and the result is compared with the f64 oracle on the GLOBAL batch.  RCCL refuses
+two ranks on one device, so the collectives go through gloo on host copies (a test-local shim around
+torch.distributed); the exchange CODE under test is the product's."""
+import os
+import pathlib
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = pathlib.Path(__file__).resolve().parents[1]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
+def _install_host_bounce():
+    real_a2a, real_ar = dist.all_to_all_single, dist.all_reduce
+
+    def a2a(out, inp, group=None, async_op=False, **kw):
+        torch.cuda.synchronize()
+        o = torch.empty(out.shape, dtype=out.dtype)
+        real_a2a(o, inp.cpu(), group=group)
+        out.copy_(o)
+        return _Done()
+
+    def ar(t, op=dist.ReduceOp.SUM, group=None, async_op=False):
+        torch.cuda.synchronize()
+        c = t.cpu()
+        real_ar(c, op=op, group=group)
+        t.copy_(c)
+        return _Done()
+
+    dist.all_to_all_single, dist.all_reduce = a2a, ar
+
+
+def _worker(rank, world, port, opt, variant, ret):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        _install_host_bounce()
+        from oracle import synth, two_tower as tt
+        from two_tower_amazon_recommender_amd.sharded import ShardedTwoTowerTrainer
+        from two_tower_amazon_recommender_amd.trainer import TwoTowerConfig
+        dev = torch.device("cuda:0")
+        n_users, n_items, dim, tower_dims, b, seed = 3001, 2000, 64, [128, 64], 1024, 41
+        cfg = TwoTowerConfig(n_users=n_users, n_items=n_items, embedding_dim=dim, tower_dims=tower_dims, temperature=0.1,
+                             l2_regularization=1e-6, learning_rate=0.001, optimizer=opt, batch_size=b)
+        tr = ShardedTwoTowerTrainer(cfg, dev, seed=seed, negatives="local", capacity_factor=3.0)
+        ref = tt.synthetic_state(seed, n_users, n_items, dim, tower_dims, dtype=np.float64, optimizer=opt)
+        # each rank holds exactly its rows of the synthetic tables
+        assert np.array_equal(tr.user_emb.table.cpu().numpy()[:len(ref.user_table[rank::world])],
+                              ref.user_table[rank::world].astype(np.float32))
+        for step in range(2):
+            u, i = tr.synthetic_batch(seed, step, variant)
+            loss = tr.step(u, i).item()
+            tr.check_ids()
+            # oracle: forward/backward of EVERY rank's sub-batch on the shared state, then one update with all gradients
+            subs, dense = [], None
+            for r in range(world):
+                ids_u = synth.batch_ids(seed, synth.TID_USER_IDS, step * world + r, b, n_users, variant)
+                ids_i = synth.batch_ids(seed, synth.TID_ITEM_IDS, step * world + r, b, n_items, variant)
+                if r == rank:
+                    assert np.array_equal(u.cpu().numpy(), ids_u) and np.array_equal(i.cpu().numpy(), ids_i)
+                    masks = tuple([(t.acts[l + 1] > 0).cpu().numpy() for l in range(t.n_layers - 1)]
+                                  for t in (tr.user_tower, tr.item_tower))
+                allm = [None] * world
+                dist.all_gather_object(allm, masks if r == rank else None)
+                fb = tt.forward_backward(ref, ids_u, ids_i, temperature=0.1, l2=0.0, relu_masks=allm[r])
+                if r == rank:
+                    assert abs(loss - fb["loss"]) <= 1e-4 * abs(fb["loss"]), (loss, fb["loss"])
+                subs.append((ids_u, ids_i, fb))
+            gu = np.concatenate([s[2]["due"] for s in subs]); iu = np.concatenate([s[0] for s in subs])
+            gi = np.concatenate([s[2]["die"] for s in subs]); ii = np.concatenate([s[1] for s in subs])
+            if opt == "sgd":
+                tt.sparse_sgd(ref.user_table, iu, gu, 0.001); tt.sparse_sgd(ref.item_table, ii, gi, 0.001)
+            else:
+                tt.sparse_adagrad(ref.user_table, ref.user_accum, iu, gu, 0.001)
+                tt.sparse_adagrad(ref.item_table, ref.item_accum, ii, gi, 0.001)
+            for tw, kw_, kb_ in ((ref.user_tower, "udw", "udb"), (ref.item_tower, "idw", "idb")):
+                for l in range(len(tw.weights)):
+                    gw = sum(s[2][kw_][l] for s in subs) + 2e-6 * tw.weights[l]
+                    gb = sum(s[2][kb_][l] for s in subs)
+                    if opt == "sgd":
+                        tt.dense_sgd(tw.weights[l], gw, 0.001); tt.dense_sgd(tw.biases[l], gb, 0.001)
+                    else:
+                        tt.dense_adagrad(tw.weights[l], tw.w_accum[l], gw, 0.001); tt.dense_adagrad(tw.biases[l], tw.b_accum[l], gb, 0.001)
+            for emb, full in ((tr.user_emb, ref.user_table), (tr.item_emb, ref.item_table)):
+                mine = full[rank::world]
+                got = emb.table.cpu().numpy()[:len(mine)]
+                assert np.abs(got - mine).max() <= 3e-6, np.abs(got - mine).max()
+            for tower, rt in ((tr.user_tower, ref.user_tower), (tr.item_tower, ref.item_tower)):
+                for l in range(len(tower_dims)):
+                    assert np.abs(tower.w[l].cpu().numpy() - rt.weights[l]).max() <= 1e-5
+                    assert np.abs(tower.b[l].cpu().numpy() - rt.biases[l]).max() <= 1e-5
+        # replicas of the dense parameters stay bit-identical across ranks
+        flat = [None] * world
+        dist.all_gather_object(flat, tr.dense_flat.cpu().numpy())
+        assert np.array_equal(flat[0], flat[1])
+        ret[rank] = "ok"
+    except Exception:                                             # noqa: BLE001
+        import traceback
+        ret[rank] = traceback.format_exc()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("opt,variant", [("sgd", "U"), ("adagrad", "Z")])
+def test_sharded_trainer_two_ranks_on_one_gpu(opt, variant):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), opt, variant, ret), nprocs=2, join=True)
+    for r in range(2):
+        assert ret.get(r) == "ok", f"rank {r}: {ret.get(r)}"
