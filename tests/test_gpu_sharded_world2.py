@@ -48,10 +48,28 @@ def _install_host_bounce():
         t.copy_(c)
         return _Done()
 
+    real_ag, real_rs = dist.all_gather_into_tensor, dist.reduce_scatter_tensor
+
+    def ag(out, inp, group=None, async_op=False):
+        torch.cuda.synchronize()
+        o = torch.empty(out.shape, dtype=out.dtype)
+        real_ag(o, inp.cpu(), group=group)
+        out.copy_(o)
+        return _Done()
+
+    def rs(out, inp, op=dist.ReduceOp.SUM, group=None, async_op=False):
+        torch.cuda.synchronize()
+        full = inp.cpu()
+        real_ar(full, op=op, group=group)                         # gloo has no reduce_scatter: all-reduce, keep my slice
+        n = out.shape[0]
+        out.copy_(full[dist.get_rank(group) * n:(dist.get_rank(group) + 1) * n])
+        return _Done()
+
     dist.all_to_all_single, dist.all_reduce = a2a, ar
+    dist.all_gather_into_tensor, dist.reduce_scatter_tensor = ag, rs
 
 
-def _worker(rank, world, port, opt, variant, ret):
+def _worker(rank, world, port, opt, variant, negatives, ret):
     sys.path.insert(0, str(ROOT))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -64,7 +82,7 @@ def _worker(rank, world, port, opt, variant, ret):
         n_users, n_items, dim, tower_dims, b, seed = 3001, 2000, 64, [128, 64], 1024, 41
         cfg = TwoTowerConfig(n_users=n_users, n_items=n_items, embedding_dim=dim, tower_dims=tower_dims, temperature=0.1,
                              l2_regularization=1e-6, learning_rate=0.001, optimizer=opt, batch_size=b)
-        tr = ShardedTwoTowerTrainer(cfg, dev, seed=seed, negatives="local", capacity_factor=3.0)
+        tr = ShardedTwoTowerTrainer(cfg, dev, seed=seed, negatives=negatives, capacity_factor=3.0)
         ref = tt.synthetic_state(seed, n_users, n_items, dim, tower_dims, dtype=np.float64, optimizer=opt)
         # each rank holds exactly its rows of the synthetic tables
         assert np.array_equal(tr.user_emb.table.cpu().numpy()[:len(ref.user_table[rank::world])],
@@ -75,7 +93,19 @@ def _worker(rank, world, port, opt, variant, ret):
             tr.check_ids()
             # oracle: forward/backward of EVERY rank's sub-batch on the shared state, then one update with all gradients
             subs, dense = [], None
-            for r in range(world):
+            if negatives == "global":
+                # every query sees all world*b candidates: identical to ONE oracle step on the concatenated batch
+                ids_u = np.concatenate([synth.batch_ids(seed, synth.TID_USER_IDS, step * world + r, b, n_users, variant) for r in range(world)])
+                ids_i = np.concatenate([synth.batch_ids(seed, synth.TID_ITEM_IDS, step * world + r, b, n_items, variant) for r in range(world)])
+                masks = tuple([(t.acts[l + 1] > 0).cpu().numpy() for l in range(t.n_layers - 1)] for t in (tr.user_tower, tr.item_tower))
+                allm = [None] * world
+                dist.all_gather_object(allm, masks)
+                gm = tuple([np.concatenate([allm[r][t][l] for r in range(world)]) for l in range(len(tower_dims) - 1)] for t in (0, 1))
+                fb = tt.forward_backward(ref, ids_u, ids_i, temperature=0.1, l2=0.0, relu_masks=gm)
+                mine = fb["per_row"][rank * b:(rank + 1) * b].sum()
+                assert abs(loss - mine) <= 1e-4 * abs(mine), (loss, mine)
+                subs.append((ids_u, ids_i, fb))
+            for r in range(world if negatives == "local" else 0):
                 ids_u = synth.batch_ids(seed, synth.TID_USER_IDS, step * world + r, b, n_users, variant)
                 ids_i = synth.batch_ids(seed, synth.TID_ITEM_IDS, step * world + r, b, n_items, variant)
                 if r == rank:
@@ -123,12 +153,12 @@ def _worker(rank, world, port, opt, variant, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("opt,variant", [("sgd", "U"), ("adagrad", "Z")])
-def test_sharded_trainer_two_ranks_on_one_gpu(opt, variant):
+@pytest.mark.parametrize("opt,variant,negatives", [("sgd", "U", "local"), ("adagrad", "Z", "local"), ("sgd", "Z", "global")])
+def test_sharded_trainer_two_ranks_on_one_gpu(opt, variant, negatives):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(2, _free_port(), opt, variant, ret), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), opt, variant, negatives, ret), nprocs=2, join=True)
     for r in range(2):
         assert ret.get(r) == "ok", f"rank {r}: {ret.get(r)}"
