@@ -560,3 +560,22 @@ def test_retrieval_task_num_hard_negatives_autograd(dev):
     assert abs(loss.item() - rl) <= 1e-4 * abs(rl)
     assert np.abs(tq.grad.cpu().numpy() - rdq).max() <= 1e-4 * np.abs(rdq).max()
     assert np.abs(tc.grad.cpu().numpy() - rdc).max() <= 1e-4 * np.abs(rdc).max()
+
+
+# ----------------------------------------------------------------------------------- the C ABI without Python
+def test_plain_c_caller_of_the_abi(dev, tmp_path):
+    """examples/c_abi_smoke.c: a C program (no torch, no Python) drives the library through include/twotower_hip.h."""
+    import pathlib
+    import shutil
+    import subprocess
+    root = pathlib.Path(__file__).resolve().parents[1]
+    gcc = shutil.which("gcc") or "gcc"
+    exe = tmp_path / "c_abi_smoke"
+    libdir = root / "two_tower_amazon_recommender_amd"
+    cmd = [gcc, str(root / "examples" / "c_abi_smoke.c"), "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", f"-I{root / 'include'}",
+           f"-L{libdir}", "-ltwotower_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lm", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib",
+           "-o", str(exe)]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    res = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "ok" in res.stdout
