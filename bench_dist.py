@@ -18,6 +18,9 @@ def run_distributed(args, rank, world, dev):
     from two_tower_amazon_recommender_amd.sharded import ShardedTwoTowerTrainer
     from two_tower_amazon_recommender_amd.trainer import TwoTowerConfig
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world == 1:                      # TT_FORCE_DIST=1 without a launcher: a one-rank group
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):
+            os.environ.setdefault(k, v)
     dist.init_process_group("nccl", device_id=dev)
     negatives = os.environ.get("TT_NEGATIVES", "local")
     users_per_gpu = int(os.environ.get("TT_USERS_PER_GPU", 5_000_000))

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TT_ABI_VERSION 2
+#define TT_ABI_VERSION 3
 
 enum {
   TT_OK = 0,
@@ -144,6 +144,20 @@ int tt_sparse_update2_f32(int32_t opt,
  *     into the send buffer; duplicates are summed later, on the owner, by the sparse optimizer).            */
 int tt_route_by_owner_i64(const int64_t* ids, int64_t n_ids, int32_t world, int64_t num_rows, int32_t cap,
                           int64_t* send_ids, int64_t* pos_flat, int32_t* flags, tt_stream_t stream);
+/* Several tables in one launch and ONE exchange: each rank keeps its shards of all tables in one combined
+ * allocation (table t at rows [local_offset_t, local_offset_t + ceil(num_rows_t/world))), so the owner runs
+ * one gather, one sort plan and one sparse update over every table's ids.  send_ids is
+ * [world][n_tables][cap]: bucket (o, t) at ((o*n_tables + t)*cap ...), value id/world + local_offset_t,
+ * padding -1; tables[t].pos_flat[p] = flat slot of position p in that buffer (or -1).  flags as above.   */
+#define TT_ROUTE_MAX_TABLES 4
+typedef struct {
+  const int64_t* ids;       /* [n_ids] global row ids of this table            */
+  int64_t num_rows;         /* global rows of this table                       */
+  int64_t local_offset;     /* first row of this table in the owner's shard    */
+  int64_t* pos_flat;        /* [n_ids] out                                     */
+} tt_route_table;
+int tt_route_tables_by_owner_i64(const tt_route_table* tables, int32_t n_tables, int64_t n_ids, int32_t world,
+                                 int32_t cap, int64_t* send_ids, int32_t* flags, tt_stream_t stream);
 int tt_scatter_rows_f32(const float* src, const int64_t* idx, int64_t n, int32_t dim,
                         float* dst, int64_t dst_rows, tt_stream_t stream);
 
@@ -157,7 +171,9 @@ int tt_scatter_rows_f32(const float* src, const int64_t* idx, int64_t n, int32_t
  *         already masked by this layer's own ReLU — see dx_relu_src);
  *         dx = dz@w^T, and if dx_relu_src != NULL (the [m,k] output of the previous
  *         ReLU layer, i.e. x itself) dx is multiplied by (dx_relu_src > 0) so that it
- *         is directly the previous layer's dz;  dx may be NULL to skip it.
+ *         is directly the previous layer's dz;  dx may be NULL to skip it; dw_slabs AND db_slabs may
+ *         both be NULL to skip the weight gradients (a caller that wants every dx before any dw, so the
+ *         embedding gradients can travel while the dw GEMMs run, calls the layer twice).
  *         dw_slabs [n_slabs, k, n] and db_slabs [n_slabs, n] receive split-K partial
  *         sums of x^T@dz and colsum(dz); the dense update sums them in slab order.
  *         n_slabs = tt_dense_bwd_num_slabs(m).                                            */

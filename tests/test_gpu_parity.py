@@ -231,6 +231,26 @@ def test_dense_bwd(dev, m, k, n, mask):
     assert rel_err(db_s.sum(0).cpu().numpy(), dz64.sum(0)) <= 1e-5
 
 
+def test_dense_bwd_dx_only_then_dw_only_equals_one_call(dev):
+    """dw_slabs = db_slabs = NULL skips the weight gradients, dx = NULL skips dx: the two half calls (the sharded
+    trainer's dx-first order) write exactly what the full call writes; neither NULL-everything is accepted."""
+    m, k, n = 1000, 128, 256
+    x = T(synth.uniform_f32(33, 1, m * k, -1.0, 2.0).reshape(m, k), dev)
+    w = T(synth.dense_kernel(33, 2, k, n), dev)
+    dz = T(synth.uniform_f32(33, 3, m * n, -1.0, 2.0).reshape(m, n), dev)
+    ns = ops.dense_bwd_num_slabs(m)
+    full = [torch.empty(m, k, device=dev), torch.empty(ns, k, n, device=dev), torch.empty(ns, n, device=dev)]
+    ops.dense_bwd(x, w, dz, full[0], x, full[1], full[2], dx_scale=1.25)
+    half = [torch.full((m, k), float("nan"), device=dev), torch.full((ns, k, n), float("nan"), device=dev),
+            torch.full((ns, n), float("nan"), device=dev)]
+    ops.dense_bwd(x, w, dz, half[0], x, None, None, dx_scale=1.25)
+    assert torch.equal(half[0], full[0]) and torch.isnan(half[1]).all()
+    ops.dense_bwd(x, w, dz, None, None, half[1], half[2])
+    assert torch.equal(half[1], full[1]) and torch.equal(half[2], full[2])
+    with pytest.raises(ValueError):
+        ops.dense_bwd(x, w, dz, None, None, None, None)
+
+
 @pytest.mark.parametrize("opt", ["sgd", "adagrad"])
 def test_dense_update_segments(dev, opt):
     rng = np.random.default_rng(5)
@@ -431,6 +451,34 @@ def test_route_by_owner_matches_stable_partition(dev, world, n, rows, cap, varia
     rs, rp, oob, over = np_route(ids, world, rows, cap)
     assert np.array_equal(send.cpu().numpy(), rs) and np.array_equal(pos.cpu().numpy(), rp)
     assert flags.tolist() == [oob, over]
+
+
+@pytest.mark.parametrize("world,n,cap", [(2, 1000, 640), (8, 8192, 2048), (3, 257, 64), (1, 64, 64)])
+def test_route_tables_one_launch_combined_layout(dev, world, n, cap):
+    """Three tables in one launch: bucket (owner, table) of send_ids [world][3][cap], ids offset into the owner's
+    combined shard; every table's slice equals the single-table stable partition shifted by its offset."""
+    rows = [5000, 37, 100_000]
+    offs = [0, 7000, 7100]
+    ids = [synth.batch_ids(63, 3 + t, 0, n, rows[t], "Z" if t == 1 else "U") for t in range(3)]
+    ids[2][5] = rows[2] + 3          # out of range in one table only
+    send = torch.empty(world * 3 * cap, dtype=torch.int64, device=dev)
+    pos = [torch.empty(n, dtype=torch.int64, device=dev) for _ in range(3)]
+    flags = torch.zeros(2, dtype=torch.int32, device=dev)
+    ops.route_tables_by_owner([T(i, dev) for i in ids], world, rows, offs, cap, send, pos, flags)
+    got = send.cpu().numpy().reshape(world, 3, cap)
+    any_oob = any_over = 0
+    for t in range(3):
+        rs, rp, oob, over = np_route(ids[t], world, rows[t], cap)
+        rs = rs.reshape(world, cap)
+        want = np.where(rs >= 0, rs + offs[t], -1)
+        assert np.array_equal(got[:, t, :], want), t
+        o, k = rp // cap, rp % cap
+        want_pos = np.where(rp >= 0, (o * 3 + t) * cap + k, -1)
+        assert np.array_equal(pos[t].cpu().numpy(), want_pos), t
+        any_oob |= oob
+        any_over |= over
+    assert flags.tolist() == [any_oob, any_over]
+    assert any_oob == 1
 
 
 def test_scatter_rows(dev):

@@ -110,7 +110,7 @@ def test_sharded_trainer_world1_is_bit_identical_to_single_gpu_trainer(dev, opt,
     cfg, tr, _ = make(dev, *shape, opt, 31)
     cfg2 = TwoTowerConfig(**cfg.__dict__)
     sh = ShardedTwoTowerTrainer(cfg2, dev, seed=31)
-    assert torch.equal(sh.user_emb.table, tr.user_table) and torch.equal(sh.dense_flat, tr.dense_flat)
+    assert torch.equal(sh.user_table, tr.user_table) and torch.equal(sh.dense_flat, tr.dense_flat)
     for step in range(3):
         u, i = tr.synthetic_batch(31, step, variant)
         u2, i2 = sh.synthetic_batch(31, step, variant)
@@ -119,10 +119,10 @@ def test_sharded_trainer_world1_is_bit_identical_to_single_gpu_trainer(dev, opt,
         l2 = sh.step(u2, i2).clone()
         assert torch.equal(l1, l2)
     sh.check_ids()
-    assert torch.equal(sh.user_emb.table, tr.user_table) and torch.equal(sh.item_emb.table, tr.item_table)
+    assert torch.equal(sh.user_table, tr.user_table) and torch.equal(sh.item_table, tr.item_table)
     assert torch.equal(sh.dense_flat, tr.dense_flat)
     if opt == "adagrad":
-        assert torch.equal(sh.user_emb.accum, tr.user_accum)
+        assert torch.equal(sh.emb.accum_shard(0), tr.user_accum) and torch.equal(sh.emb.accum_shard(1), tr.item_accum)
 
 
 def test_retrieval_task_autograd_matches_oracle(dev):
@@ -224,7 +224,7 @@ def test_sharded_trainer_global_negatives_world1_equals_local(dev):
             u, i = a.synthetic_batch(17, step, "Z")
             la = a.step(u, i).clone(); lb = b.step(u, i).clone()
             assert torch.equal(la, lb)
-        assert torch.equal(a.user_emb.table, b.user_emb.table) and torch.equal(a.dense_flat, b.dense_flat)
+        assert torch.equal(a.emb.table, b.emb.table) and torch.equal(a.dense_flat, b.dense_flat)
         a.check_ids(); b.check_ids()
     finally:
         if created:

@@ -21,24 +21,27 @@ class OracleRowBackend:
     """Test-only stand-in for HipRowBackend: NumPy restatements of the row kernels (route = stable partition by
     owner, gather, scatter_rows, sort+apply through the oracle's sparse optimizers)."""
 
-    def route(self, ids, world, num_rows, cap, send_ids, pos_flat, flags):
-        i = ids.numpy()
-        send = np.full(world * cap, -1, dtype=np.int64)
-        pos = np.full(len(i), -1, dtype=np.int64)
-        fill = [0] * world
-        for p, v in enumerate(i):
-            if v < 0 or v >= num_rows:
-                flags[0] = 1
-                continue
-            o = int(v % world)
-            if fill[o] < cap:
-                send[o * cap + fill[o]] = v // world
-                pos[p] = o * cap + fill[o]
-            else:
-                flags[1] = 1
-            fill[o] += 1
+    def route(self, ids_list, world, num_rows_list, offsets, cap, send_ids, pos_flats, flags):
+        nt = len(ids_list)
+        send = np.full(world * nt * cap, -1, dtype=np.int64)
+        for t in range(nt):
+            i = ids_list[t].numpy()
+            pos = np.full(len(i), -1, dtype=np.int64)
+            fill = [0] * world
+            for p, v in enumerate(i):
+                if v < 0 or v >= num_rows_list[t]:
+                    flags[0] = 1
+                    continue
+                o = int(v % world)
+                if fill[o] < cap:
+                    slot = (o * nt + t) * cap + fill[o]
+                    send[slot] = v // world + offsets[t]
+                    pos[p] = slot
+                else:
+                    flags[1] = 1
+                fill[o] += 1
+            pos_flats[t].copy_(torch.from_numpy(pos))
         send_ids.copy_(torch.from_numpy(send))
-        pos_flat.copy_(torch.from_numpy(pos))
 
     def gather(self, table, ids, out, oob_flag):
         t, i = table.numpy(), ids.numpy()
@@ -189,33 +192,57 @@ def test_overflow_and_out_of_range_are_reported():
         assert ret.get(r) == "ok", f"rank {r}: {ret.get(r)}"
 
 
-def _worker_interleaved(rank, world, port, ret):
-    """Two tables with their phases interleaved exactly as ShardedTwoTowerTrainer.step issues them (async collectives)."""
+def _worker_combined(rank, world, port, ret):
+    """Two tables behind ONE set of exchange buffers, as ShardedTwoTowerTrainer.step drives them (async collectives):
+    ragged shards (700 and 333 rows over 2 and 3 ranks), heavy duplicates, SGD and Adagrad."""
     sys.path.insert(0, str(ROOT))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from oracle import synth, two_tower as tt
-        from two_tower_amazon_recommender_amd.sharded import ShardedEmbedding
+        from two_tower_amazon_recommender_amd.sharded import ShardedTables, shard_rows
         dim, batch = 16, 128
-        fulls = [synth.embedding_table(5, 1, 700, dim), synth.embedding_table(5, 2, 333, dim)]
-        embs = [ShardedEmbedding(f.shape[0], dim, batch, torch.device("cpu"), capacity_factor=3.0, backend=OracleRowBackend(),
-                                 table=torch.from_numpy(f[rank::world].copy())) for f in fulls]
-        ids = [synth.batch_ids(5, 3 + t, 0, world * batch, fulls[t].shape[0], "Z") for t in range(2)]
-        grads = [synth.uniform_f32(5, 9 + t, world * batch * dim, -1.0, 2.0).reshape(world * batch, dim) for t in range(2)]
-        sl = slice(rank * batch, (rank + 1) * batch)
-        outs = [torch.empty(batch, dim), torch.empty(batch, dim)]
-        embs[0].lookup_start(torch.from_numpy(ids[0][sl])); embs[1].lookup_start(torch.from_numpy(ids[1][sl]))
-        embs[0].lookup_rows(); embs[1].lookup_rows()
-        embs[0].lookup_finish(outs[0]); embs[1].lookup_finish(outs[1])
-        for t in range(2):
-            assert np.array_equal(outs[t].numpy(), fulls[t][ids[t][sl]])
-        embs[0].grads_start(torch.from_numpy(grads[0][sl])); embs[1].grads_start(torch.from_numpy(grads[1][sl]))
-        embs[0].grads_finish("sgd", 0.01); embs[1].grads_finish("sgd", 0.01)
-        for t in range(2):
-            ref = tt.sparse_sgd(fulls[t].copy(), ids[t], grads[t], 0.01)
-            assert np.allclose(embs[t].table.numpy(), ref[rank::world], rtol=0, atol=2e-6)
-            embs[t].check()
+        for opt in ("sgd", "adagrad"):
+            fulls = [synth.embedding_table(5, 1, 700, dim), synth.embedding_table(5, 2, 333, dim)]
+            accs = [np.full_like(f, np.float32(0.1)) for f in fulls]
+            em = ShardedTables([700, 333], dim, batch, torch.device("cpu"), capacity_factor=3.0, backend=OracleRowBackend())
+            assert em.offsets == [0, (700 + world - 1) // world] and em.table.shape[0] == sum(em.rows_cap)
+            for t in range(2):
+                em.shard(t).copy_(torch.from_numpy(fulls[t][rank::world].copy()))
+                assert em.shard(t).shape[0] == shard_rows(fulls[t].shape[0], world, rank)
+            if opt == "adagrad":
+                em.accum = torch.full_like(em.table, 0.1)
+            for step in range(2):
+                ids = [synth.batch_ids(5, 3 + t, step, world * batch, fulls[t].shape[0], "Z") for t in range(2)]
+                grads = [synth.uniform_f32(5, 9 + 2 * step + t, world * batch * dim, -1.0, 2.0).reshape(world * batch, dim)
+                         for t in range(2)]
+                sl = slice(rank * batch, (rank + 1) * batch)
+                out = torch.empty(2 * batch, dim)
+                em.lookup_start([torch.from_numpy(ids[0][sl]), torch.from_numpy(ids[1][sl])])
+                em.lookup_rows()
+                em.lookup_finish(out)
+                for t in range(2):
+                    assert np.array_equal(out.numpy()[t * batch:(t + 1) * batch], fulls[t][ids[t][sl]])
+                em.grads_start(torch.from_numpy(np.concatenate([grads[0][sl], grads[1][sl]])))
+                em.grads_finish(opt, 0.01)
+                em.check()
+                for t in range(2):
+                    if opt == "sgd":
+                        tt.sparse_sgd(fulls[t], ids[t], grads[t], 0.01)
+                    else:
+                        tt.sparse_adagrad(fulls[t], accs[t], ids[t], grads[t], 0.01, 1e-7)
+                    got = em.shard(t).numpy()
+                    assert np.allclose(got, fulls[t][rank::world], rtol=0, atol=2e-6), (opt, t, np.abs(got - fulls[t][rank::world]).max())
+                    # re-sync the oracle to the sharded state so last-bit differences do not compound
+                    gathered = [None] * world
+                    dist.all_gather_object(gathered, got.copy())
+                    for r in range(world):
+                        fulls[t][r::world] = gathered[r]
+                    if opt == "adagrad":
+                        gacc = [None] * world
+                        dist.all_gather_object(gacc, em.accum_shard(t).numpy().copy())
+                        for r in range(world):
+                            accs[t][r::world] = gacc[r]
         ret[rank] = "ok"
     except Exception:                                             # noqa: BLE001
         import traceback
@@ -224,9 +251,10 @@ def _worker_interleaved(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-def test_two_tables_interleaved_phases_world2():
+@pytest.mark.parametrize("world", [2, 3])
+def test_two_tables_one_exchange(world):
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker_interleaved, args=(2, _free_port(), ret), nprocs=2, join=True)
-    for r in range(2):
+    mp.spawn(_worker_combined, args=(world, _free_port(), ret), nprocs=world, join=True)
+    for r in range(world):
         assert ret.get(r) == "ok", f"rank {r}: {ret.get(r)}"

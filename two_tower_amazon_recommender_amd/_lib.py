@@ -14,7 +14,7 @@ import threading
 
 _PKG = pathlib.Path(__file__).resolve().parent
 LIB_PATH = _PKG / "libtwotower_hip.so"
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 TT_OK, TT_ERR_INVALID_ARG, TT_ERR_LAUNCH, TT_ERR_UNSUPPORTED, TT_ERR_WORKSPACE = range(5)
 TT_OPT_SGD, TT_OPT_ADAGRAD = 0, 1
@@ -31,6 +31,11 @@ class DenseBwdArgs(C.Structure):
     """Mirror of ``tt_dense_bwd_args``."""
     _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("dz", C.c_void_p), ("dx", C.c_void_p), ("dx_relu_src", C.c_void_p),
                 ("dw_slabs", C.c_void_p), ("db_slabs", C.c_void_p)]
+
+
+class RouteTable(C.Structure):
+    """Mirror of ``tt_route_table`` (include/twotower_hip.h)."""
+    _fields_ = [("ids", C.c_void_p), ("num_rows", C.c_int64), ("local_offset", C.c_int64), ("pos_flat", C.c_void_p)]
 
 
 class DenseSeg(C.Structure):
@@ -57,6 +62,7 @@ SIGNATURES = {
     "tt_embedding_gather_f32": (C.c_int, [_p, _i64, _i32, _p, _i64, _p, _p, _p]),
     "tt_embedding_gather2_f32": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _p, _p, _i32, _i64, _p, _p]),
     "tt_route_by_owner_i64": (C.c_int, [_p, _i64, _i32, _i64, _i32, _p, _p, _p, _p]),
+    "tt_route_tables_by_owner_i64": (C.c_int, [_p, _i32, _i64, _i32, _i32, _p, _p, _p]),
     "tt_scatter_rows_f32": (C.c_int, [_p, _p, _i64, _i32, _p, _i64, _p]),
     "tt_sparse_plan_workspace_bytes": (_i64, [_i64]),
     "tt_sparse_plan": (C.c_int, [_p, _i64, _i64, _p, _i64, _p, _p, _p]),

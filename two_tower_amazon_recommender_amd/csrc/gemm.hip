@@ -272,11 +272,15 @@ extern "C" int tt_dense_bwd_batched_f32(const tt_dense_bwd_args* probs, int32_t 
   GemmArgs ax[2] = {}, aw[2] = {};
   const int splits = tt_dense_bwd_num_slabs(m);
   const bool want_dx = probs[0].dx != nullptr;
+  const bool want_dw = probs[0].dw_slabs != nullptr;
   for (int i = 0; i < n_probs; ++i) {
     const tt_dense_bwd_args& q = probs[i];
-    TT_REQUIRE(q.x && q.w && q.dz && q.dw_slabs && q.db_slabs, "tt_dense_bwd_f32: null pointer");
+    TT_REQUIRE(q.x && q.w && q.dz, "tt_dense_bwd_f32: null pointer");
     TT_REQUIRE((q.dx != nullptr) == want_dx, "tt_dense_bwd_batched_f32: dx must be given for all problems or for none");
-    TT_REQUIRE(tt::aligned16(q.x) && tt::aligned16(q.w) && tt::aligned16(q.dz) && tt::aligned16(q.dw_slabs) &&
+    TT_REQUIRE((q.dw_slabs != nullptr) == want_dw && (q.db_slabs != nullptr) == want_dw,
+               "tt_dense_bwd_batched_f32: dw_slabs and db_slabs must be given together, for all problems or for none");
+    TT_REQUIRE(want_dx || want_dw, "tt_dense_bwd_f32: nothing to compute (dx and dw_slabs are both NULL)");
+    TT_REQUIRE(tt::aligned16(q.x) && tt::aligned16(q.w) && tt::aligned16(q.dz) && (q.dw_slabs == nullptr || tt::aligned16(q.dw_slabs)) &&
                    (q.dx == nullptr || tt::aligned16(q.dx)),
                "tt_dense_bwd_f32: pointers must be 16-byte aligned");
     // dx[m][k] = sum_n dz[m][n] * w[k][n]
@@ -291,6 +295,7 @@ extern "C" int tt_dense_bwd_batched_f32(const tt_dense_bwd_args* probs, int32_t 
   }
   int rc;
   if (want_dx && (rc = launch<true, true, false>(ax, n_probs, 1, stream, "tt_dense_bwd_f32(dx)", "dense_bwd_dx")) != TT_OK) return rc;
+  if (!want_dw) return TT_OK;
   return launch<false, false, true>(aw, n_probs, splits, stream, "tt_dense_bwd_f32(dw)", "dense_bwd_dw");
 }
 

@@ -1,7 +1,8 @@
 // Requester-side routing of the row-sharded embedding exchange.
 //
-// route_kernel   : stable partition of a batch of ids by owner rank (owner = id % world, local row = id / world)
-//                  into fixed-capacity per-owner send buffers (padding id -1) + the flat slot of every position.
+// route_kernel   : stable partition of a batch of ids by owner rank (owner = id % world, local row = id / world
+//                  + the table's offset inside the owner's combined shard) into fixed-capacity per-owner send
+//                  buffers (padding id -1) + the flat slot of every position; one workgroup per table.
 //                  One workgroup, 16 waves; per 1024-position round: `world` wave ballots give the rank inside the
 //                  wave, a 16 x world table in LDS gives the offsets across waves (ascending position order inside
 //                  every owner bucket: deterministic).  Integer/byte work, latency-bound (a few microseconds).
@@ -13,15 +14,25 @@ namespace {
 
 constexpr int kMaxWorld = 16;
 
-__global__ __launch_bounds__(1024) void route_kernel(const int64_t* __restrict__ ids, int64_t n, int world, int64_t num_rows,
-                                                     int cap, int64_t* __restrict__ send_ids, int64_t* __restrict__ pos_flat,
-                                                     int32_t* __restrict__ flags) {
+struct RouteTables {
+  tt_route_table t[TT_ROUTE_MAX_TABLES];
+};
+
+// One workgroup per table (blockIdx.x = table t); bucket (owner o, table t) of the send buffer is
+// send_ids[(o*n_tables + t)*cap ...]: one all-to-all moves every table's ids (and later rows) at once.
+__global__ __launch_bounds__(1024) void route_kernel(RouteTables tabs, int n_tables, int64_t n, int world, int cap,
+                                                     int64_t* __restrict__ send_ids, int32_t* __restrict__ flags) {
   __shared__ int wave_cnt[16][kMaxWorld];
   __shared__ int wave_off[16][kMaxWorld];
   __shared__ int running[kMaxWorld];
+  const int t = blockIdx.x;
+  const int64_t* __restrict__ ids = tabs.t[t].ids;
+  int64_t* __restrict__ pos_flat = tabs.t[t].pos_flat;
+  const int64_t num_rows = tabs.t[t].num_rows, local_offset = tabs.t[t].local_offset;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  for (int64_t i = tid; i < (int64_t)world * cap; i += 1024) send_ids[i] = -1;
+  for (int o = 0; o < world; ++o)
+    for (int i = tid; i < cap; i += 1024) send_ids[((int64_t)o * n_tables + t) * cap + i] = -1;
   if (tid < kMaxWorld) running[tid] = 0;
   __syncthreads();
   bool oob = false, over = false;
@@ -51,8 +62,9 @@ __global__ __launch_bounds__(1024) void route_kernel(const int64_t* __restrict__
     if (owner >= 0) {
       const int slot = wave_off[wave][owner] + my_rank;
       if (slot < cap) {
-        send_ids[(int64_t)owner * cap + slot] = id / world;
-        pos_flat[p] = (int64_t)owner * cap + slot;
+        const int64_t flat = ((int64_t)owner * n_tables + t) * cap + slot;
+        send_ids[flat] = id / world + local_offset;
+        pos_flat[p] = flat;
       } else {
         pos_flat[p] = -1;
         over = true;
@@ -83,15 +95,30 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const tt::f32x4* __re
 
 }  // namespace
 
-extern "C" int tt_route_by_owner_i64(const int64_t* ids, int64_t n_ids, int32_t world, int64_t num_rows, int32_t cap,
-                                     int64_t* send_ids, int64_t* pos_flat, int32_t* flags, tt_stream_t stream_) {
-  TT_REQUIRE(n_ids >= 0 && world >= 1 && world <= kMaxWorld && num_rows > 0 && cap >= 1,
-             "tt_route_by_owner_i64: need n_ids >= 0, 1 <= world <= %d, num_rows > 0, cap >= 1", kMaxWorld);
-  TT_REQUIRE(send_ids != nullptr && (n_ids == 0 || (ids != nullptr && pos_flat != nullptr)), "tt_route_by_owner_i64: null pointer");
+extern "C" int tt_route_tables_by_owner_i64(const tt_route_table* tables, int32_t n_tables, int64_t n_ids, int32_t world,
+                                            int32_t cap, int64_t* send_ids, int32_t* flags, tt_stream_t stream_) {
+  TT_REQUIRE(tables != nullptr && n_tables >= 1 && n_tables <= TT_ROUTE_MAX_TABLES,
+             "tt_route_tables_by_owner_i64: 1 <= n_tables <= %d", TT_ROUTE_MAX_TABLES);
+  TT_REQUIRE(n_ids >= 0 && world >= 1 && world <= kMaxWorld && cap >= 1,
+             "tt_route_tables_by_owner_i64: need n_ids >= 0, 1 <= world <= %d, cap >= 1", kMaxWorld);
+  TT_REQUIRE(send_ids != nullptr, "tt_route_tables_by_owner_i64: null pointer");
+  RouteTables tabs = {};
+  for (int t = 0; t < n_tables; ++t) {
+    TT_REQUIRE(tables[t].num_rows > 0 && tables[t].local_offset >= 0, "tt_route_tables_by_owner_i64: table %d: num_rows > 0, local_offset >= 0", t);
+    TT_REQUIRE(n_ids == 0 || (tables[t].ids != nullptr && tables[t].pos_flat != nullptr), "tt_route_tables_by_owner_i64: table %d: null pointer", t);
+    tabs.t[t] = tables[t];
+  }
   hipStream_t stream = tt::as_stream(stream_);
   tt::ProfScope prof("route", stream);
-  hipLaunchKernelGGL(route_kernel, dim3(1), dim3(1024), 0, stream, ids, n_ids, world, num_rows, cap, send_ids, pos_flat, flags);
-  return tt::check_launch("tt_route_by_owner_i64");
+  hipLaunchKernelGGL(route_kernel, dim3(n_tables), dim3(1024), 0, stream, tabs, n_tables, n_ids, world, cap, send_ids, flags);
+  return tt::check_launch("tt_route_tables_by_owner_i64");
+}
+
+extern "C" int tt_route_by_owner_i64(const int64_t* ids, int64_t n_ids, int32_t world, int64_t num_rows, int32_t cap,
+                                     int64_t* send_ids, int64_t* pos_flat, int32_t* flags, tt_stream_t stream_) {
+  TT_REQUIRE(num_rows > 0, "tt_route_by_owner_i64: num_rows > 0");
+  const tt_route_table tab{ids, num_rows, 0, pos_flat};
+  return tt_route_tables_by_owner_i64(&tab, 1, n_ids, world, cap, send_ids, flags, stream_);
 }
 
 extern "C" int tt_scatter_rows_f32(const float* src, const int64_t* idx, int64_t n, int32_t dim, float* dst, int64_t dst_rows,

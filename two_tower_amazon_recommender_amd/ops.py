@@ -144,6 +144,25 @@ def route_by_owner(ids, world: int, num_rows: int, cap: int, send_ids, pos_flat,
                                          _stream()), "tt_route_by_owner_i64")
 
 
+def route_tables_by_owner(ids_list, world: int, num_rows_list, local_offsets, cap: int, send_ids, pos_flats, flags=None):
+    """Several tables, one launch: send_ids is [world][n_tables][cap] (see tt_route_tables_by_owner_i64)."""
+    t = len(ids_list)
+    n = ids_list[0].numel()
+    for ids, pos in zip(ids_list, pos_flats):
+        _chk(ids, torch.int64, "ids", 1)
+        _chk(pos, torch.int64, "pos_flat")
+        if ids.numel() != n or pos.numel() < n:
+            raise RuntimeError("route_tables_by_owner: every table needs n_ids ids and a pos_flat of n_ids")
+    _chk(send_ids, torch.int64, "send_ids")
+    if send_ids.numel() < world * t * cap:
+        raise RuntimeError("route_tables_by_owner: send_ids too small")
+    arr = (_lib.RouteTable * t)(*[_lib.RouteTable(_p(ids_list[i]), int(num_rows_list[i]), int(local_offsets[i]), _p(pos_flats[i]))
+                                  for i in range(t)])
+    lib = _lib.load()
+    _lib.check(lib.tt_route_tables_by_owner_i64(arr, t, n, world, cap, _p(send_ids), _p(flags), _stream()),
+               "tt_route_tables_by_owner_i64")
+
+
 def scatter_rows(src, idx, dst):
     _chk(src, torch.float32, "src", 2)
     _chk(idx, torch.int64, "idx", 1)
@@ -258,10 +277,11 @@ def dense_bwd(x, w, dz, dx, dx_relu_src, dw_slabs, db_slabs, dx_scale: float = 1
     if dx_relu_src is not None:
         _chk(dx_relu_src, torch.float32, "dx_relu_src", 2)
     ns = dense_bwd_num_slabs(m)
-    _chk(dw_slabs, torch.float32, "dw_slabs")
-    _chk(db_slabs, torch.float32, "db_slabs")
-    if dw_slabs.numel() < ns * k * n or db_slabs.numel() < ns * n:
-        raise RuntimeError("dense_bwd: slab buffers too small")
+    if dw_slabs is not None or db_slabs is not None:      # both None: dx only
+        _chk(dw_slabs, torch.float32, "dw_slabs")
+        _chk(db_slabs, torch.float32, "db_slabs")
+        if dw_slabs.numel() < ns * k * n or db_slabs.numel() < ns * n:
+            raise RuntimeError("dense_bwd: slab buffers too small")
     lib = _lib.load()
     _lib.check(lib.tt_dense_bwd_scaled_f32(_p(x), _p(w), _p(dz), _p(dx), _p(dx_relu_src), dx_scale, _p(dw_slabs),
                                            _p(db_slabs), m, k, n, _stream()), "tt_dense_bwd_scaled_f32")

@@ -1,24 +1,28 @@
 """Row-sharded embedding tables over the GPUs of one node (BASELINE.json configs 4-5).
 
-One process per GPU (``torch.distributed``; backend "nccl" = RCCL over xGMI).  Table row ``id`` lives on
-rank ``id % world`` at local row ``id // world`` (mod placement balances skewed ids).  Per table and step:
+One process per GPU (``torch.distributed``; backend "nccl" = RCCL over xGMI).  Row ``id`` of table t lives on
+rank ``id % world`` at local row ``offset_t + id // world`` of that rank's COMBINED shard (mod placement
+balances skewed ids; all tables of a rank share one allocation so the owner side is one gather, one sort and
+one sparse update per step, and every exchange is ONE collective for all tables).  Per step:
 
-  route   HIP kernel: stable partition of the batch by owner into fixed-capacity send buffers [world, cap]
-          (padding id -1) + the flat slot of every position               (tt_route_by_owner_i64)
-  C1      all-to-all of the id buffers                      (world*cap*8 B per rank)
+  route   HIP kernel, one workgroup per table: stable partition of the batch by owner into fixed-capacity
+          send buffers [world, n_tables, cap] (padding id -1) + the flat slot of every position
+                                                                            (tt_route_tables_by_owner_i64)
+  C1      all-to-all of the id buffers                      (world*n_tables*cap*8 B per rank)
   K1      owner gathers its rows for the received ids       (HIP gather; -1 -> zero row)
   plan    owner sorts the received ids (side stream, beside the forward/backward pass)
-  C2      all-to-all of the rows back                       (world*cap*4*dim B per rank)
+  C2      all-to-all of the rows back                       (world*n_tables*cap*4*dim B per rank)
   K1'     expand to per-position embeddings                 (HIP gather from the received buffer)
-  ... towers, scorer, loss, backward ...
+  ... towers, scorer, loss, every dx of the backward pass ...
   K2'     per-position gradient rows into the send buffer   (tt_scatter_rows_f32)
-  C3      all-to-all of the gradient rows to the owners
+  C3      all-to-all of the gradient rows to the owners     (travels beside the dw GEMMs and the dense reduce)
   K2      owner applies the fused sparse SGD/Adagrad: duplicates — inside one rank's batch and across ranks —
           are summed first, in (source rank, position) order: bitwise reproducible
 
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): an all-to-all uses every link at once, one peer per
-link.  The buffers are fixed-size so no step waits on the host; ``capacity_factor`` x the mean positions per
-peer is reserved and an overflow raises at the next ``check()``.
+link; what costs at these sizes (a few MB) is the per-collective latency, hence three all-to-alls per step
+for all tables together instead of three per table.  The buffers are fixed-size so no step waits on the host;
+``capacity_factor`` x the mean positions per peer is reserved and an overflow raises at the next ``check()``.
 
 The exchange code is device-agnostic torch.distributed; the row kernels come from a ``backend`` (default:
 the HIP ops; the CPU/gloo tests pass a NumPy-oracle backend defined in the test).
@@ -40,8 +44,8 @@ class HipRowBackend:
         self._side = torch.cuda.Stream(device=device)
         self._pending = None
 
-    def route(self, ids, world, num_rows, cap, send_ids, pos_flat, flags):
-        self.ops.route_by_owner(ids, world, num_rows, cap, send_ids, pos_flat, flags)
+    def route(self, ids_list, world, num_rows_list, offsets, cap, send_ids, pos_flats, flags):
+        self.ops.route_tables_by_owner(ids_list, world, num_rows_list, offsets, cap, send_ids, pos_flats, flags)
 
     def gather(self, table, ids, out, oob_flag):
         self.ops.embedding_gather(table, ids, out=out, oob_flag=oob_flag)
@@ -74,22 +78,31 @@ def shard_rows(num_rows: int, world: int, rank: int) -> int:
     return (num_rows - rank + world - 1) // world if num_rows > rank else 0
 
 
-class ShardedEmbedding:
-    def __init__(self, num_rows: int, dim: int, batch: int, device, group=None, capacity_factor: float = 2.0,
+class ShardedTables:
+    """Several row-sharded tables of one width behind one set of exchange buffers (see the module docstring)."""
+
+    def __init__(self, num_rows, dim: int, batch: int, device, group=None, capacity_factor: float = 2.0,
                  backend=None, table: torch.Tensor | None = None, accum: torch.Tensor | None = None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.num_rows, self.dim, self.batch, self.device = num_rows, dim, batch, device
+        self.num_rows = [int(n) for n in num_rows]
+        self.n_tables = nt = len(self.num_rows)
+        self.dim, self.batch, self.device = dim, batch, device
         w = self.world
         mean = (batch + w - 1) // w
         cap = batch if w == 1 else min(batch, int(mean * capacity_factor + 63) // 64 * 64)
         self.cap = max(cap, 1)
-        self.local_rows = max(shard_rows(num_rows, w, self.rank), 1)
-        self.table = table if table is not None else torch.zeros(self.local_rows, dim, device=device)
+        # every rank reserves ceil(rows/world) rows per table, so local offsets are the same on all ranks
+        self.rows_cap = [max((n + w - 1) // w, 1) for n in self.num_rows]
+        self.offsets = [sum(self.rows_cap[:t]) for t in range(nt)]
+        total = sum(self.rows_cap)
+        if table is not None and table.shape[0] < self.offsets[-1] + max(shard_rows(self.num_rows[-1], w, self.rank), 1):
+            raise ValueError("ShardedTables: the given shard has too few rows")
+        self.table = table if table is not None else torch.zeros(total, dim, device=device)
         self.accum = accum
         self.backend = backend if backend is not None else HipRowBackend(device)
-        n = w * self.cap
+        n = w * nt * self.cap
         i64 = dict(dtype=torch.int64, device=device)
         self.send_ids = torch.empty(n, **i64)
         self.rows_out = torch.empty(n, dim, device=device)        # owner side: gathered rows / received grads
@@ -98,8 +111,16 @@ class ShardedEmbedding:
         else:
             self.recv_ids = torch.empty(n, **i64)
             self.rows_in = torch.empty(n, dim, device=device)     # requester side: received rows / grads to send
-        self.pos_flat = torch.empty(batch, **i64)
+        self.pos_flat = torch.empty(nt * batch, **i64)            # table t's positions at [t*batch, (t+1)*batch)
+        self.pos_flats = [self.pos_flat[t * batch:(t + 1) * batch] for t in range(nt)]
         self.flags = torch.zeros(2, dtype=torch.int32, device=device)   # [oob, overflow]
+
+    def shard(self, t: int) -> torch.Tensor:
+        """This rank's rows of table t (a view of the combined shard)."""
+        return self.table[self.offsets[t]:self.offsets[t] + shard_rows(self.num_rows[t], self.world, self.rank)]
+
+    def accum_shard(self, t: int) -> torch.Tensor:
+        return self.accum[self.offsets[t]:self.offsets[t] + shard_rows(self.num_rows[t], self.world, self.rank)]
 
     def _a2a(self, out, inp):
         """Asynchronous all-to-all (returns the work handle; None on one rank).  ``wait()`` on an NCCL work makes the
@@ -114,11 +135,11 @@ class ShardedEmbedding:
         if work is not None:
             work.wait()
 
-    # ---------------------------------------------------------------- forward, in three phases (so that the two
-    # tables' exchanges and the towers can be interleaved by the caller)
-    def lookup_start(self, ids: torch.Tensor):
-        """route + C1 (ids to their owners)."""
-        self.backend.route(ids, self.world, self.num_rows, self.cap, self.send_ids, self.pos_flat, self.flags)
+    # ---------------------------------------------------------------- forward, in three phases
+    def lookup_start(self, ids_list):
+        """route + C1 (ids to their owners); ids_list[t] = this rank's ids into table t (all of length batch)."""
+        self.backend.route(list(ids_list), self.world, self.num_rows, self.offsets, self.cap, self.send_ids, self.pos_flats,
+                           self.flags)
         self._w = self._a2a(self.recv_ids, self.send_ids)                          # C1
 
     def lookup_rows(self):
@@ -130,20 +151,19 @@ class ShardedEmbedding:
         self._w = self._a2a(self.rows_in, self.rows_out)                           # C2
 
     def lookup_finish(self, out: torch.Tensor):
-        """K1': rows of this rank's positions."""
+        """K1': out[t*batch + p, :] = row of position p of table t."""
         self._wait(self._w)
         self.backend.gather(self.rows_in, self.pos_flat, out, None)
         return out
 
-    def lookup(self, ids: torch.Tensor, out: torch.Tensor):
-        """out[p, :] = T[ids[p], :] for this rank's batch (route, C1, K1, C2, K1')."""
-        self.lookup_start(ids)
+    def lookup(self, ids_list, out: torch.Tensor):
+        self.lookup_start(ids_list)
         self.lookup_rows()
         return self.lookup_finish(out)
 
     # ---------------------------------------------------------------- backward, in two phases
     def grads_start(self, grads: torch.Tensor):
-        """K2' + C3: per-position gradient rows to the owners (padding slots are never read)."""
+        """K2' + C3: per-position gradient rows [n_tables*batch, dim] to the owners (padding slots are never read)."""
         self.backend.scatter_rows(grads, self.pos_flat, self.rows_in)
         self._w = self._a2a(self.rows_out, self.rows_in)                           # C3
 
@@ -153,7 +173,7 @@ class ShardedEmbedding:
         self.backend.apply(opt, self.table, self.accum, self.recv_ids, self.rows_out, lr, eps)
 
     def apply_gradients(self, grads: torch.Tensor, opt: str, lr: float, eps: float = 1e-7):
-        """grads[p, :] = dLoss/d(out[p, :]) of the last lookup (K2', C3, K2)."""
+        """grads[t*batch + p, :] = dLoss/d(out[t*batch + p, :]) of the last lookup (K2', C3, K2)."""
         self.grads_start(grads)
         self.grads_finish(opt, lr, eps)
 
@@ -166,6 +186,22 @@ class ShardedEmbedding:
         if int(f[1]):
             raise RuntimeError(f"sharded exchange overflow: more than {self.cap} positions for one owner; "
                                "raise capacity_factor")
+
+
+class ShardedEmbedding(ShardedTables):
+    """One row-sharded table: ``lookup(ids, out)`` / ``apply_gradients(grads, ...)`` on this rank's batch."""
+
+    def __init__(self, num_rows: int, dim: int, batch: int, device, group=None, capacity_factor: float = 2.0,
+                 backend=None, table: torch.Tensor | None = None, accum: torch.Tensor | None = None):
+        super().__init__([num_rows], dim, batch, device, group, capacity_factor, backend, table, accum)
+
+    def lookup_start(self, ids):
+        super().lookup_start([ids])
+
+    def lookup(self, ids, out):
+        self.lookup_start(ids)
+        self.lookup_rows()
+        return self.lookup_finish(out)
 
 
 class ShardedTwoTowerTrainer:
@@ -195,11 +231,10 @@ class ShardedTwoTowerTrainer:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         b, d, w = cfg.batch_size, cfg.embedding_dim, self.world
         adagrad = cfg.optimizer == "adagrad"
-        self.user_emb = ShardedEmbedding(cfg.n_users, d, b, dev, group, capacity_factor)
-        self.item_emb = ShardedEmbedding(cfg.n_items, d, b, dev, group, capacity_factor)
+        # both tables behind one set of exchange buffers: 3 all-to-alls per step, one owner-side gather/sort/update
+        self.emb = ShardedTables([cfg.n_users, cfg.n_items], d, b, dev, group, capacity_factor)
         if adagrad:
-            self.user_emb.accum = torch.full_like(self.user_emb.table, cfg.adagrad_initial_accumulator)
-            self.item_emb.accum = torch.full_like(self.item_emb.table, cfg.adagrad_initial_accumulator)
+            self.emb.accum = torch.full_like(self.emb.table, cfg.adagrad_initial_accumulator)
         n_tower = Tower.param_count(cfg, cfg.user_dims)
         n_item = Tower.param_count(cfg, cfg.item_dims)
         self.dense_flat = torch.zeros(n_tower + n_item, device=dev)
@@ -207,6 +242,11 @@ class ShardedTwoTowerTrainer:
         self.dense_grad = torch.empty_like(self.dense_flat)
         self.user_tower = Tower(cfg, cfg.user_dims, self.dense_flat, self.dense_accum, 0, dev)
         self.item_tower = Tower(cfg, cfg.item_dims, self.dense_flat, self.dense_accum, n_tower, dev)
+        # the towers' inputs / input gradients are the two halves of one buffer: one expand gather, one scatter
+        self.emb_in = torch.empty(2 * b, d, device=dev)
+        self.emb_grad = torch.empty(2 * b, d, device=dev)
+        self.user_tower.acts[0], self.item_tower.acts[0] = self.emb_in[:b], self.emb_in[b:]
+        self.user_tower.demb, self.item_tower.demb = self.emb_grad[:b], self.emb_grad[b:]
         l2 = cfg.l2_regularization
         # pass 1: slabs -> flat gradient (no update); pass 2 (after the all-reduce): update from the flat gradient
         self._segs_reduce = self.user_tower.segments(l2, self.dense_grad, 0) + \
@@ -237,10 +277,10 @@ class ShardedTwoTowerTrainer:
         import math
         from .trainer import TID_USER_TABLE, TID_ITEM_TABLE, TID_DENSE_BASE
         ops, w, r = self.ops, self.world, self.rank
-        for emb, tid in ((self.user_emb, TID_USER_TABLE), (self.item_emb, TID_ITEM_TABLE)):
-            n = shard_rows(emb.num_rows, w, r)
-            if n:
-                ops.fill_uniform_rows_(emb.table[:n], seed, tid, -0.05, 0.1, row_start=r, row_stride=w)
+        for t, tid in enumerate((TID_USER_TABLE, TID_ITEM_TABLE)):
+            shard = self.emb.shard(t)
+            if shard.shape[0]:
+                ops.fill_uniform_rows_(shard, seed, tid, -0.05, 0.1, row_start=r, row_stride=w)
         self.dense_flat.zero_()
         for t, tower in enumerate((self.user_tower, self.item_tower)):
             for l, wt in enumerate(tower.w):
@@ -260,19 +300,18 @@ class ShardedTwoTowerTrainer:
 
     def step(self, user_ids: torch.Tensor, item_ids: torch.Tensor) -> torch.Tensor:
         """One train step on this rank's batch; returns this rank's (device, unsynchronised) loss."""
-        cfg, ops, ut, it = self.cfg, self.ops, self.user_tower, self.item_tower
+        from .trainer import towers_forward, towers_backward
+        cfg, ops, ut, it, em = self.cfg, self.ops, self.user_tower, self.item_tower, self.emb
         b, w = cfg.batch_size, self.world
-        ue, ie = self.user_emb, self.item_emb
-        # both tables' exchanges are in flight together; the item rows travel while the user tower computes
-        ue.lookup_start(user_ids)
-        ie.lookup_start(item_ids)
-        ue.lookup_rows()
-        ie.lookup_rows()
-        ue.lookup_finish(ut.acts[0])
+        em.lookup_start((user_ids, item_ids))
+        em.lookup_rows()
+        em.lookup_finish(self.emb_in)
         row0 = (self.step_index * w + self.rank) * b          # first global batch row of this rank
-        q = ut.forward((cfg.dropout_rate, self.dropout_seed, 0, row0))
-        ie.lookup_finish(it.acts[0])
-        c = it.forward((cfg.dropout_rate, self.dropout_seed, 1, row0))
+        if cfg.symmetric:
+            q, c = towers_forward(ut, it, (cfg.dropout_rate, self.dropout_seed, row0))
+        else:
+            q = ut.forward((cfg.dropout_rate, self.dropout_seed, 0, row0))
+            c = it.forward((cfg.dropout_rate, self.dropout_seed, 1, row0))
         inv_t = 1.0 / cfg.temperature
         if self.negatives == "local" or w == 1:
             ops.retrieval_fwd_bwd(q, c, inv_t, self.ws, self.lse, self.per_row, self.loss, ut.dz[-1], it.dz[-1])
@@ -282,24 +321,38 @@ class ShardedTwoTowerTrainer:
             ops.retrieval_fwd_bwd(q, self.c_all, inv_t, self.ws, self.lse, self.per_row, self.loss, ut.dz[-1], self.dc_all,
                                   diag_offset=off)
             dist.reduce_scatter_tensor(it.dz[-1], self.dc_all, op=dist.ReduceOp.SUM, group=self.group)   # C5
-        ut.backward(cfg.dropout_rate)
-        ue.grads_start(ut.demb)                               # user gradient rows travel during the item tower's backward
-        it.backward(cfg.dropout_rate)
-        ie.grads_start(it.demb)
+
+        # every dx first: the embedding gradient rows travel to their owners beside the dw GEMMs and the dense reduce
+        def send():
+            em.grads_start(self.emb_grad)
+        if cfg.symmetric:
+            towers_backward(ut, it, cfg.dropout_rate, on_embedding_grads=send)
+        else:
+            ut.backward(cfg.dropout_rate, dx=True, dw=False)
+            it.backward(cfg.dropout_rate, dx=True, dw=False)
+            send()
+            ut.backward(cfg.dropout_rate, dx=False, dw=True)
+            it.backward(cfg.dropout_rate, dx=False, dw=True)
         self.step_index += 1
         if w == 1:
             ops.dense_update_(self._segs_reduce, cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon, apply=True)
-            ue.grads_finish(cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon)
-            ie.grads_finish(cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon)
+            em.grads_finish(cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon)
         else:
             ops.dense_update_(self._segs_reduce, cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon, apply=False)
             ar = dist.all_reduce(self.dense_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)   # C6
-            ue.grads_finish(cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon)
-            ie.grads_finish(cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon)
+            em.grads_finish(cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon)
             ar.wait()
             ops.dense_update_(self._segs_apply, cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon, apply=True)
         return self.loss
 
+    @property
+    def user_table(self) -> torch.Tensor:
+        """This rank's rows of the user table (global rows rank, rank+world, ...)."""
+        return self.emb.shard(0)
+
+    @property
+    def item_table(self) -> torch.Tensor:
+        return self.emb.shard(1)
+
     def check_ids(self):
-        self.user_emb.check()
-        self.item_emb.check()
+        self.emb.check()

@@ -117,17 +117,18 @@ class Tower:
             ops.dense_fwd(self.acts[l], self.w[l], self.b[l], relu=hidden, out=self.acts[l + 1], dropout=d)
         return self.acts[-1]
 
-    def backward(self, dropout_rate: float = 0.0):
-        """Consumes dz[-1]; leaves demb and the dw/db slabs."""
+    def backward(self, dropout_rate: float = 0.0, dx: bool = True, dw: bool = True):
+        """Consumes dz[-1]; leaves demb (dx) and the dw/db slabs (dw).  backward(dx=True, dw=False) followed by
+        backward(dx=False, dw=True) is the same computation with every dx first."""
         scale = 1.0
         if dropout_rate > 0.0:      # the same f32 arithmetic as the forward kernel's launcher: 1.0f / (1.0f - rate)
             one = torch.ones((), dtype=torch.float32)
             scale = (one / (one - torch.tensor(dropout_rate, dtype=torch.float32))).item()
         for l in range(self.n_layers - 1, -1, -1):
-            dx = self.dz[l - 1] if l > 0 else self.demb
-            mask_src = self.acts[l] if l > 0 else None       # acts[l] = (dropped-out) ReLU output of layer l-1
-            ops.dense_bwd(self.acts[l], self.w[l], self.dz[l], dx, mask_src, self.dw_slabs[l], self.db_slabs[l],
-                          dx_scale=scale if l > 0 else 1.0)
+            dxo = (self.dz[l - 1] if l > 0 else self.demb) if dx else None
+            mask_src = self.acts[l] if (l > 0 and dx) else None       # acts[l] = (dropped-out) ReLU output of layer l-1
+            ops.dense_bwd(self.acts[l], self.w[l], self.dz[l], dxo, mask_src, self.dw_slabs[l] if dw else None,
+                          self.db_slabs[l] if dw else None, dx_scale=scale if l > 0 else 1.0)
 
     def segments(self, l2: float, grad_flat=None, grad_offset: int = 0):
         segs = []
@@ -155,17 +156,32 @@ def towers_forward(ut: "Tower", it: "Tower", dropout=None):
     return ut.acts[-1], it.acts[-1]
 
 
-def towers_backward(ut: "Tower", it: "Tower", dropout_rate: float = 0.0):
-    """Backward of both towers, two launches per layer (dx of both, dw+db of both)."""
+def towers_backward(ut: "Tower", it: "Tower", dropout_rate: float = 0.0, on_embedding_grads=None):
+    """Backward of both towers, two launches per layer (dx of both, dw+db of both).
+    With ``on_embedding_grads`` every dx is computed first, the callback runs as soon as demb is complete (the
+    sharded trainer starts the gradient exchange there) and the dw+db launches follow, beside the transfer."""
     scale = 1.0
     if dropout_rate > 0.0:
         one = torch.ones((), dtype=torch.float32)
         scale = (one / (one - torch.tensor(dropout_rate, dtype=torch.float32))).item()
-    for l in range(ut.n_layers - 1, -1, -1):
-        dxs = (ut.dz[l - 1], it.dz[l - 1]) if l > 0 else (ut.demb, it.demb)
-        masks = (ut.acts[l], it.acts[l]) if l > 0 else (None, None)
+    none2 = (None, None)
+
+    def layer(l, dx: bool, dw: bool):
+        dxs = ((ut.dz[l - 1], it.dz[l - 1]) if l > 0 else (ut.demb, it.demb)) if dx else none2
+        masks = (ut.acts[l], it.acts[l]) if (l > 0 and dx) else none2
         ops.dense_bwd2((ut.acts[l], it.acts[l]), (ut.w[l], it.w[l]), (ut.dz[l], it.dz[l]), dxs, masks,
-                       (ut.dw_slabs[l], it.dw_slabs[l]), (ut.db_slabs[l], it.db_slabs[l]), dx_scale=scale if l > 0 else 1.0)
+                       (ut.dw_slabs[l], it.dw_slabs[l]) if dw else none2, (ut.db_slabs[l], it.db_slabs[l]) if dw else none2,
+                       dx_scale=scale if l > 0 else 1.0)
+
+    if on_embedding_grads is None:
+        for l in range(ut.n_layers - 1, -1, -1):
+            layer(l, True, True)
+        return
+    for l in range(ut.n_layers - 1, -1, -1):
+        layer(l, True, False)
+    on_embedding_grads()
+    for l in range(ut.n_layers - 1, -1, -1):
+        layer(l, False, True)
 
 
 class TwoTowerTrainer:
