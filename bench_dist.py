@@ -30,21 +30,29 @@ def run_distributed(args, rank, world, dev):
     cfg = TwoTowerConfig(n_users=users_per_gpu * world, n_items=items_per_gpu * world, embedding_dim=dim,
                          tower_dims=tower_dims, temperature=0.1, l2_regularization=1e-6, learning_rate=0.001,
                          optimizer=args.optimizer, batch_size=batch)
-    trainer = ShardedTwoTowerTrainer(cfg, dev, seed=seed, negatives=negatives)
+    # TT_FORCE_COLLECTIVES=1: issue the RCCL calls even on one rank (their launch cost without any xGMI traffic)
+    trainer = ShardedTwoTowerTrainer(cfg, dev, seed=seed, negatives=negatives,
+                                     capacity_factor=float(os.environ.get("TT_CAPACITY_FACTOR", 2.0)),
+                                     force_collectives=bool(os.environ.get("TT_FORCE_COLLECTIVES")))
     total = args.warmup + args.steps
     uids = torch.empty(total, batch, dtype=torch.int64, device=dev)
     iids = torch.empty(total, batch, dtype=torch.int64, device=dev)
     for s in range(total):
         trainer.synthetic_batch(seed, s, args.ids, out=(uids[s], iids[s]))
+    # TT_PREFETCH=1: hand the next batch's ids to step(): their routing + id all-to-all then run beside this step's
+    # scorer.  Off by default: on one rank (forced RCCL calls) the concurrent kernels cost the scorer more (+15 us)
+    # than the exposed exchange they hide; to be re-measured on a multi-GPU node.
+    prefetch = os.environ.get("TT_PREFETCH", "0") == "1"
+    batches = [(uids[s], iids[s]) for s in range(total)] + [None]
     for s in range(args.warmup):
-        trainer.step(uids[s], iids[s])
+        trainer.step(*batches[s], next_ids=batches[s + 1] if prefetch else None)
     torch.cuda.synchronize()
     trainer.check_ids()
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for s in range(args.warmup, total):
-        trainer.step(uids[s], iids[s])
+        trainer.step(*batches[s], next_ids=batches[s + 1] if prefetch else None)
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()

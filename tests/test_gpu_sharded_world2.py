@@ -87,9 +87,12 @@ def _worker(rank, world, port, opt, variant, negatives, ret):
         # each rank holds exactly its rows of the synthetic tables
         assert np.array_equal(tr.user_table.cpu().numpy(),
                               ref.user_table[rank::world].astype(np.float32))
+        batches = [tr.synthetic_batch(seed, step, variant) for step in range(2)]
         for step in range(2):
-            u, i = tr.synthetic_batch(seed, step, variant)
-            loss = tr.step(u, i).item()
+            u, i = batches[step]
+            # step 0 hands step 1's ids over: their routing and id exchange are issued in the middle of step 0
+            loss = tr.step(u, i, next_ids=batches[1] if step == 0 else None).item()
+            assert (tr.emb._cur == 1) == (step == 1)
             tr.check_ids()
             # oracle: forward/backward of EVERY rank's sub-batch on the shared state, then one update with all gradients
             subs, dense = [], None

@@ -204,6 +204,37 @@ def test_two_tower_model_facade(dev):
         m.train_step({"user": u, "item": i})
 
 
+@pytest.mark.parametrize("negatives", ["local", "global"])
+def test_sharded_trainer_one_rank_rccl_collectives(dev, negatives):
+    """The N>1 code path with its collectives really issued — asynchronous all_to_all_single (ids int64, rows f32,
+    gradient rows), the dense all-reduce, and for negatives="global" all_gather_into_tensor + reduce_scatter_tensor —
+    on a one-rank "nccl" (= RCCL) group, which is all one GPU allows.  Everything must equal the plain trainer bit for
+    bit (a one-rank sum is the identity)."""
+    import os
+    import torch.distributed as dist
+    from two_tower_amazon_recommender_amd.sharded import ShardedTwoTowerTrainer
+    assert not dist.is_initialized()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ["MASTER_PORT"] = "29578"
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        cfg, tr, _ = make(dev, 5000, 3000, 64, [128, 64], 1024, "adagrad", 37)
+        sh = ShardedTwoTowerTrainer(TwoTowerConfig(**cfg.__dict__), dev, seed=37, negatives=negatives, force_collectives=True)
+        assert sh.collectives and sh.emb.recv_ids.data_ptr() != sh.emb.send_ids.data_ptr()
+        batches = [tr.synthetic_batch(37, step, "Z") for step in range(4)]
+        for step in range(4):
+            u, i = batches[step]
+            l1 = tr.step(u, i).clone()
+            # steps 0-1 hand the next step's ids over (route + id all-to-all run beside the scorer), step 2 does not
+            l2 = sh.step(u, i, next_ids=batches[step + 1] if step < 2 else None).clone()
+            assert torch.equal(l1, l2)
+        sh.check_ids()
+        assert torch.equal(sh.user_table, tr.user_table) and torch.equal(sh.item_table, tr.item_table)
+        assert torch.equal(sh.dense_flat, tr.dense_flat)
+        assert torch.equal(sh.emb.accum_shard(0), tr.user_accum)
+    finally:
+        dist.destroy_process_group()
+
+
 def test_sharded_trainer_global_negatives_world1_equals_local(dev):
     """negatives="global" (all-gather candidates, diag offset, reduce-scatter dC) degenerates to the local form on one
     rank; needs a process group, so a single-rank gloo group is created on the fly when none exists."""

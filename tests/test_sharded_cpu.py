@@ -60,6 +60,13 @@ class OracleRowBackend:
     def plan(self, ids, num_rows):
         pass
 
+    def prefetch_stream(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def join_prefetch(self):
+        pass
+
     def apply(self, opt, table, accum, ids, grads, lr, eps):
         from oracle import two_tower as tt
         i = ids.numpy()
@@ -212,15 +219,24 @@ def _worker_combined(rank, world, port, ret):
                 assert em.shard(t).shape[0] == shard_rows(fulls[t].shape[0], world, rank)
             if opt == "adagrad":
                 em.accum = torch.full_like(em.table, 0.1)
-            for step in range(2):
-                ids = [synth.batch_ids(5, 3 + t, step, world * batch, fulls[t].shape[0], "Z") for t in range(2)]
+            n_steps = 3
+            all_ids = [[synth.batch_ids(5, 3 + t, step, world * batch, fulls[t].shape[0], "Z") for t in range(2)]
+                       for step in range(n_steps)]
+            sl = slice(rank * batch, (rank + 1) * batch)
+            mine = [[torch.from_numpy(all_ids[step][t][sl]) for t in range(2)] for step in range(n_steps)]
+            for step in range(n_steps):
+                ids = all_ids[step]
                 grads = [synth.uniform_f32(5, 9 + 2 * step + t, world * batch * dim, -1.0, 2.0).reshape(world * batch, dim)
                          for t in range(2)]
-                sl = slice(rank * batch, (rank + 1) * batch)
                 out = torch.empty(2 * batch, dim)
-                em.lookup_start([torch.from_numpy(ids[0][sl]), torch.from_numpy(ids[1][sl])])
+                cur_before = em._cur
+                em.lookup_start(mine[step])
+                # steps 1.. were prefetched during the previous step: the other id-buffer set is adopted
+                assert (em._cur != cur_before) == (step > 0)
                 em.lookup_rows()
                 em.lookup_finish(out)
+                if step + 1 < n_steps:
+                    em.lookup_prefetch(mine[step + 1])          # next step's route + id exchange, issued mid-step
                 for t in range(2):
                     assert np.array_equal(out.numpy()[t * batch:(t + 1) * batch], fulls[t][ids[t][sl]])
                 em.grads_start(torch.from_numpy(np.concatenate([grads[0][sl], grads[1][sl]])))
@@ -243,6 +259,13 @@ def _worker_combined(rank, world, port, ret):
                         dist.all_gather_object(gacc, em.accum_shard(t).numpy().copy())
                         for r in range(world):
                             accs[t][r::world] = gacc[r]
+            # a prefetch for ids that are NOT the next call's: dropped, the lookup routes afresh
+            em.lookup_prefetch(mine[0])
+            out = torch.empty(2 * batch, dim)
+            em.lookup(mine[2], out)
+            for t in range(2):
+                assert np.array_equal(out.numpy()[t * batch:(t + 1) * batch], fulls[t][all_ids[2][t][sl]])
+            em.check()
         ret[rank] = "ok"
     except Exception:                                             # noqa: BLE001
         import traceback

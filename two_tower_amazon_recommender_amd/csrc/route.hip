@@ -3,9 +3,10 @@
 // route_kernel   : stable partition of a batch of ids by owner rank (owner = id % world, local row = id / world
 //                  + the table's offset inside the owner's combined shard) into fixed-capacity per-owner send
 //                  buffers (padding id -1) + the flat slot of every position; one workgroup per table.
-//                  One workgroup, 16 waves; per 1024-position round: `world` wave ballots give the rank inside the
-//                  wave, a 16 x world table in LDS gives the offsets across waves (ascending position order inside
-//                  every owner bucket: deterministic).  Integer/byte work, latency-bound (a few microseconds).
+//                  16 waves, 8 consecutive positions per thread; per 8192-position round: `world` wave scans of the
+//                  per-thread counts give the first slot inside the wave, a 16 x world table in LDS gives the
+//                  offsets across waves (ascending position order inside every owner bucket: deterministic).
+//                  Integer/byte work, latency-bound (a few microseconds).
 // scatter_rows   : dst[idx[p], :] = src[p, :] (idx < 0 skipped) — per-position gradient rows into the send buffer;
 //                  HBM-bound, dim/4 lanes per row like the gather.
 #include "common.h"
@@ -20,34 +21,58 @@ struct RouteTables {
 
 // One workgroup per table (blockIdx.x = table t); bucket (owner o, table t) of the send buffer is
 // send_ids[(o*n_tables + t)*cap ...]: one all-to-all moves every table's ids (and later rows) at once.
-__global__ __launch_bounds__(1024) void route_kernel(RouteTables tabs, int n_tables, int64_t n, int world, int cap,
+// A thread owns kIpt CONSECUTIVE positions, so "ascending position" = (thread, j) order: per owner, a wave
+// scan of the per-thread counts + a 16 x world table across waves gives every thread its first slot; a batch
+// of 8192 ids is one round (two barriers) instead of eight.
+constexpr int kIpt = 8;
+
+// WORLD is a template parameter: id % WORLD and id / WORLD on int64 are multiply-shift sequences for a constant
+// divisor, but a ~100-instruction software division for a runtime one (that alone made the kernel 15 us).
+template <int WORLD>
+__global__ __launch_bounds__(1024) void route_kernel(RouteTables tabs, int n_tables, int64_t n, int cap,
                                                      int64_t* __restrict__ send_ids, int32_t* __restrict__ flags) {
+  constexpr int world = WORLD;
   __shared__ int wave_cnt[16][kMaxWorld];
   __shared__ int wave_off[16][kMaxWorld];
   __shared__ int running[kMaxWorld];
+  __shared__ unsigned short thread_excl[kMaxWorld][1024];      // first slot of a thread inside its wave, per owner
   const int t = blockIdx.x;
   const int64_t* __restrict__ ids = tabs.t[t].ids;
   int64_t* __restrict__ pos_flat = tabs.t[t].pos_flat;
   const int64_t num_rows = tabs.t[t].num_rows, local_offset = tabs.t[t].local_offset;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   for (int o = 0; o < world; ++o)
     for (int i = tid; i < cap; i += 1024) send_ids[((int64_t)o * n_tables + t) * cap + i] = -1;
   if (tid < kMaxWorld) running[tid] = 0;
   __syncthreads();
   bool oob = false, over = false;
-  const int64_t rounds = (n + 1023) / 1024;
+  const int64_t chunk = 1024 * kIpt;
+  const int64_t rounds = (n + chunk - 1) / chunk;
   for (int64_t r = 0; r < rounds; ++r) {
-    const int64_t p = r * 1024 + tid;
-    const bool valid = p < n;
-    const int64_t id = valid ? ids[p] : 0;
-    const bool bad = valid && (id < 0 || id >= num_rows);
-    const int owner = (valid && !bad) ? (int)(id % world) : -1;
-    int my_rank = 0;
+    const int64_t base = r * chunk + (int64_t)tid * kIpt;
+    int64_t id[kIpt];
+    int owner[kIpt];
+#pragma unroll
+    for (int j = 0; j < kIpt; ++j) {
+      const int64_t p = base + j;
+      const bool valid = p < n;
+      id[j] = valid ? ids[p] : 0;
+      const bool bad = valid && (id[j] < 0 || id[j] >= num_rows);
+      oob = oob || bad;
+      owner[j] = (valid && !bad) ? (int)((uint64_t)id[j] % (uint64_t)world) : -1;
+    }
     for (int o = 0; o < world; ++o) {
-      const unsigned long long m = __ballot(owner == o);
-      if (owner == o) my_rank = __popcll(m & lt_mask);
-      if (lane == 0) wave_cnt[wave][o] = __popcll(m);
+      int c = 0;
+#pragma unroll
+      for (int j = 0; j < kIpt; ++j) c += owner[j] == o;
+      int incl = c;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d);
+        if (lane >= d) incl += v;
+      }
+      thread_excl[o][tid] = (unsigned short)(incl - c);
+      if (lane == 63) wave_cnt[wave][o] = incl;
     }
     __syncthreads();
     if (tid < world) {
@@ -59,20 +84,29 @@ __global__ __launch_bounds__(1024) void route_kernel(RouteTables tabs, int n_tab
       running[tid] = run;
     }
     __syncthreads();
-    if (owner >= 0) {
-      const int slot = wave_off[wave][owner] + my_rank;
+#pragma unroll
+    for (int j = 0; j < kIpt; ++j) {
+      const int64_t p = base + j;
+      if (p >= n) break;
+      const int o = owner[j];
+      if (o < 0) {
+        pos_flat[p] = -1;
+        continue;
+      }
+      int before = 0;                       // earlier positions of this thread with the same owner
+#pragma unroll
+      for (int i = 0; i < kIpt; ++i) before += (i < j) && (owner[i] == o);
+      const int slot = wave_off[wave][o] + thread_excl[o][tid] + before;
       if (slot < cap) {
-        const int64_t flat = ((int64_t)owner * n_tables + t) * cap + slot;
-        send_ids[flat] = id / world + local_offset;
+        const int64_t flat = ((int64_t)o * n_tables + t) * cap + slot;
+        send_ids[flat] = (int64_t)((uint64_t)id[j] / (uint64_t)world) + local_offset;
         pos_flat[p] = flat;
       } else {
         pos_flat[p] = -1;
         over = true;
       }
-    } else if (valid) {
-      pos_flat[p] = -1;
-      oob = oob || bad;
     }
+    __syncthreads();                        // thread_excl / wave_off are rewritten by the next round
   }
   if (flags != nullptr) {
     if (oob) atomicOr(&flags[0], 1);
@@ -110,7 +144,16 @@ extern "C" int tt_route_tables_by_owner_i64(const tt_route_table* tables, int32_
   }
   hipStream_t stream = tt::as_stream(stream_);
   tt::ProfScope prof("route", stream);
-  hipLaunchKernelGGL(route_kernel, dim3(n_tables), dim3(1024), 0, stream, tabs, n_tables, n_ids, world, cap, send_ids, flags);
+  switch (world) {
+#define TT_ROUTE_CASE(W)                                                                                                   \
+  case W:                                                                                                                  \
+    hipLaunchKernelGGL(route_kernel<W>, dim3(n_tables), dim3(1024), 0, stream, tabs, n_tables, n_ids, cap, send_ids, flags); \
+    break;
+    TT_ROUTE_CASE(1) TT_ROUTE_CASE(2) TT_ROUTE_CASE(3) TT_ROUTE_CASE(4) TT_ROUTE_CASE(5) TT_ROUTE_CASE(6) TT_ROUTE_CASE(7)
+    TT_ROUTE_CASE(8) TT_ROUTE_CASE(9) TT_ROUTE_CASE(10) TT_ROUTE_CASE(11) TT_ROUTE_CASE(12) TT_ROUTE_CASE(13)
+    TT_ROUTE_CASE(14) TT_ROUTE_CASE(15) TT_ROUTE_CASE(16)
+#undef TT_ROUTE_CASE
+  }
   return tt::check_launch("tt_route_tables_by_owner_i64");
 }
 

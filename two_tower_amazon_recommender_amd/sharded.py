@@ -29,6 +29,8 @@ the HIP ops; the CPU/gloo tests pass a NumPy-oracle backend defined in the test)
 """
 from __future__ import annotations
 
+import contextlib
+
 import torch
 import torch.distributed as dist
 
@@ -42,7 +44,18 @@ class HipRowBackend:
         self.device = device
         self._plans = {}
         self._side = torch.cuda.Stream(device=device)
+        self._pre = torch.cuda.Stream(device=device)
         self._pending = None
+
+    @contextlib.contextmanager
+    def prefetch_stream(self):
+        """Work issued inside runs on a side stream, after everything queued so far on the current stream."""
+        self._pre.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._pre):
+            yield
+
+    def join_prefetch(self):
+        torch.cuda.current_stream().wait_stream(self._pre)
 
     def route(self, ids_list, world, num_rows_list, offsets, cap, send_ids, pos_flats, flags):
         self.ops.route_tables_by_owner(ids_list, world, num_rows_list, offsets, cap, send_ids, pos_flats, flags)
@@ -82,8 +95,11 @@ class ShardedTables:
     """Several row-sharded tables of one width behind one set of exchange buffers (see the module docstring)."""
 
     def __init__(self, num_rows, dim: int, batch: int, device, group=None, capacity_factor: float = 2.0,
-                 backend=None, table: torch.Tensor | None = None, accum: torch.Tensor | None = None):
+                 backend=None, table: torch.Tensor | None = None, accum: torch.Tensor | None = None,
+                 force_collectives: bool = False):
         self.group = group
+        # force_collectives: issue the collectives even in a one-rank group (exercises the RCCL calls on one GPU)
+        self.collectives = force_collectives and dist.is_initialized()
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.num_rows = [int(n) for n in num_rows]
@@ -103,17 +119,28 @@ class ShardedTables:
         self.accum = accum
         self.backend = backend if backend is not None else HipRowBackend(device)
         n = w * nt * self.cap
-        i64 = dict(dtype=torch.int64, device=device)
-        self.send_ids = torch.empty(n, **i64)
+        self.collectives = self.collectives or w > 1
         self.rows_out = torch.empty(n, dim, device=device)        # owner side: gathered rows / received grads
-        if w == 1:                                                # one rank: the "exchange" is the identity
-            self.recv_ids, self.rows_in = self.send_ids, self.rows_out
-        else:
-            self.recv_ids = torch.empty(n, **i64)
-            self.rows_in = torch.empty(n, dim, device=device)     # requester side: received rows / grads to send
-        self.pos_flat = torch.empty(nt * batch, **i64)            # table t's positions at [t*batch, (t+1)*batch)
-        self.pos_flats = [self.pos_flat[t * batch:(t + 1) * batch] for t in range(nt)]
+        # requester side: received rows / grads to send (one rank without collectives: the exchange is the identity)
+        self.rows_in = torch.empty(n, dim, device=device) if self.collectives else self.rows_out
+        # id buffers exist twice: lookup_prefetch() routes and exchanges the NEXT step's ids while this step computes
+        self._idbufs = [self._make_idbufs(), None]
+        self._cur = 0
+        self._prefetched = None
         self.flags = torch.zeros(2, dtype=torch.int32, device=device)   # [oob, overflow]
+
+    def _make_idbufs(self):
+        n = self.world * self.n_tables * self.cap
+        i64 = dict(dtype=torch.int64, device=self.device)
+        send = torch.empty(n, **i64)
+        recv = torch.empty(n, **i64) if self.collectives else send
+        pos = torch.empty(self.n_tables * self.batch, **i64)      # table t's positions at [t*batch, (t+1)*batch)
+        return send, recv, pos, [pos[t * self.batch:(t + 1) * self.batch] for t in range(self.n_tables)]
+
+    send_ids = property(lambda self: self._idbufs[self._cur][0])
+    recv_ids = property(lambda self: self._idbufs[self._cur][1])
+    pos_flat = property(lambda self: self._idbufs[self._cur][2])
+    pos_flats = property(lambda self: self._idbufs[self._cur][3])
 
     def shard(self, t: int) -> torch.Tensor:
         """This rank's rows of table t (a view of the combined shard)."""
@@ -126,7 +153,7 @@ class ShardedTables:
         """Asynchronous all-to-all (returns the work handle; None on one rank).  ``wait()`` on an NCCL work makes the
         current stream wait for the collective without blocking the host, so independent kernels issued before
         the wait overlap the transfer."""
-        if self.world > 1:
+        if self.collectives:
             return dist.all_to_all_single(out, inp, group=self.group, async_op=True)
         return None
 
@@ -137,10 +164,35 @@ class ShardedTables:
 
     # ---------------------------------------------------------------- forward, in three phases
     def lookup_start(self, ids_list):
-        """route + C1 (ids to their owners); ids_list[t] = this rank's ids into table t (all of length batch)."""
-        self.backend.route(list(ids_list), self.world, self.num_rows, self.offsets, self.cap, self.send_ids, self.pos_flats,
+        """route + C1 (ids to their owners); ids_list[t] = this rank's ids into table t (all of length batch).
+        If exactly these tensors were handed to lookup_prefetch() the exchange is already on its way."""
+        ids_list = list(ids_list)
+        pre, self._prefetched = self._prefetched, None
+        if pre is not None and len(pre[0]) == len(ids_list) and all(a is b for a, b in zip(pre[0], ids_list)):
+            self._cur = 1 - self._cur
+            self._w = pre[1]
+            self.backend.join_prefetch()
+            return
+        if pre is not None:                       # prefetched for other ids: let that exchange finish, then ignore it
+            self._wait(pre[1])
+            self.backend.join_prefetch()
+        self.backend.route(ids_list, self.world, self.num_rows, self.offsets, self.cap, self.send_ids, self.pos_flats,
                            self.flags)
         self._w = self._a2a(self.recv_ids, self.send_ids)                          # C1
+
+    def lookup_prefetch(self, ids_list):
+        """route + C1 of the NEXT step's ids (they do not depend on the tables) into the other id-buffer set, on a side
+        stream: the id exchange leaves the next step's critical path.  Call it after lookup_finish(), when the
+        collective queue is idle and the long scorer kernels are about to run."""
+        ids_list = list(ids_list)
+        nxt = 1 - self._cur
+        if self._idbufs[nxt] is None:
+            self._idbufs[nxt] = self._make_idbufs()
+        send, recv, _, pos_flats = self._idbufs[nxt]
+        with self.backend.prefetch_stream():
+            self.backend.route(ids_list, self.world, self.num_rows, self.offsets, self.cap, send, pos_flats, self.flags)
+            work = self._a2a(recv, send)                                           # C1 of the next step
+        self._prefetched = (ids_list, work)
 
     def lookup_rows(self):
         """owner side: sort plan (side stream), K1 gather, C2 (rows back to the requesters)."""
@@ -198,6 +250,9 @@ class ShardedEmbedding(ShardedTables):
     def lookup_start(self, ids):
         super().lookup_start([ids])
 
+    def lookup_prefetch(self, ids):
+        super().lookup_prefetch([ids])
+
     def lookup(self, ids, out):
         self.lookup_start(ids)
         self.lookup_rows()
@@ -217,7 +272,7 @@ class ShardedTwoTowerTrainer:
     """
 
     def __init__(self, cfg, device, group=None, seed: int | None = None, negatives: str = "local",
-                 capacity_factor: float = 2.0):
+                 capacity_factor: float = 2.0, force_collectives: bool = False):
         from . import ops
         from .trainer import Tower, TID_USER_TABLE, TID_ITEM_TABLE
         cfg.validate()
@@ -232,7 +287,9 @@ class ShardedTwoTowerTrainer:
         b, d, w = cfg.batch_size, cfg.embedding_dim, self.world
         adagrad = cfg.optimizer == "adagrad"
         # both tables behind one set of exchange buffers: 3 all-to-alls per step, one owner-side gather/sort/update
-        self.emb = ShardedTables([cfg.n_users, cfg.n_items], d, b, dev, group, capacity_factor)
+        self.emb = ShardedTables([cfg.n_users, cfg.n_items], d, b, dev, group, capacity_factor,
+                                 force_collectives=force_collectives)
+        self.collectives = self.emb.collectives
         if adagrad:
             self.emb.accum = torch.full_like(self.emb.table, cfg.adagrad_initial_accumulator)
         n_tower = Tower.param_count(cfg, cfg.user_dims)
@@ -298,14 +355,18 @@ class ShardedTwoTowerTrainer:
         self.ops.fill_ids_(out[1], seed, TID_ITEM_IDS, self.cfg.n_items, variant, start=start)
         return out
 
-    def step(self, user_ids: torch.Tensor, item_ids: torch.Tensor) -> torch.Tensor:
-        """One train step on this rank's batch; returns this rank's (device, unsynchronised) loss."""
+    def step(self, user_ids: torch.Tensor, item_ids: torch.Tensor, next_ids=None) -> torch.Tensor:
+        """One train step on this rank's batch; returns this rank's (device, unsynchronised) loss.
+        next_ids = (user_ids, item_ids) of the following step, if the input pipeline already has them: their
+        routing and id all-to-all then run beside this step's scorer (pass the same tensors to the next call)."""
         from .trainer import towers_forward, towers_backward
         cfg, ops, ut, it, em = self.cfg, self.ops, self.user_tower, self.item_tower, self.emb
         b, w = cfg.batch_size, self.world
         em.lookup_start((user_ids, item_ids))
         em.lookup_rows()
         em.lookup_finish(self.emb_in)
+        if next_ids is not None:
+            em.lookup_prefetch(next_ids)
         row0 = (self.step_index * w + self.rank) * b          # first global batch row of this rank
         if cfg.symmetric:
             q, c = towers_forward(ut, it, (cfg.dropout_rate, self.dropout_seed, row0))
@@ -313,7 +374,7 @@ class ShardedTwoTowerTrainer:
             q = ut.forward((cfg.dropout_rate, self.dropout_seed, 0, row0))
             c = it.forward((cfg.dropout_rate, self.dropout_seed, 1, row0))
         inv_t = 1.0 / cfg.temperature
-        if self.negatives == "local" or w == 1:
+        if self.negatives == "local" or not self.collectives:
             ops.retrieval_fwd_bwd(q, c, inv_t, self.ws, self.lse, self.per_row, self.loss, ut.dz[-1], it.dz[-1])
         else:
             dist.all_gather_into_tensor(self.c_all, c, group=self.group)                       # C4
@@ -334,7 +395,7 @@ class ShardedTwoTowerTrainer:
             ut.backward(cfg.dropout_rate, dx=False, dw=True)
             it.backward(cfg.dropout_rate, dx=False, dw=True)
         self.step_index += 1
-        if w == 1:
+        if not self.collectives:
             ops.dense_update_(self._segs_reduce, cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon, apply=True)
             em.grads_finish(cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon)
         else:
