@@ -415,6 +415,59 @@ def test_full_size_properties_cfg3(dev):
     assert dc.abs().max().item() <= 1e-6
 
 
+def test_full_size_table_kernels_cfg4_100m_rows(dev):
+    """BASELINE configs[3] size: a 100M x 128 f32 item table (51 GB; element offsets pass 2^33, byte offsets 2^35).
+    The generator, the gather and both sparse optimizers are checked bit for bit against the oracle ON THE ROWS
+    THEY TOUCH (the oracle regenerates any row range from the counter), and a checksum over a 1M-row window around
+    every touched row proves the neighbours were left alone."""
+    rows, d, n = 100_000_000, 128, 16384
+    free, _ = torch.cuda.mem_get_info(dev)
+    if free < 120 * 2**30:
+        pytest.skip("needs ~110 GB of free HBM")
+    table = torch.empty(rows, d, device=dev)
+    ops.fill_uniform_rows_(table, 5, synth.TID_ITEM_TABLE, -0.05, 0.1, row_start=0, row_stride=1)
+    # ids: power-law batch (heavy duplicates at the front) + hand-placed rows at the far end and around 2^24 / 2^25 rows
+    ids = synth.batch_ids(5, synth.TID_ITEM_IDS, 0, n, rows, "Z")
+    ids[:8] = [rows - 1, rows - 1, rows - 2, 1 << 24, (1 << 24) + 1, (1 << 25) - 1, 33_554_433, 99_999_937]
+    uniq = np.unique(ids)
+
+    def oracle_rows(u):
+        return np.stack([synth.embedding_table(5, synth.TID_ITEM_TABLE, rows, d, row_start=int(r), row_count=1)[0] for r in u])
+    far = uniq[uniq >= (1 << 24)]
+    near = uniq[uniq < (1 << 24)][:200]
+    check = np.concatenate([near, far])
+    want = oracle_rows(check)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    got = ops.embedding_gather(table, T(check, dev), oob_flag=flag)
+    assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32)) and flag.item() == 0
+    # checksums of the windows that must not change (everything except the touched rows)
+    before = table.clone()
+    grads = synth.uniform_f32(5, 9, n * d, -1.0, 2.0).reshape(n, d)
+    plan = ops.SparsePlan(n, dev).run(T(ids, dev), rows)
+    ops.sparse_sgd_(table, T(grads, dev), plan, lr=0.01)
+    changed = (table != before).any(dim=1).nonzero().flatten().cpu().numpy()
+    assert np.isin(changed, uniq).all(), "a row outside the batch was modified"
+    assert len(changed) >= 0.99 * len(uniq)
+    # bit-exact on the checked rows.  The kernel sums a duplicated id's gradients in sorted-slot pieces of 64, so the
+    # oracle's de-duplication runs on the FULL batch (the slots depend on every id), then the checked rows are picked
+    ref_full_uniq, ref_g = tt.dedup_sum(ids, grads)
+    gsum = ref_g[np.searchsorted(ref_full_uniq, check)]
+    ref = want - np.float32(0.01) * gsum
+    got = ops.embedding_gather(table, T(check, dev)).cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    # Adagrad on the same table
+    accum = torch.full_like(before, 0.1)
+    del before
+    plan.run(T(ids, dev), rows)
+    acc_ref = np.full_like(want, np.float32(0.1)) + gsum * gsum
+    ref2 = ref - (np.float32(0.01) * gsum) / np.sqrt(acc_ref + np.float32(1e-7))
+    ops.sparse_adagrad_(table, accum, T(grads, dev), plan, lr=0.01, eps=1e-7)
+    got2 = ops.embedding_gather(table, T(check, dev)).cpu().numpy()
+    assert np.array_equal(got2.view(np.uint32), ref2.view(np.uint32))
+    assert np.array_equal(ops.embedding_gather(accum, T(check, dev)).cpu().numpy().view(np.uint32), acc_ref.view(np.uint32))
+    assert int((accum != 0.1).any(dim=1).sum().item()) <= len(uniq)
+
+
 # ----------------------------------------------------------------------------------- sharded routing kernels
 def np_route(ids, world, num_rows, cap):
     send = np.full(world * cap, -1, dtype=np.int64)

@@ -83,6 +83,38 @@ def test_train_steps_match_oracle(dev, name, shape, opt, variant):
         assert np.abs(tr.user_accum.cpu().numpy() - ref.user_accum).max() <= 1e-4 * ref.user_accum.max()
 
 
+def test_full_size_train_step_properties_cfg3(dev):
+    """BASELINE configs[2] at full size (5M users x 10M items x 128, towers 256-128, batch 8192), properties that
+    need no O(B^2) host work: only the batch's rows change, the first loss is ~ln(B) (near-uniform softmax at init),
+    and the whole step is bit-reproducible from the seed."""
+    shape = (5_000_000, 10_000_000, 128, [256, 128], 8192)
+    sums = []
+    for rep in range(2):
+        cfg = TwoTowerConfig(n_users=shape[0], n_items=shape[1], embedding_dim=shape[2], tower_dims=shape[3], temperature=0.1,
+                             l2_regularization=1e-6, learning_rate=0.001, optimizer="sgd", batch_size=shape[4])
+        tr = TwoTowerTrainer(cfg, dev, seed=1003)
+        before_u, before_i = tr.user_table.clone(), tr.item_table.clone()
+        dense_before = tr.dense_flat.clone()
+        u, i = tr.synthetic_batch(1003, 0, "Z")
+        loss = tr.step(u, i).item()
+        tr.check_ids()
+        assert abs(loss / shape[4] - np.log(shape[4])) < 0.05
+        for table, before, ids in ((tr.user_table, before_u, u), (tr.item_table, before_i, i)):
+            changed = (table != before).any(dim=1).nonzero().flatten()
+            uniq = torch.unique(ids)
+            assert torch.isin(changed, uniq).all(), "a row outside the batch was modified"
+            assert changed.numel() >= 0.99 * uniq.numel()
+            assert torch.isfinite(table[uniq]).all()
+        assert (tr.dense_flat != dense_before).float().mean().item() > 0.5
+        loss2 = tr.step(*tr.synthetic_batch(1003, 1, "Z")).item()
+        sums.append((loss, loss2, tr.user_table.view(torch.int32).sum(dtype=torch.int64).item(),
+                     tr.item_table.view(torch.int32).sum(dtype=torch.int64).item(),
+                     tr.dense_flat.view(torch.int32).sum(dtype=torch.int64).item()))
+        del tr, before_u, before_i
+        torch.cuda.empty_cache()
+    assert sums[0] == sums[1], "the train step is not bit-reproducible"
+
+
 def test_out_of_range_id_is_reported(dev):
     cfg, tr, _ = make(dev, 100, 100, 32, [32], 256, "sgd", 5)
     u, i = tr.synthetic_batch(5, 0)
