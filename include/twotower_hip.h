@@ -96,6 +96,17 @@ int tt_embedding_gather_f32(const float* table, int64_t num_rows, int32_t dim,
 int tt_embedding_gather2_f32(const float* table_a, int64_t rows_a, const int64_t* ids_a, float* out_a,
                              const float* table_b, int64_t rows_b, const int64_t* ids_b, float* out_b,
                              int32_t dim, int64_t n_ids, int32_t* oob_flag, tt_stream_t stream);
+/* A further feature summed into a tower input (BASELINE configs[4]: the hashed category feature added to the
+ * item tower's input): out[p,:] += table[ids[p],:] (one f32 add per element; id -1 / out of range adds
+ * nothing, out of range sets the flag).  Its gradient rows are the tower-input gradient rows themselves.  */
+int tt_embedding_gather_add_f32(const float* table, int64_t num_rows, int32_t dim,
+                                const int64_t* ids, int64_t n_ids, float* out,
+                                int32_t* oob_flag, tt_stream_t stream);
+/* Hash feature ids: out[i] = FNV-1a-64(bytes of row i up to its first NUL) mod n_buckets, rows as for
+ * tt_encode_ids_u8 (zero-padded [n, width] u8).  The reference names no hash (SURVEY.md Appendix A "not
+ * specified anywhere"); this one is restated in oracle/hashing.py.                                          */
+int tt_hash_bucket_u8(const uint8_t* rows_u8, int64_t n, int32_t width, int64_t n_buckets,
+                      int64_t* out, tt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * a5 — sparse optimizer on embedding rows (Keras SGD / Adagrad on IndexedSlices,

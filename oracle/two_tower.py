@@ -243,12 +243,17 @@ class ModelState:
     item_tower: TowerParams
     user_accum: np.ndarray | None = None
     item_accum: np.ndarray | None = None
+    # hashed category feature summed into the item tower's input (BASELINE configs[4]); None = no such feature
+    cat_table: np.ndarray | None = None
+    cat_accum: np.ndarray | None = None
 
 
 def init_adagrad_state(state: ModelState, initial_accumulator_value=0.1):
     t = state.user_table.dtype.type
     state.user_accum = np.full_like(state.user_table, t(initial_accumulator_value))
     state.item_accum = np.full_like(state.item_table, t(initial_accumulator_value))
+    if state.cat_table is not None:
+        state.cat_accum = np.full_like(state.cat_table, t(initial_accumulator_value))
     for tw in (state.user_tower, state.item_tower):
         tw.w_accum = [np.full_like(w, t(initial_accumulator_value)) for w in tw.weights]
         tw.b_accum = [np.full_like(b, t(initial_accumulator_value)) for b in tw.biases]
@@ -256,11 +261,16 @@ def init_adagrad_state(state: ModelState, initial_accumulator_value=0.1):
 
 def forward_backward(state: ModelState, user_ids, item_ids, temperature=0.1,
                      l2=0.0, sample_weight=None, candidate_sampling_probability=None,
-                     candidate_ids=None, remove_accidental_hits=False, relu_masks=None, dropout=None):
+                     candidate_ids=None, remove_accidental_hits=False, relu_masks=None, dropout=None,
+                     category_ids=None):
     """One forward+backward.  total_loss = retrieval loss (SUM) + l2 * sum(W**2)
-    over Dense kernels (Keras ``kernel_regularizer=l2``; biases unregularised)."""
+    over Dense kernels (Keras ``kernel_regularizer=l2``; biases unregularised).
+    category_ids: bucket of every pair's hashed category; its embedding is ADDED to the item embedding
+    (one add, in the state's dtype), so ``die`` is the gradient of both lookups."""
     ue = embedding_gather(state.user_table, user_ids)
     ie = embedding_gather(state.item_table, item_ids)
+    if category_ids is not None:
+        ie = ie + embedding_gather(state.cat_table, category_ids)
     # dropout = (user_list, item_list, scale): per-tower lists of (keep, scale) per hidden layer
     ud, idr, dscale = (None, None, 1.0) if dropout is None else dropout
     ua = tower_fwd(ue, state.user_tower.weights, state.user_tower.biases, ud)
@@ -291,9 +301,12 @@ def train_step(state: ModelState, user_ids, item_ids, lr, optimizer="sgd",
                temperature=0.1, l2=0.0, eps=1e-7, **loss_kw):
     """In-place train step; returns forward_backward's dict."""
     r = forward_backward(state, user_ids, item_ids, temperature=temperature, l2=l2, **loss_kw)
+    cat = loss_kw.get("category_ids")
     if optimizer == "sgd":
         sparse_sgd(state.user_table, user_ids, r["due"], lr)
         sparse_sgd(state.item_table, item_ids, r["die"], lr)
+        if cat is not None:
+            sparse_sgd(state.cat_table, cat, r["die"], lr)
         for tw, dws, dbs in ((state.user_tower, r["udw"], r["udb"]),
                              (state.item_tower, r["idw"], r["idb"])):
             for l in range(len(tw.weights)):
@@ -302,6 +315,8 @@ def train_step(state: ModelState, user_ids, item_ids, lr, optimizer="sgd",
     elif optimizer == "adagrad":
         sparse_adagrad(state.user_table, state.user_accum, user_ids, r["due"], lr, eps)
         sparse_adagrad(state.item_table, state.item_accum, item_ids, r["die"], lr, eps)
+        if cat is not None:
+            sparse_adagrad(state.cat_table, state.cat_accum, cat, r["die"], lr, eps)
         for tw, dws, dbs in ((state.user_tower, r["udw"], r["udb"]),
                              (state.item_tower, r["idw"], r["idb"])):
             for l in range(len(tw.weights)):
@@ -313,7 +328,7 @@ def train_step(state: ModelState, user_ids, item_ids, lr, optimizer="sgd",
 
 
 def synthetic_state(seed, n_users, n_items, emb_dim, tower_dims, dtype=np.float64,
-                    optimizer="sgd", item_tower_dims=None) -> ModelState:
+                    optimizer="sgd", item_tower_dims=None, n_category_buckets=0) -> ModelState:
     """Deterministic init shared with the product's ``synthetic`` initialiser
     (oracle.synth tensor-id convention).  ``tower_dims`` = output dims of each
     Dense layer, e.g. [256, 128]; both towers share the shape."""
@@ -329,6 +344,8 @@ def synthetic_state(seed, n_users, n_items, emb_dim, tower_dims, dtype=np.float6
             fan_in = fan_out
         towers.append(TowerParams(ws, bs))
     st = ModelState(ut, it, towers[0], towers[1])
+    if n_category_buckets:
+        st.cat_table = synth.embedding_table(seed, synth.TID_CATEGORY_TABLE, n_category_buckets, emb_dim).astype(dtype)
     if optimizer == "adagrad":
         init_adagrad_state(st)
     return st

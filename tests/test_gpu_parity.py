@@ -76,6 +76,30 @@ def test_gather2_matches_two_gathers(dev):
     assert np.array_equal(oa.cpu().numpy(), ta[ia]) and np.array_equal(ob.cpu().numpy(), tb[ib])
 
 
+def test_gather_add_and_hash_buckets_bit_exact(dev):
+    """out += table[ids] (one f32 add per element) and the FNV-1a-64 bucket ids of category strings."""
+    from oracle import hashing
+    rows, d, n = 30, 256, 5000
+    table = synth.embedding_table(13, synth.TID_CATEGORY_TABLE, rows, d)
+    base = synth.uniform_f32(13, 9, n * d, -1.0, 2.0).reshape(n, d)
+    ids = synth.batch_ids(13, synth.TID_CATEGORY_IDS, 0, n, rows, "Z")
+    ids[3], ids[4] = -1, rows                       # padding adds nothing silently; out of range adds nothing + flag
+    out = T(base, dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.embedding_gather_add_(out, T(table, dev), T(ids, dev), flag)
+    ok = (ids >= 0) & (ids < rows)
+    ref = base.copy()
+    ref[ok] = base[ok] + table[ids[ok]]
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), ref.view(np.uint32)) and flag.item() == 1
+    cats = ["All_Beauty", "Books", "Electronics", "Home_and_Kitchen", "Unknown", "", "Tools_and_Home_Improvement",
+            "Caf\u00e9 & Th\u00e9", "\u5bb6\u7535", "x" * 40] * 37
+    for nb in (30, 1, 1 << 20):
+        got = ops.hash_buckets(ops.strings_to_padded_bytes(cats).to(dev), nb).cpu().numpy()
+        assert np.array_equal(got, hashing.hash_buckets(cats, nb))
+    assert hashing.fnv1a64(b"") == 0xCBF29CE484222325 and hashing.fnv1a64(b"a") == 0xAF63DC4C8601EC8C   # published FNV-1a vectors
+    assert hashing.fnv1a64(b"foobar") == 0x85944171F73967E8
+
+
 def test_ops_reject_cpu_tensors():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.embedding_gather(torch.zeros(4, 4), torch.zeros(2, dtype=torch.int64))

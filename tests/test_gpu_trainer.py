@@ -83,6 +83,57 @@ def test_train_steps_match_oracle(dev, name, shape, opt, variant):
         assert np.abs(tr.user_accum.cpu().numpy() - ref.user_accum).max() <= 1e-4 * ref.user_accum.max()
 
 
+@pytest.mark.parametrize("opt", ["sgd", "adagrad"])
+def test_hashed_category_feature_matches_oracle(dev, opt):
+    """BASELINE configs[4]: a 30-bucket hashed category table whose row is ADDED to the item embedding before the item
+    tower.  Three steps against the f64 oracle: loss, the shared input gradient, and the 30 rows after ~270
+    duplicate-gradient sums per row and step (sorted-slot pieces of 64 + the finish kernel)."""
+    n_users, n_items, dim, tower_dims, batch, nb, seed = 3000, 2000, 64, [128, 64], 1024, 30, 1005
+    cfg = TwoTowerConfig(n_users=n_users, n_items=n_items, embedding_dim=dim, tower_dims=tower_dims, temperature=0.1,
+                         l2_regularization=1e-6, learning_rate=0.001, optimizer=opt, batch_size=batch, n_category_buckets=nb)
+    tr = TwoTowerTrainer(cfg, dev, seed=seed)
+    ref = tt.synthetic_state(seed, n_users, n_items, dim, tower_dims, dtype=np.float64, optimizer=opt, n_category_buckets=nb)
+    assert np.array_equal(tr.cat_table.cpu().numpy(), ref.cat_table.astype(np.float32))
+    with pytest.raises(ValueError):
+        tr.step(*tr.synthetic_batch(seed, 0, "Z"))                     # the model has the feature: ids are required
+    for step in range(3):
+        du, di = tr.synthetic_batch(seed, step, "Z")
+        dc = tr.synthetic_categories(seed, step)
+        cid = synth.batch_ids(seed, synth.TID_CATEGORY_IDS, step, batch, nb, "Z")
+        assert np.array_equal(dc.cpu().numpy(), cid)
+        loss = tr.step(du, di, category_ids=dc).item()
+        masks = tuple([(t.acts[l + 1] > 0).cpu().numpy() for l in range(len(tower_dims) - 1)]
+                      for t in (tr.user_tower, tr.item_tower))
+        r = tt.train_step(ref, du.cpu().numpy(), di.cpu().numpy(), lr=0.001, optimizer=opt, temperature=0.1, l2=1e-6,
+                          relu_masks=masks, category_ids=cid)
+        tr.check_ids()
+        assert abs(loss - r["loss"]) / batch <= 1e-4 and abs(loss - r["loss"]) <= 1e-4 * abs(r["loss"]), (step, loss, r["loss"])
+        err = np.abs(tr.item_tower.demb.cpu().numpy() - r["die"]).max()
+        assert err <= 1e-4 * np.abs(r["die"]).max()
+    for got, want in ((tr.cat_table, ref.cat_table), (tr.item_table, ref.item_table), (tr.user_table, ref.user_table)):
+        assert np.abs(got.cpu().numpy() - want).max() <= 2e-6
+    assert (tr.cat_table.cpu().numpy() != synth.embedding_table(seed, synth.TID_CATEGORY_TABLE, nb, dim)).mean() > 0.9
+    if opt == "adagrad":
+        assert np.abs(tr.cat_accum.cpu().numpy() - ref.cat_accum).max() <= 1e-4 * ref.cat_accum.max()
+    # validation loss and the item corpus use the feature too
+    val = tr.evaluate(du, di, category_ids=dc).item()
+    rv = tt.forward_backward(ref, du.cpu().numpy(), di.cpu().numpy(), temperature=0.1, category_ids=cid)
+    assert abs(val - rv["loss"]) <= 1e-4 * abs(rv["loss"])
+    item_cat = torch.arange(n_items, device=dev) % nb
+    corpus = tr.item_corpus_embeddings(item_cat)
+    want = tt.tower_fwd(ref.item_table + ref.cat_table[item_cat.cpu().numpy()], ref.item_tower.weights, ref.item_tower.biases)[-1]
+    assert np.abs(corpus.cpu().numpy() - want).max() <= 1e-4 * np.abs(want).max()
+    # checkpoint round trip keeps the table; graph replay takes the ids
+    sd = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in tr.state_dict().items()}
+    tr2 = TwoTowerTrainer(TwoTowerConfig(**cfg.__dict__), dev, seed=seed + 1)
+    tr2.load_state_dict(sd)
+    assert torch.equal(tr2.cat_table, tr.cat_table)
+    l_eager = tr.step(du, di, category_ids=dc).clone()
+    tr2.capture_graph()
+    l_graph = tr2.step_graph(du, di, dc).clone()
+    assert torch.equal(l_eager, l_graph) and torch.equal(tr.cat_table, tr2.cat_table)
+
+
 def test_full_size_train_step_properties_cfg3(dev):
     """BASELINE configs[2] at full size (5M users x 10M items x 128, towers 256-128, batch 8192), properties that
     need no O(B^2) host work: only the batch's rows change, the first loss is ~ln(B) (near-uniform softmax at init),

@@ -61,6 +61,8 @@ SIGNATURES = {
     "tt_encode_ids_u8": (C.c_int, [_p, _i64, _i32, _p, _i64, _p, _p, _p]),
     "tt_embedding_gather_f32": (C.c_int, [_p, _i64, _i32, _p, _i64, _p, _p, _p]),
     "tt_embedding_gather2_f32": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _p, _p, _i32, _i64, _p, _p]),
+    "tt_embedding_gather_add_f32": (C.c_int, [_p, _i64, _i32, _p, _i64, _p, _p, _p]),
+    "tt_hash_bucket_u8": (C.c_int, [_p, _i64, _i32, _i64, _p, _p]),
     "tt_route_by_owner_i64": (C.c_int, [_p, _i64, _i32, _i64, _i32, _p, _p, _p, _p]),
     "tt_route_tables_by_owner_i64": (C.c_int, [_p, _i32, _i64, _i32, _i32, _p, _p, _p]),
     "tt_scatter_rows_f32": (C.c_int, [_p, _p, _i64, _i32, _p, _i64, _p]),

@@ -14,7 +14,8 @@ struct GatherArgs {
   int64_t rows[2];
 };
 
-template <int UNROLL>
+// ACC: out[p,:] += table[ids[p],:] (a further feature summed into a tower input: the hashed category of cfg5)
+template <int UNROLL, bool ACC>
 __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a, int dim4 /* dim/4 */, int lpr_log2,
                                                      int64_t n_ids, int32_t* __restrict__ oob_flag) {
   const int t = blockIdx.y;
@@ -45,14 +46,39 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a, int dim4 /* d
         }
       }
     }
+    if constexpr (ACC) {
+      tt::f32x4 o[UNROLL];
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u)
-      if (b[u] < n_ids) out[b[u] * dim4 + c] = v[u];
+      for (int u = 0; u < UNROLL; ++u)
+        if (b[u] < n_ids) o[u] = out[b[u] * dim4 + c];
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u)
+        if (b[u] < n_ids) out[b[u] * dim4 + c] = o[u] + v[u];      // one f32 add per element (oracle: a + b)
+    } else {
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u)
+        if (b[u] < n_ids) out[b[u] * dim4 + c] = v[u];
+    }
   }
 }
 
+// FNV-1a (64-bit) of the bytes of each zero-padded row up to its first NUL, reduced modulo n_buckets.
+__global__ __launch_bounds__(256) void hash_bucket_kernel(const uint8_t* __restrict__ rows, int64_t n, int width,
+                                                          uint64_t n_buckets, int64_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* r = rows + i * width;
+  uint64_t h = 0xCBF29CE484222325ull;
+  for (int k = 0; k < width; ++k) {
+    const uint8_t c = r[k];
+    if (c == 0) break;
+    h = (h ^ c) * 0x100000001B3ull;
+  }
+  out[i] = (int64_t)(h % n_buckets);
+}
+
 int launch(const GatherArgs& a, int n_tables, int32_t dim, int64_t n_ids, int32_t* oob_flag, hipStream_t stream,
-           const char* what) {
+           const char* what, bool accumulate = false) {
   if (n_ids == 0) return TT_OK;
   const int dim4 = dim / 4;
   int lpr_log2 = 0;
@@ -63,8 +89,12 @@ int launch(const GatherArgs& a, int n_tables, int32_t dim, int64_t n_ids, int32_
   const int64_t blocks = (n_ids + rows_per_block - 1) / rows_per_block;
   TT_REQUIRE(blocks <= 0x7fffffff, "%s: n_ids too large", what);
   tt::ProfScope prof("gather", stream);
-  hipLaunchKernelGGL(gather_kernel<UNROLL>, dim3((unsigned)blocks, n_tables), dim3(256), 0, stream, a, dim4, lpr_log2,
-                     n_ids, oob_flag);
+  if (accumulate)
+    hipLaunchKernelGGL((gather_kernel<UNROLL, true>), dim3((unsigned)blocks, n_tables), dim3(256), 0, stream, a, dim4, lpr_log2,
+                       n_ids, oob_flag);
+  else
+    hipLaunchKernelGGL((gather_kernel<UNROLL, false>), dim3((unsigned)blocks, n_tables), dim3(256), 0, stream, a, dim4, lpr_log2,
+                       n_ids, oob_flag);
   return tt::check_launch(what);
 }
 
@@ -94,4 +124,28 @@ extern "C" int tt_embedding_gather2_f32(const float* table_a, int64_t rows_a, co
   a.table[0] = table_a; a.ids[0] = ids_a; a.out[0] = out_a; a.rows[0] = rows_a;
   a.table[1] = table_b; a.ids[1] = ids_b; a.out[1] = out_b; a.rows[1] = rows_b;
   return launch(a, 2, dim, n_ids, oob_flag, tt::as_stream(stream), "tt_embedding_gather2_f32");
+}
+
+extern "C" int tt_embedding_gather_add_f32(const float* table, int64_t num_rows, int32_t dim, const int64_t* ids,
+                                           int64_t n_ids, float* out, int32_t* oob_flag, tt_stream_t stream) {
+  TT_REQUIRE(n_ids >= 0 && num_rows > 0, "tt_embedding_gather_add_f32: bad n_ids/num_rows");
+  TT_REQUIRE(dim > 0 && dim % 4 == 0, "tt_embedding_gather_add_f32: dim must be a positive multiple of 4 (got %d)", dim);
+  TT_REQUIRE(n_ids == 0 || (table && ids && out), "tt_embedding_gather_add_f32: null pointer");
+  TT_REQUIRE(tt::aligned16(table) && tt::aligned16(out), "tt_embedding_gather_add_f32: table/out must be 16-byte aligned");
+  GatherArgs a{};
+  a.table[0] = table; a.ids[0] = ids; a.out[0] = out; a.rows[0] = num_rows;
+  return launch(a, 1, dim, n_ids, oob_flag, tt::as_stream(stream), "tt_embedding_gather_add_f32", true);
+}
+
+extern "C" int tt_hash_bucket_u8(const uint8_t* rows, int64_t n, int32_t width, int64_t n_buckets, int64_t* out,
+                                 tt_stream_t stream_) {
+  TT_REQUIRE(n >= 0 && width > 0 && n_buckets > 0, "tt_hash_bucket_u8: need n >= 0, width > 0, n_buckets > 0");
+  if (n == 0) return TT_OK;
+  TT_REQUIRE(rows && out, "tt_hash_bucket_u8: null pointer");
+  const int64_t blocks = (n + 255) / 256;
+  TT_REQUIRE(blocks <= 0x7fffffff, "tt_hash_bucket_u8: n too large");
+  hipStream_t stream = tt::as_stream(stream_);
+  tt::ProfScope prof("hash_bucket", stream);
+  hipLaunchKernelGGL(hash_bucket_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, rows, n, width, (uint64_t)n_buckets, out);
+  return tt::check_launch("tt_hash_bucket_u8");
 }

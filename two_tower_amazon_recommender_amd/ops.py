@@ -132,6 +132,29 @@ def embedding_gather2(table_a, ids_a, out_a, table_b, ids_b, out_b, oob_flag=Non
     return out_a, out_b
 
 
+def embedding_gather_add_(out, table, ids, oob_flag=None):
+    """out[p, :] += table[ids[p], :] — a further feature summed into a tower input (hashed category, cfg5)."""
+    _chk(table, torch.float32, "table", 2)
+    _chk(ids, torch.int64, "ids", 1)
+    _chk(out, torch.float32, "out", 2)
+    if out.shape[0] != ids.numel() or out.shape[1] != table.shape[1]:
+        raise RuntimeError("embedding_gather_add_: out must be [n_ids, dim]")
+    lib = _lib.load()
+    _lib.check(lib.tt_embedding_gather_add_f32(_p(table), table.shape[0], table.shape[1], _p(ids), ids.numel(), _p(out),
+                                               _p(oob_flag), _stream()), "tt_embedding_gather_add_f32")
+    return out
+
+
+def hash_buckets(rows_u8: torch.Tensor, n_buckets: int) -> torch.Tensor:
+    """int64 bucket of every zero-padded byte row: FNV-1a-64 mod n_buckets (oracle/hashing.py)."""
+    _chk(rows_u8, torch.uint8, "rows_u8", 2)
+    n, width = rows_u8.shape
+    out = torch.empty(n, dtype=torch.int64, device=rows_u8.device)
+    lib = _lib.load()
+    _lib.check(lib.tt_hash_bucket_u8(_p(rows_u8), n, width, n_buckets, _p(out), _stream()), "tt_hash_bucket_u8")
+    return out
+
+
 # ----------------------------------------------------------------------------- sharded routing
 def route_by_owner(ids, world: int, num_rows: int, cap: int, send_ids, pos_flat, flags=None):
     _chk(ids, torch.int64, "ids", 1)

@@ -26,6 +26,7 @@ from . import ops
 # tensor-id convention of the synthetic initialiser (must match oracle/synth.py, which restates it
 # for the tests; the product does not import the oracle)
 TID_USER_TABLE, TID_ITEM_TABLE, TID_USER_IDS, TID_ITEM_IDS = 1, 2, 3, 4
+TID_CATEGORY_TABLE, TID_CATEGORY_IDS = 5, 6
 TID_DENSE_BASE = 16
 TID_DROPOUT_BASE = 64
 
@@ -45,6 +46,9 @@ class TwoTowerConfig:
     adagrad_epsilon: float = 1e-7                  # Keras 2.15 default
     batch_size: int = 1024                         # :62
     dropout_rate: float = 0.0                      # :58 is 0.1; parity/bench runs use 0
+    # BASELINE configs[4] "30 categories as hash features": a [n_category_buckets, embedding_dim] table whose row
+    # (bucket of the pair's hashed category) is ADDED to the item embedding before the item tower.  0 = no such feature.
+    n_category_buckets: int = 0
 
     @property
     def user_dims(self) -> list:
@@ -71,6 +75,8 @@ class TwoTowerConfig:
             raise ValueError("dropout_rate must be in [0, 1)")
         if self.temperature <= 0:
             raise ValueError("temperature must be positive")
+        if self.n_category_buckets < 0:
+            raise ValueError("n_category_buckets must be >= 0")
 
 
 class Tower:
@@ -211,6 +217,11 @@ class TwoTowerTrainer:
         self.oob = torch.zeros(1, dtype=torch.int32, device=dev)
         self.user_plan = ops.SparsePlan(b, dev)
         self.item_plan = ops.SparsePlan(b, dev)
+        self.cat_table = self.cat_accum = self.cat_plan = None
+        if cfg.n_category_buckets:
+            self.cat_table = torch.empty(cfg.n_category_buckets, d, device=dev)
+            self.cat_accum = torch.full_like(self.cat_table, cfg.adagrad_initial_accumulator) if adagrad else None
+            self.cat_plan = ops.SparsePlan(b, dev)
         self._side = torch.cuda.Stream(device=dev)
         self.step_index = 0                      # counter of the dropout stream (global batch row = step*batch + r)
         self.dropout_seed = 0 if seed is None else seed
@@ -224,6 +235,8 @@ class TwoTowerTrainer:
         generator: identical, bit for bit, to oracle.two_tower.synthetic_state(seed, ...)."""
         ops.fill_uniform_(self.user_table, seed, TID_USER_TABLE, -0.05, 0.1)
         ops.fill_uniform_(self.item_table, seed, TID_ITEM_TABLE, -0.05, 0.1)
+        if self.cat_table is not None:
+            ops.fill_uniform_(self.cat_table, seed, TID_CATEGORY_TABLE, -0.05, 0.1)
         self.dense_flat.zero_()
         for t, tower in enumerate((self.user_tower, self.item_tower)):
             for l, w in enumerate(tower.w):
@@ -232,8 +245,9 @@ class TwoTowerTrainer:
                 scale32 = (lim + lim).item()
                 ops.fill_uniform_(w, seed, TID_DENSE_BASE + 2 * l + t, -lim32, scale32)
         if self.cfg.optimizer == "adagrad":
-            for a in (self.user_accum, self.item_accum, self.dense_accum):
-                a.fill_(self.cfg.adagrad_initial_accumulator)
+            for a in (self.user_accum, self.item_accum, self.dense_accum, self.cat_accum):
+                if a is not None:
+                    a.fill_(self.cfg.adagrad_initial_accumulator)
 
     def synthetic_batch(self, seed: int, step: int, variant: str = "U", out=None):
         b = self.cfg.batch_size
@@ -243,11 +257,33 @@ class TwoTowerTrainer:
         ops.fill_ids_(out[1], seed, TID_ITEM_IDS, self.cfg.n_items, variant, start=step * b)
         return out
 
+    def synthetic_categories(self, seed: int, step: int, variant: str = "Z", out=None):
+        """Category bucket of every pair of synthetic step ``step`` (power-law by default: a few big categories)."""
+        b = self.cfg.batch_size
+        if out is None:
+            out = torch.empty(b, dtype=torch.int64, device=self.dev)
+        ops.fill_ids_(out, seed, TID_CATEGORY_IDS, self.cfg.n_category_buckets, variant, start=step * b)
+        return out
+
+    def _check_categories(self, category_ids):
+        if (category_ids is None) != (self.cat_table is None):
+            raise ValueError("category_ids must be given exactly when cfg.n_category_buckets > 0")
+        if category_ids is not None and category_ids.numel() != self.cfg.batch_size:
+            raise ValueError(f"category_ids must have {self.cfg.batch_size} entries")
+
+    def _item_inputs(self, user_ids, item_ids, category_ids):
+        """K1: both towers' input rows; the hashed category's row is summed into the item tower's input."""
+        ut, it = self.user_tower, self.item_tower
+        ops.embedding_gather2(self.user_table, user_ids, ut.acts[0], self.item_table, item_ids, it.acts[0], self.oob)
+        if category_ids is not None:
+            ops.embedding_gather_add_(it.acts[0], self.cat_table, category_ids, self.oob)
+
     # ------------------------------------------------------------------ the hot path
     def forward_backward(self, user_ids: torch.Tensor, item_ids: torch.Tensor, sample_weight=None,
-                         candidate_sampling_probability=None, candidate_ids=None):
+                         candidate_sampling_probability=None, candidate_ids=None, category_ids=None):
         cfg, ut, it = self.cfg, self.user_tower, self.item_tower
-        ops.embedding_gather2(self.user_table, user_ids, ut.acts[0], self.item_table, item_ids, it.acts[0], self.oob)
+        self._check_categories(category_ids)
+        self._item_inputs(user_ids, item_ids, category_ids)
         row0 = self.step_index * cfg.batch_size
         if cfg.symmetric:        # same shapes: every layer of both towers in one launch
             q, c = towers_forward(ut, it, (cfg.dropout_rate, self.dropout_seed, row0))
@@ -272,6 +308,12 @@ class TwoTowerTrainer:
         ops.sparse_update2_(cfg.optimizer, self.user_table, self.user_accum, self.user_tower.demb, self.user_plan,
                             self.item_table, self.item_accum, self.item_tower.demb, self.item_plan,
                             cfg.learning_rate, cfg.adagrad_epsilon)
+        if self.cat_table is not None:       # the category row's gradient is the item-tower input gradient itself
+            if cfg.optimizer == "sgd":
+                ops.sparse_sgd_(self.cat_table, self.item_tower.demb, self.cat_plan, cfg.learning_rate)
+            else:
+                ops.sparse_adagrad_(self.cat_table, self.cat_accum, self.item_tower.demb, self.cat_plan, cfg.learning_rate,
+                                    cfg.adagrad_epsilon)
 
     def step(self, user_ids: torch.Tensor, item_ids: torch.Tensor, **loss_kw) -> torch.Tensor:
         """One train step; returns the (device, unsynchronised) retrieval loss (SUM over the batch)."""
@@ -283,6 +325,8 @@ class TwoTowerTrainer:
         with torch.cuda.stream(self._side):
             self.user_plan.run(user_ids, self.cfg.n_users)
             self.item_plan.run(item_ids, self.cfg.n_items)
+            if loss_kw.get("category_ids") is not None and self.cat_plan is not None:
+                self.cat_plan.run(loss_kw["category_ids"], self.cfg.n_category_buckets)
         loss = self.forward_backward(user_ids, item_ids, **loss_kw)
         main.wait_stream(self._side)
         self.apply_gradients()
@@ -291,7 +335,8 @@ class TwoTowerTrainer:
     def evaluate(self, user_ids: torch.Tensor, item_ids: torch.Tensor, **loss_kw) -> torch.Tensor:
         """Forward only (validation loss, SUM over the batch); device tensor, unsynchronised."""
         cfg, ut, it = self.cfg, self.user_tower, self.item_tower
-        ops.embedding_gather2(self.user_table, user_ids, ut.acts[0], self.item_table, item_ids, it.acts[0], self.oob)
+        self._check_categories(loss_kw.get("category_ids"))
+        self._item_inputs(user_ids, item_ids, loss_kw.get("category_ids"))
         q, c = towers_forward(ut, it) if cfg.symmetric else (ut.forward(), it.forward())
         kw = dict(sample_weight=loss_kw.get("sample_weight"), cand_prob=loss_kw.get("candidate_sampling_probability"),
                   cand_ids=loss_kw.get("candidate_ids"))
@@ -299,14 +344,19 @@ class TwoTowerTrainer:
 
     # ------------------------------------------------------------------ retrieval metrics
     @torch.no_grad()
-    def item_corpus_embeddings(self) -> torch.Tensor:
-        """Item-tower output for EVERY item row ([n_items, scorer_dim]), computed batch by batch on the tower's buffers."""
+    def item_corpus_embeddings(self, item_category_ids: torch.Tensor | None = None) -> torch.Tensor:
+        """Item-tower output for EVERY item row ([n_items, scorer_dim]), computed batch by batch on the tower's buffers.
+        item_category_ids [n_items]: the category bucket of every item (required iff the model has the feature)."""
         it, b = self.item_tower, self.cfg.batch_size
         n = self.cfg.n_items
+        if (item_category_ids is None) != (self.cat_table is None):
+            raise ValueError("item_category_ids must be given exactly when cfg.n_category_buckets > 0")
         out = torch.empty(n, it.dims[-1], device=self.dev)
         for s in range(0, n, b):
             e = min(s + b, n)
             it.acts[0][:e - s].copy_(self.item_table[s:e])
+            if item_category_ids is not None:
+                ops.embedding_gather_add_(it.acts[0][:e - s], self.cat_table, item_category_ids[s:e], self.oob)
             it.forward()
             out[s:e].copy_(it.acts[-1][:e - s])
         return out
@@ -326,15 +376,23 @@ class TwoTowerTrainer:
     def state_dict(self) -> dict:
         sd = {"config": dict(self.cfg.__dict__), "user_table": self.user_table, "item_table": self.item_table,
               "dense": self.dense_flat}
+        if self.cat_table is not None:
+            sd["cat_table"] = self.cat_table
         if self.cfg.optimizer == "adagrad":
             sd.update(user_accum=self.user_accum, item_accum=self.item_accum, dense_accum=self.dense_accum)
+            if self.cat_table is not None:
+                sd["cat_accum"] = self.cat_accum
         return sd
 
     def load_state_dict(self, sd: dict):
-        for k in ("n_users", "n_items", "embedding_dim", "tower_dims", "item_tower_dims", "optimizer"):
-            if sd["config"][k] != getattr(self.cfg, k):
+        for k in ("n_users", "n_items", "embedding_dim", "tower_dims", "item_tower_dims", "optimizer", "n_category_buckets"):
+            if sd["config"].get(k, 0 if k == "n_category_buckets" else None) != getattr(self.cfg, k):
                 raise ValueError(f"checkpoint {k}={sd['config'][k]!r} does not match the trainer's {getattr(self.cfg, k)!r}")
         self.user_table.copy_(sd["user_table"]); self.item_table.copy_(sd["item_table"]); self.dense_flat.copy_(sd["dense"])
+        if self.cat_table is not None:
+            self.cat_table.copy_(sd["cat_table"])
+            if self.cfg.optimizer == "adagrad":
+                self.cat_accum.copy_(sd["cat_accum"])
         if self.cfg.optimizer == "adagrad":
             self.user_accum.copy_(sd["user_accum"]); self.item_accum.copy_(sd["item_accum"])
             self.dense_accum.copy_(sd["dense_accum"])
@@ -348,6 +406,11 @@ class TwoTowerTrainer:
         b = self.cfg.batch_size
         self._g_uid = torch.zeros(b, dtype=torch.int64, device=self.dev)
         self._g_iid = torch.zeros(b, dtype=torch.int64, device=self.dev)
+        self._g_kw = {}
+        if self.cat_table is not None:
+            self._g_kw["category_ids"] = torch.zeros(b, dtype=torch.int64, device=self.dev)
+        cat_state = None if self.cat_table is None else \
+            [self.cat_table[:1].clone(), None if self.cat_accum is None else self.cat_accum[:1].clone()]
         state = [t.clone() for t in (self.user_table[:1], self.item_table[:1], self.dense_flat)]
         acc = None
         if self.cfg.optimizer == "adagrad":
@@ -355,22 +418,29 @@ class TwoTowerTrainer:
         s = torch.cuda.Stream(device=self.dev)
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            self.step(self._g_uid, self._g_iid)          # warm-up on the capture stream (ids 0: touches row 0 only)
+            self.step(self._g_uid, self._g_iid, **self._g_kw)   # warm-up on the capture stream (ids 0: touches row 0 only)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
-            self.step(self._g_uid, self._g_iid)
+            self.step(self._g_uid, self._g_iid, **self._g_kw)
         torch.cuda.synchronize()
         # undo the warm-up step's update (row 0 of both tables, dense parameters)
         self.user_table[:1].copy_(state[0]); self.item_table[:1].copy_(state[1]); self.dense_flat.copy_(state[2])
         if acc is not None:
             self.user_accum[:1].copy_(acc[0]); self.item_accum[:1].copy_(acc[1]); self.dense_accum.copy_(acc[2])
+        if cat_state is not None:
+            self.cat_table[:1].copy_(cat_state[0])
+            if cat_state[1] is not None:
+                self.cat_accum[:1].copy_(cat_state[1])
         return self
 
-    def step_graph(self, user_ids: torch.Tensor, item_ids: torch.Tensor) -> torch.Tensor:
+    def step_graph(self, user_ids: torch.Tensor, item_ids: torch.Tensor, category_ids: torch.Tensor | None = None) -> torch.Tensor:
+        self._check_categories(category_ids)
         self._g_uid.copy_(user_ids, non_blocking=True)
         self._g_iid.copy_(item_ids, non_blocking=True)
+        if category_ids is not None:
+            self._g_kw["category_ids"].copy_(category_ids, non_blocking=True)
         self._graph.replay()
         return self.loss
 
