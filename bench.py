@@ -35,6 +35,7 @@ CONFIGS = {
     "cfg4": (5_000_000, 100_000_000, 128, [256, 128], 16384),
     "cfg5": (54_000_000, 48_000_000, 256, [512, 256], 32768),
 }
+CATEGORY_BUCKETS = {"cfg5": 30}     # BASELINE configs[4]: "30 categories as hash features" (summed into the item tower input)
 MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32-input MFMA dense peak
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
 
@@ -122,21 +123,30 @@ def main():
     seed = 1000 + int(args.config[3:])
     cfg = TwoTowerConfig(n_users=n_users, n_items=n_items, embedding_dim=dim, tower_dims=tower_dims,
                          temperature=0.1, l2_regularization=1e-6, learning_rate=0.001,
-                         optimizer=args.optimizer, batch_size=batch)
+                         optimizer=args.optimizer, batch_size=batch,
+                         n_category_buckets=CATEGORY_BUCKETS.get(args.config, 0))
     trainer = TwoTowerTrainer(cfg, dev, seed=seed)
     total = args.warmup + args.steps
     uids = torch.empty(total, batch, dtype=torch.int64, device=dev)
     iids = torch.empty(total, batch, dtype=torch.int64, device=dev)
+    cids = torch.empty(total, batch, dtype=torch.int64, device=dev) if cfg.n_category_buckets else None
     for s in range(total):
         trainer.synthetic_batch(seed, s, args.ids, out=(uids[s], iids[s]))
+        if cids is not None:
+            trainer.synthetic_categories(seed, s, out=cids[s])
     torch.cuda.synchronize()
 
-    step = trainer.step
     if args.graph:
         trainer.capture_graph()
-        step = trainer.step_graph
+
+    def step(s):
+        if args.graph:
+            return trainer.step_graph(uids[s], iids[s], None if cids is None else cids[s])
+        if cids is None:
+            return trainer.step(uids[s], iids[s])
+        return trainer.step(uids[s], iids[s], category_ids=cids[s])
     for s in range(args.warmup):
-        step(uids[s], iids[s])
+        step(s)
     torch.cuda.synchronize()
     trainer.check_ids()
 
@@ -145,7 +155,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for s in range(args.warmup, total):
-        step(uids[s], iids[s])
+        step(s)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof = {t: _lib.profile_read(t, 2 * args.steps + 8)[0] for t in tags.split(",")}
@@ -181,7 +191,12 @@ def main():
         dominant["score_fwd_bwd_frac"] = dominant["score_fwd_bwd_algorithmic_tflops"] / MFMA_F32_PEAK_TFLOPS
     # gather + scatter (HBM): algorithmic bytes per step: gather 16BD+16B, SGD 24BD, Adagrad 40BD
     gs_bytes = 16 * batch * dim + 16 * batch + (24 if args.optimizer == "sgd" else 40) * batch * dim
-    t_gs = max((mean(prof["gather"]) + mean(prof["sparse_apply"])) * 1e-3, 1e-12)
+    if cfg.n_category_buckets:         # +8BD per extra hashed feature: its rows summed into the item input
+        gs_bytes += 8 * batch * dim
+
+    def per_step(tag):                 # ms per STEP (a step may launch a tagged kernel more than once)
+        return sum(prof[tag]) / args.steps
+    t_gs = max((per_step("gather") + per_step("sparse_apply")) * 1e-3, 1e-12)
     out = {
         "metric": "user-item pairs/sec (train step) + embedding-gather HBM GB/s, 1/2/4/8 MI355X",
         "value": batch / (dt / args.steps), "unit": "pairs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -189,7 +204,9 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.config}: {n_users} users x {n_items} items, emb_dim {dim}, towers "
                                f"{dim}->{'->'.join(map(str, tower_dims))}, batch {batch}, in-batch sampled softmax T=0.1, "
-                               f"{args.optimizer} lr 1e-3, ids {args.ids}",
+                               f"{args.optimizer} lr 1e-3, ids {args.ids}"
+                               + (f", + {cfg.n_category_buckets}-bucket hashed category feature summed into the item input"
+                                  if cfg.n_category_buckets else ""),
                    "global_batch": batch, "parallelism": "single GPU"},
         "roofline": dominant,
         "roofline_hbm": {"bound": "hbm", "kernel": "gather2 + sparse_update2 (K1 + K2 apply; both tables; hipEvent brackets add "
@@ -198,11 +215,11 @@ def main():
                          "frac": gs_bytes / t_gs / 1e9 / HBM_PEAK_GBS,
                          "traffic": ((pmc_traffic("gather") or 0) + (pmc_traffic("sparse_apply") or 0)) or None
                          if (args.config == "cfg3" and args.optimizer == "sgd") else None,
-                         "gather_us": mean(prof["gather"]) * 1e3, "sparse_apply_us": mean(prof["sparse_apply"]) * 1e3,
+                         "gather_us": per_step("gather") * 1e3, "sparse_apply_us": per_step("sparse_apply") * 1e3,
                          "sparse_plan_us_each_side_stream": mean(prof["sparse_plan"]) * 1e3, "algorithmic_bytes": gs_bytes},
         "loss_per_pair": loss / batch,
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and not cfg.n_category_buckets:     # the torch-CPU port covers the cfg1-cfg4 model
         out["cpu_baseline"] = cpu_baseline(trainer, cfg, seed, args, batch)
     print(json.dumps(out))
 

@@ -69,7 +69,7 @@ def _install_host_bounce():
     dist.all_gather_into_tensor, dist.reduce_scatter_tensor = ag, rs
 
 
-def _worker(rank, world, port, opt, variant, negatives, ret):
+def _worker(rank, world, port, opt, variant, negatives, nb, ret):
     sys.path.insert(0, str(ROOT))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -81,9 +81,13 @@ def _worker(rank, world, port, opt, variant, negatives, ret):
         dev = torch.device("cuda:0")
         n_users, n_items, dim, tower_dims, b, seed = 3001, 2000, 64, [128, 64], 1024, 41
         cfg = TwoTowerConfig(n_users=n_users, n_items=n_items, embedding_dim=dim, tower_dims=tower_dims, temperature=0.1,
-                             l2_regularization=1e-6, learning_rate=0.001, optimizer=opt, batch_size=b)
+                             l2_regularization=1e-6, learning_rate=0.001, optimizer=opt, batch_size=b, n_category_buckets=nb)
         tr = ShardedTwoTowerTrainer(cfg, dev, seed=seed, negatives=negatives, capacity_factor=3.0)
-        ref = tt.synthetic_state(seed, n_users, n_items, dim, tower_dims, dtype=np.float64, optimizer=opt)
+        ref = tt.synthetic_state(seed, n_users, n_items, dim, tower_dims, dtype=np.float64, optimizer=opt,
+                                 n_category_buckets=nb)
+
+        def cats(step, r):          # category buckets of rank r's sub-batch (None when the model has no such feature)
+            return synth.batch_ids(seed, synth.TID_CATEGORY_IDS, step * world + r, b, nb, "Z") if nb else None
         # each rank holds exactly its rows of the synthetic tables
         assert np.array_equal(tr.user_table.cpu().numpy(),
                               ref.user_table[rank::world].astype(np.float32))
@@ -91,7 +95,10 @@ def _worker(rank, world, port, opt, variant, negatives, ret):
         for step in range(2):
             u, i = batches[step]
             # step 0 hands step 1's ids over: their routing and id exchange are issued in the middle of step 0
-            loss = tr.step(u, i, next_ids=batches[1] if step == 0 else None).item()
+            dc = tr.synthetic_categories(seed, step) if nb else None
+            if nb:
+                assert np.array_equal(dc.cpu().numpy(), cats(step, rank))
+            loss = tr.step(u, i, next_ids=batches[1] if step == 0 else None, category_ids=dc).item()
             assert (tr.emb._cur == 1) == (step == 1)
             tr.check_ids()
             # oracle: forward/backward of EVERY rank's sub-batch on the shared state, then one update with all gradients
@@ -104,10 +111,11 @@ def _worker(rank, world, port, opt, variant, negatives, ret):
                 allm = [None] * world
                 dist.all_gather_object(allm, masks)
                 gm = tuple([np.concatenate([allm[r][t][l] for r in range(world)]) for l in range(len(tower_dims) - 1)] for t in (0, 1))
-                fb = tt.forward_backward(ref, ids_u, ids_i, temperature=0.1, l2=0.0, relu_masks=gm)
+                ids_c = np.concatenate([cats(step, r) for r in range(world)]) if nb else None
+                fb = tt.forward_backward(ref, ids_u, ids_i, temperature=0.1, l2=0.0, relu_masks=gm, category_ids=ids_c)
                 mine = fb["per_row"][rank * b:(rank + 1) * b].sum()
                 assert abs(loss - mine) <= 1e-4 * abs(mine), (loss, mine)
-                subs.append((ids_u, ids_i, fb))
+                subs.append((ids_u, ids_i, fb, ids_c))
             for r in range(world if negatives == "local" else 0):
                 ids_u = synth.batch_ids(seed, synth.TID_USER_IDS, step * world + r, b, n_users, variant)
                 ids_i = synth.batch_ids(seed, synth.TID_ITEM_IDS, step * world + r, b, n_items, variant)
@@ -117,17 +125,24 @@ def _worker(rank, world, port, opt, variant, negatives, ret):
                                   for t in (tr.user_tower, tr.item_tower))
                 allm = [None] * world
                 dist.all_gather_object(allm, masks if r == rank else None)
-                fb = tt.forward_backward(ref, ids_u, ids_i, temperature=0.1, l2=0.0, relu_masks=allm[r])
+                fb = tt.forward_backward(ref, ids_u, ids_i, temperature=0.1, l2=0.0, relu_masks=allm[r], category_ids=cats(step, r))
                 if r == rank:
                     assert abs(loss - fb["loss"]) <= 1e-4 * abs(fb["loss"]), (loss, fb["loss"])
-                subs.append((ids_u, ids_i, fb))
+                subs.append((ids_u, ids_i, fb, cats(step, r)))
             gu = np.concatenate([s[2]["due"] for s in subs]); iu = np.concatenate([s[0] for s in subs])
             gi = np.concatenate([s[2]["die"] for s in subs]); ii = np.concatenate([s[1] for s in subs])
+            ic = np.concatenate([s[3] for s in subs]) if nb else None
             if opt == "sgd":
                 tt.sparse_sgd(ref.user_table, iu, gu, 0.001); tt.sparse_sgd(ref.item_table, ii, gi, 0.001)
+                if nb:
+                    tt.sparse_sgd(ref.cat_table, ic, gi, 0.001)
             else:
                 tt.sparse_adagrad(ref.user_table, ref.user_accum, iu, gu, 0.001)
                 tt.sparse_adagrad(ref.item_table, ref.item_accum, ii, gi, 0.001)
+                if nb:
+                    tt.sparse_adagrad(ref.cat_table, ref.cat_accum, ic, gi, 0.001)
+            if nb:       # replicated table: every rank holds all rows (summed with the dense all-reduce)
+                assert np.abs(tr.cat_table.cpu().numpy() - ref.cat_table).max() <= 3e-6
             for tw, kw_, kb_ in ((ref.user_tower, "udw", "udb"), (ref.item_tower, "idw", "idb")):
                 for l in range(len(tw.weights)):
                     gw = sum(s[2][kw_][l] for s in subs) + 2e-6 * tw.weights[l]
@@ -157,12 +172,13 @@ def _worker(rank, world, port, opt, variant, negatives, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("opt,variant,negatives", [("sgd", "U", "local"), ("adagrad", "Z", "local"), ("sgd", "Z", "global")])
-def test_sharded_trainer_two_ranks_on_one_gpu(opt, variant, negatives):
+@pytest.mark.parametrize("opt,variant,negatives,nb", [("sgd", "U", "local", 0), ("adagrad", "Z", "local", 30),
+                                                      ("sgd", "Z", "global", 30)])
+def test_sharded_trainer_two_ranks_on_one_gpu(opt, variant, negatives, nb):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(2, _free_port(), opt, variant, negatives, ret), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), opt, variant, negatives, nb, ret), nprocs=2, join=True)
     for r in range(2):
         assert ret.get(r) == "ok", f"rank {r}: {ret.get(r)}"

@@ -250,6 +250,38 @@ def test_train_cli_synthetic_runs_and_learns(dev, tmp_path):
     assert sd["user_table"].shape == (2000, 32)
 
 
+def test_train_cli_parquet_with_hashed_category_column(dev, tmp_path):
+    """train-model on a parquet shaped like prepare_training_data.py:216-218's output, with its `category` column
+    hashed into 30 buckets on the GPU and fed to the item tower (BASELINE configs[4])."""
+    import pandas as pd
+    from oracle import hashing
+    from two_tower_amazon_recommender_amd import data as datamod, train
+    rng = np.random.default_rng(1)
+    n, cats = 6000, ["All_Beauty", "Books", "Electronics", "Home_and_Kitchen", "Toys_and_Games", None]
+    df = pd.DataFrame({"user_idx": rng.integers(0, 800, n), "item_idx": rng.integers(0, 600, n),
+                       "category": [cats[k] for k in rng.integers(0, len(cats), n)], "rating": 5.0})
+    df.loc[0, ["user_idx", "item_idx"]] = [799, 599]
+    p = tmp_path / "combined_interactions.parquet"
+    df.to_parquet(p, compression="snappy", index=False)
+    codes, values = datamod.read_category_values(p)
+    got = datamod.category_buckets(codes, values, 30, dev)
+    want = hashing.hash_buckets(["Unknown" if c is None else c for c in df["category"]], 30)
+    assert np.array_equal(got, want)                                 # GPU hash == oracle, row by row
+    cfgp = tmp_path / "cfg.yaml"
+    cfgp.write_text("model:\n  embedding_dim: 32\n  user_tower_dims: [32]\n  item_tower_dims: [32]\n"
+                    "  dropout_rate: 0.0\n  l2_regularization: 1e-6\n  training:\n    batch_size: 256\n    learning_rate: 0.05\n"
+                    "    epochs: 2\n    patience: 5\n    validation_freq: 1\n  retrieval:\n    candidate_sampling: in_batch\n"
+                    "    temperature: 0.1\n    top_k_eval: [1, 10]\n")
+    ck = tmp_path / "ck.pt"
+    assert train.main(["--config", str(cfgp), "--data", str(p), "--category-buckets", "30", "--save", str(ck)]) == 0
+    sd = torch.load(ck, weights_only=True)
+    assert sd["cat_table"].shape == (30, 32) and sd["config"]["n_category_buckets"] == 30
+    touched = np.unique(want)
+    init = synth.embedding_table(42, synth.TID_CATEGORY_TABLE, 30, 32)
+    moved = np.flatnonzero((sd["cat_table"].cpu().numpy() != init).any(axis=1))
+    assert set(moved) == set(touched.tolist())                       # exactly the buckets that occur were trained
+
+
 def test_evaluate_topk_against_item_corpus(dev):
     from two_tower_amazon_recommender_amd.metrics import FactorizedTopK
     cfg, tr, ref = make(dev, 3000, 2500, 64, [64], 512, "adagrad", 13)
@@ -285,10 +317,22 @@ def test_two_tower_model_facade(dev):
     assert val["loss"].item() > 0
     with pytest.raises(KeyError):
         m.train_step({"user": u, "item": i})
+    # with the hashed category feature: raw strings (hashed on the GPU) or ready bucket ids
+    from oracle import hashing
+    cfg2 = TwoTowerConfig(n_users=500, n_items=400, embedding_dim=32, tower_dims=[32], batch_size=128, optimizer="sgd",
+                          n_category_buckets=30)
+    a, b = TwoTowerModel(cfg2, dev, seed=3), TwoTowerModel(TwoTowerConfig(**cfg2.__dict__), dev, seed=3)
+    cats = [("Books", "Electronics", "All_Beauty")[k % 3] for k in range(128)]
+    la = a.train_step({"user_idx": u, "item_idx": i, "category": cats})["loss"]
+    lb = b.train_step({"user_idx": u, "item_idx": i,
+                       "category_bucket": torch.from_numpy(hashing.hash_buckets(cats, 30)).to(dev)})["loss"]
+    assert torch.equal(la, lb) and torch.equal(a.trainer.cat_table, b.trainer.cat_table)
+    with pytest.raises(KeyError):
+        a.train_step({"user_idx": u, "item_idx": i})
 
 
-@pytest.mark.parametrize("negatives", ["local", "global"])
-def test_sharded_trainer_one_rank_rccl_collectives(dev, negatives):
+@pytest.mark.parametrize("negatives,nb", [("local", 0), ("global", 0), ("local", 30)])
+def test_sharded_trainer_one_rank_rccl_collectives(dev, negatives, nb):
     """The N>1 code path with its collectives really issued — asynchronous all_to_all_single (ids int64, rows f32,
     gradient rows), the dense all-reduce, and for negatives="global" all_gather_into_tensor + reduce_scatter_tensor —
     on a one-rank "nccl" (= RCCL) group, which is all one GPU allows.  Everything must equal the plain trainer bit for
@@ -300,20 +344,27 @@ def test_sharded_trainer_one_rank_rccl_collectives(dev, negatives):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ["MASTER_PORT"] = "29578"
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
-        cfg, tr, _ = make(dev, 5000, 3000, 64, [128, 64], 1024, "adagrad", 37)
+        cfg = TwoTowerConfig(n_users=5000, n_items=3000, embedding_dim=64, tower_dims=[128, 64], temperature=0.1,
+                             l2_regularization=1e-6, learning_rate=0.001, optimizer="adagrad", batch_size=1024,
+                             n_category_buckets=nb)
+        tr = TwoTowerTrainer(cfg, dev, seed=37)
         sh = ShardedTwoTowerTrainer(TwoTowerConfig(**cfg.__dict__), dev, seed=37, negatives=negatives, force_collectives=True)
         assert sh.collectives and sh.emb.recv_ids.data_ptr() != sh.emb.send_ids.data_ptr()
         batches = [tr.synthetic_batch(37, step, "Z") for step in range(4)]
         for step in range(4):
             u, i = batches[step]
-            l1 = tr.step(u, i).clone()
+            kw = {"category_ids": tr.synthetic_categories(37, step)} if nb else {}
+            l1 = tr.step(u, i, **kw).clone()
             # steps 0-1 hand the next step's ids over (route + id all-to-all run beside the scorer), step 2 does not
-            l2 = sh.step(u, i, next_ids=batches[step + 1] if step < 2 else None).clone()
+            l2 = sh.step(u, i, next_ids=batches[step + 1] if step < 2 else None, **kw).clone()
             assert torch.equal(l1, l2)
         sh.check_ids()
         assert torch.equal(sh.user_table, tr.user_table) and torch.equal(sh.item_table, tr.item_table)
-        assert torch.equal(sh.dense_flat, tr.dense_flat)
+        n_dense = tr.dense_flat.numel()
+        assert torch.equal(sh.dense_flat[:n_dense], tr.dense_flat)
         assert torch.equal(sh.emb.accum_shard(0), tr.user_accum)
+        if nb:      # replicated table, gradient through the all-reduce bucket + dense update == the sparse update, bit for bit
+            assert torch.equal(sh.cat_table, tr.cat_table) and torch.equal(sh.cat_accum, tr.cat_accum)
     finally:
         dist.destroy_process_group()
 

@@ -52,6 +52,30 @@ def test_parquet_reader_accepts_both_reference_encodings(tmp_path):
         datamod.read_interactions(tmp_path / "bad.parquet")
 
 
+def test_category_column_reader_and_batch_triples(tmp_path):
+    """The hashed-category input: `category` strings (prepare_training_data.py:47), nulls -> "Unknown"
+    (preprocessor.py:480), integer `category_encoded` by its decimal text; the iterator yields triples."""
+    df = pd.DataFrame({"user_idx": np.arange(6), "item_idx": np.arange(6)[::-1].copy(),
+                       "category": ["Books", "Electronics", None, "Books", "All_Beauty", "Electronics"]})
+    p = tmp_path / "c.parquet"
+    df.to_parquet(p, index=False)
+    codes, values = datamod.read_category_values(p)
+    assert [values[c] for c in codes] == ["Books", "Electronics", "Unknown", "Books", "All_Beauty", "Electronics"]
+    df2 = df.drop(columns=["category"]).assign(category_encoded=np.array([3, 1, 3, 0, 1, 1]))
+    p2 = tmp_path / "e.parquet"
+    df2.to_parquet(p2, index=False)
+    codes2, values2 = datamod.read_category_values(p2)
+    assert [values2[c] for c in codes2] == ["3", "1", "3", "0", "1", "1"]
+    df.drop(columns=["category"]).to_parquet(tmp_path / "n.parquet", index=False)
+    assert datamod.read_category_values(tmp_path / "n.parquet") is None
+    it = datamod.BatchIterator(df.user_idx.to_numpy(), df.item_idx.to_numpy(), 2, "cpu", shuffle=True,
+                               category_bucket=np.array([7, 8, 9, 7, 5, 8]))
+    seen = [(int(u), int(c)) for b in it for u, c in zip(b[0], b[2])]
+    assert sorted(seen) == [(0, 7), (1, 8), (2, 9), (3, 7), (4, 5), (5, 8)]        # the triple stays aligned under shuffling
+    with pytest.raises(ValueError):
+        datamod.BatchIterator(np.arange(4), np.arange(4), 2, "cpu", category_bucket=np.arange(3))
+
+
 def test_retrieval_task_argument_errors_mirror_tfrs():
     with pytest.raises(ValueError):
         Retrieval(num_hard_negatives=0)

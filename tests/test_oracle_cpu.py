@@ -204,3 +204,37 @@ def test_train_step_decreases_loss_cfg1_shape():
         l1 = tt.train_step(st, uid, iid, lr=0.001, optimizer="sgd")["loss"]
     assert l1 < l0
     assert abs(l0 / 256 - np.log(256)) < 0.2       # near-uniform softmax at init
+
+
+def test_hash_buckets_known_answers_and_range():
+    """FNV-1a-64 published test vectors (the draft's "", "a", "foobar") pin the restated hash; buckets are in range."""
+    from oracle import hashing
+    assert hashing.fnv1a64(b"") == 0xCBF29CE484222325
+    assert hashing.fnv1a64(b"a") == 0xAF63DC4C8601EC8C
+    assert hashing.fnv1a64(b"foobar") == 0x85944171F73967E8
+    cats = ["All_Beauty", "Books", "Electronics", "Unknown", "Caf\u00e9"]
+    b = hashing.hash_buckets(cats, 30)
+    assert b.dtype == np.int64 and ((b >= 0) & (b < 30)).all()
+    assert np.array_equal(b, hashing.hash_buckets(cats, 30))
+
+
+def test_category_feature_gradient_is_the_item_input_gradient():
+    """ie = item_row + category_row: d loss / d category_row summed over the pairs of a bucket, checked by finite
+    differences on the f64 oracle; the train step moves exactly the touched buckets."""
+    st = tt.synthetic_state(7, 50, 40, 8, [8], dtype=np.float64, n_category_buckets=5)
+    rng = np.random.default_rng(0)
+    u, i, c = rng.integers(0, 50, 16), rng.integers(0, 40, 16), rng.integers(0, 4, 16)      # bucket 4 untouched
+    r = tt.forward_backward(st, u, i, temperature=0.5, category_ids=c)
+    uniq, g = tt.dedup_sum(c, r["die"])
+    eps = 1e-6
+    for bucket, col in ((int(uniq[0]), 3), (int(uniq[-1]), 0)):
+        st.cat_table[bucket, col] += eps
+        lp = tt.forward_backward(st, u, i, temperature=0.5, category_ids=c)["loss"]
+        st.cat_table[bucket, col] -= 2 * eps
+        lm = tt.forward_backward(st, u, i, temperature=0.5, category_ids=c)["loss"]
+        st.cat_table[bucket, col] += eps
+        assert abs((lp - lm) / (2 * eps) - g[list(uniq).index(bucket), col]) < 1e-6
+    before = st.cat_table.copy()
+    tt.train_step(st, u, i, lr=0.1, optimizer="sgd", temperature=0.5, category_ids=c)
+    changed = np.flatnonzero((st.cat_table != before).any(axis=1))
+    assert set(changed) == set(uniq.tolist()) and 4 not in changed

@@ -9,6 +9,9 @@ import numpy as np
 import torch
 
 ID_COLUMNS = (("user_idx", "item_idx"), ("user_id_encoded", "item_id_encoded"))
+# the pair's category: `category` (prepare_training_data.py:47), `main_category` / `category_encoded`
+# (preprocessor.py:478-489).  It feeds the hashed category feature (BASELINE configs[4]).
+CATEGORY_COLUMNS = ("category", "main_category", "category_encoded")
 
 
 def read_interactions(path) -> tuple[np.ndarray, np.ndarray]:
@@ -25,15 +28,48 @@ def read_interactions(path) -> tuple[np.ndarray, np.ndarray]:
     raise KeyError(f"{path}: none of the id column pairs {ID_COLUMNS} found (columns: {names})")
 
 
+def read_category_values(path):
+    """(codes int64 [n_rows], distinct values as str) of the first category column present, or None.
+    Integer columns are taken by their decimal representation; nulls become "Unknown" (preprocessor.py:480)."""
+    import pyarrow as pa
+    import pyarrow.compute as pc
+    import pyarrow.parquet as pq
+    names = pq.read_schema(path).names
+    for col in CATEGORY_COLUMNS:
+        if col in names:
+            arr = pq.read_table(path, columns=[col]).column(col).combine_chunks()
+            if not pa.types.is_string(arr.type) and not pa.types.is_large_string(arr.type):
+                arr = pc.cast(arr, pa.string())
+            arr = pc.fill_null(arr, "Unknown")
+            enc = pc.dictionary_encode(arr)
+            if isinstance(enc, pa.ChunkedArray):
+                enc = enc.combine_chunks()
+            return enc.indices.to_numpy().astype(np.int64, copy=False), [str(v) for v in enc.dictionary.to_pylist()]
+    return None
+
+
+def category_buckets(codes: np.ndarray, values: list, n_buckets: int, device) -> np.ndarray:
+    """Bucket of every row: the DISTINCT strings (a few dozen) are hashed on the GPU (tt_hash_bucket_u8), rows take
+    their value's bucket."""
+    from . import ops
+    b = ops.hash_buckets(ops.strings_to_padded_bytes(values).to(device), n_buckets).cpu().numpy()
+    return b[codes]
+
+
 class BatchIterator:
     """Shuffled fixed-size batches of (user_idx, item_idx), resident on the device; the last partial batch
     of an epoch is dropped (the kernels' buffers are sized for one batch size)."""
 
-    def __init__(self, user_idx: np.ndarray, item_idx: np.ndarray, batch_size: int, device, seed: int = 42, shuffle=True):
+    def __init__(self, user_idx: np.ndarray, item_idx: np.ndarray, batch_size: int, device, seed: int = 42, shuffle=True,
+                 category_bucket: np.ndarray | None = None):
         if len(user_idx) != len(item_idx):
             raise ValueError("user_idx and item_idx differ in length")
+        if category_bucket is not None and len(category_bucket) != len(user_idx):
+            raise ValueError("category_bucket and user_idx differ in length")
         self.u = torch.from_numpy(np.ascontiguousarray(user_idx)).to(device)
         self.i = torch.from_numpy(np.ascontiguousarray(item_idx)).to(device)
+        # with a category column the iterator yields (user, item, category bucket) triples
+        self.c = None if category_bucket is None else torch.from_numpy(np.ascontiguousarray(category_bucket)).to(device)
         self.batch_size, self.shuffle = batch_size, shuffle
         self.gen = torch.Generator(device="cpu").manual_seed(seed)
         self.n_batches = len(user_idx) // batch_size
@@ -43,11 +79,14 @@ class BatchIterator:
 
     def __iter__(self):
         n = self.u.numel()
+        c = self.c
         if self.shuffle:
             perm = torch.randperm(n, generator=self.gen).to(self.u.device)
             u, i = self.u[perm], self.i[perm]
+            c = None if c is None else c[perm]
         else:
             u, i = self.u, self.i
         b = self.batch_size
         for k in range(self.n_batches):
-            yield u[k * b:(k + 1) * b], i[k * b:(k + 1) * b]
+            sl = slice(k * b, (k + 1) * b)
+            yield (u[sl], i[sl]) if c is None else (u[sl], i[sl], c[sl])

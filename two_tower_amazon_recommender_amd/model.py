@@ -13,6 +13,9 @@ from .trainer import TwoTowerConfig, TwoTowerTrainer
 
 USER_KEYS = ("user_idx", "user_id_encoded")      # prepare_training_data.py:209 / preprocessor.py:481
 ITEM_KEYS = ("item_idx", "item_id_encoded")      # :210 / :482
+# hashed category feature (cfg.n_category_buckets > 0): int64 bucket ids under "category_bucket", or the raw
+# category strings (a list of str) under "category" / "main_category", hashed on the GPU
+CATEGORY_KEYS = ("category", "main_category")
 
 
 def _pick(features: dict, keys):
@@ -30,6 +33,13 @@ class TwoTowerModel:
     def compute_loss(self, features: dict, training: bool = False) -> torch.Tensor:
         u, i = _pick(features, USER_KEYS), _pick(features, ITEM_KEYS)
         kw = {k: features[k] for k in ("sample_weight", "candidate_sampling_probability", "candidate_ids") if k in features}
+        if self.cfg.n_category_buckets:
+            if "category_bucket" in features:
+                kw["category_ids"] = features["category_bucket"]
+            else:
+                from . import ops
+                rows = ops.strings_to_padded_bytes(list(_pick(features, CATEGORY_KEYS))).to(self.trainer.dev)
+                kw["category_ids"] = ops.hash_buckets(rows, self.cfg.n_category_buckets)
         if training:
             return self.trainer.step(u, i, **kw)
         return self.trainer.evaluate(u, i, **kw)

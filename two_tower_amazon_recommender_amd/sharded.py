@@ -268,7 +268,10 @@ class ShardedTwoTowerTrainer:
                          total loss = sum over ranks.
     negatives="global" — candidates (and their ids) are all-gathered, every query sees world*batch candidates
                          (identical to the single-device loss on the global batch), dC is reduce-scattered.
-    Dense tower gradients are summed with one all-reduce of a flat ~0.5 MB bucket.
+    Dense tower gradients are summed with one all-reduce of a flat ~0.5 MB bucket.  The hashed category table
+    (cfg.n_category_buckets rows; BASELINE configs[4]) is tiny, so it is REPLICATED like the dense parameters: every
+    rank de-duplicates its own gradient rows into a [buckets, dim] matrix at the tail of that bucket, the all-reduce
+    sums it, and the dense update applies it (rows no rank touched get a zero gradient: unchanged).
     """
 
     def __init__(self, cfg, device, group=None, seed: int | None = None, negatives: str = "local",
@@ -294,11 +297,19 @@ class ShardedTwoTowerTrainer:
             self.emb.accum = torch.full_like(self.emb.table, cfg.adagrad_initial_accumulator)
         n_tower = Tower.param_count(cfg, cfg.user_dims)
         n_item = Tower.param_count(cfg, cfg.item_dims)
-        self.dense_flat = torch.zeros(n_tower + n_item, device=dev)
+        n_cat = cfg.n_category_buckets * d
+        self.dense_flat = torch.zeros(n_tower + n_item + n_cat, device=dev)
         self.dense_accum = torch.full_like(self.dense_flat, cfg.adagrad_initial_accumulator) if adagrad else None
         self.dense_grad = torch.empty_like(self.dense_flat)
         self.user_tower = Tower(cfg, cfg.user_dims, self.dense_flat, self.dense_accum, 0, dev)
         self.item_tower = Tower(cfg, cfg.item_dims, self.dense_flat, self.dense_accum, n_tower, dev)
+        self.cat_table = self.cat_accum = self.cat_grad = self.cat_plan = None
+        if n_cat:
+            nb = cfg.n_category_buckets
+            self.cat_table = self.dense_flat[n_tower + n_item:].view(nb, d)
+            self.cat_grad = self.dense_grad[n_tower + n_item:].view(nb, d)
+            self.cat_accum = self.dense_accum[n_tower + n_item:].view(nb, d) if adagrad else None
+            self.cat_plan = ops.SparsePlan(b, dev)
         # the towers' inputs / input gradients are the two halves of one buffer: one expand gather, one scatter
         self.emb_in = torch.empty(2 * b, d, device=dev)
         self.emb_grad = torch.empty(2 * b, d, device=dev)
@@ -315,6 +326,8 @@ class ShardedTwoTowerTrainer:
                 for p, acc, reg in ((tower.w[l], tower.w_acc[l], l2), (tower.b[l], tower.b_acc[l], 0.0)):
                     self._segs_apply.append(ops.make_dense_seg(p, acc, self.dense_grad[off:off + p.numel()], 1, reg))
                     off += p.numel()
+        if n_cat:
+            self._segs_apply.append(ops.make_dense_seg(self.cat_table, self.cat_accum, self.cat_grad, 1, 0.0))
         sd = cfg.tower_dims[-1]
         nc = b * w if negatives == "global" else b
         self.ws = torch.empty(ops.retrieval_workspace_bytes(b, nc, sd), dtype=torch.uint8, device=dev)
@@ -332,7 +345,7 @@ class ShardedTwoTowerTrainer:
     def init_synthetic(self, seed: int):
         """Same values as the single-GPU trainer / oracle.synthetic_state: each rank fills only its rows."""
         import math
-        from .trainer import TID_USER_TABLE, TID_ITEM_TABLE, TID_DENSE_BASE
+        from .trainer import TID_USER_TABLE, TID_ITEM_TABLE, TID_DENSE_BASE, TID_CATEGORY_TABLE
         ops, w, r = self.ops, self.world, self.rank
         for t, tid in enumerate((TID_USER_TABLE, TID_ITEM_TABLE)):
             shard = self.emb.shard(t)
@@ -343,6 +356,8 @@ class ShardedTwoTowerTrainer:
             for l, wt in enumerate(tower.w):
                 lim = torch.tensor(math.sqrt(6.0 / (wt.shape[0] + wt.shape[1])), dtype=torch.float64).to(torch.float32)
                 ops.fill_uniform_(wt, seed, TID_DENSE_BASE + 2 * l + t, -lim.item(), (lim + lim).item())
+        if self.cat_table is not None:
+            ops.fill_uniform_(self.cat_table, seed, TID_CATEGORY_TABLE, -0.05, 0.1)
 
     def synthetic_batch(self, seed: int, step: int, variant: str = "U", out=None):
         """This rank's slice of the global synthetic batch of step ``step`` (global batch = world * batch)."""
@@ -355,16 +370,35 @@ class ShardedTwoTowerTrainer:
         self.ops.fill_ids_(out[1], seed, TID_ITEM_IDS, self.cfg.n_items, variant, start=start)
         return out
 
-    def step(self, user_ids: torch.Tensor, item_ids: torch.Tensor, next_ids=None) -> torch.Tensor:
+    def synthetic_categories(self, seed: int, step: int, variant: str = "Z", out=None):
+        """This rank's slice of the category buckets of global synthetic step ``step``."""
+        from .trainer import TID_CATEGORY_IDS
+        b = self.cfg.batch_size
+        if out is None:
+            out = torch.empty(b, dtype=torch.int64, device=self.dev)
+        self.ops.fill_ids_(out, seed, TID_CATEGORY_IDS, self.cfg.n_category_buckets, variant,
+                           start=(step * self.world + self.rank) * b)
+        return out
+
+    def step(self, user_ids: torch.Tensor, item_ids: torch.Tensor, next_ids=None, category_ids=None) -> torch.Tensor:
         """One train step on this rank's batch; returns this rank's (device, unsynchronised) loss.
         next_ids = (user_ids, item_ids) of the following step, if the input pipeline already has them: their
         routing and id all-to-all then run beside this step's scorer (pass the same tensors to the next call)."""
         from .trainer import towers_forward, towers_backward
         cfg, ops, ut, it, em = self.cfg, self.ops, self.user_tower, self.item_tower, self.emb
         b, w = cfg.batch_size, self.world
+        if (category_ids is None) != (self.cat_table is None):
+            raise ValueError("category_ids must be given exactly when cfg.n_category_buckets > 0")
         em.lookup_start((user_ids, item_ids))
         em.lookup_rows()
+        if category_ids is not None:          # the replicated table's sort plan joins the owner plan on the side stream
+            side = em.backend._side
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self.cat_plan.run(category_ids, cfg.n_category_buckets)
         em.lookup_finish(self.emb_in)
+        if category_ids is not None:
+            ops.embedding_gather_add_(it.acts[0], self.cat_table, category_ids, em.flags[0:1])
         if next_ids is not None:
             em.lookup_prefetch(next_ids)
         row0 = (self.step_index * w + self.rank) * b          # first global batch row of this rank
@@ -386,6 +420,11 @@ class ShardedTwoTowerTrainer:
         # every dx first: the embedding gradient rows travel to their owners beside the dw GEMMs and the dense reduce
         def send():
             em.grads_start(self.emb_grad)
+            if category_ids is not None and self.collectives:
+                # this rank's de-duplicated category gradient rows: 0 - (-1 * g_sum) = g_sum exactly
+                torch.cuda.current_stream().wait_stream(em.backend._side)
+                self.cat_grad.zero_()
+                ops.sparse_sgd_(self.cat_grad, it.demb, self.cat_plan, -1.0)
         if cfg.symmetric:
             towers_backward(ut, it, cfg.dropout_rate, on_embedding_grads=send)
         else:
@@ -398,6 +437,12 @@ class ShardedTwoTowerTrainer:
         if not self.collectives:
             ops.dense_update_(self._segs_reduce, cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon, apply=True)
             em.grads_finish(cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon)
+            if category_ids is not None:      # one rank, no collectives: the plain trainer's sparse update
+                if cfg.optimizer == "sgd":
+                    ops.sparse_sgd_(self.cat_table, it.demb, self.cat_plan, cfg.learning_rate)
+                else:
+                    ops.sparse_adagrad_(self.cat_table, self.cat_accum, it.demb, self.cat_plan, cfg.learning_rate,
+                                        cfg.adagrad_epsilon)
         else:
             ops.dense_update_(self._segs_reduce, cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon, apply=False)
             ar = dist.all_reduce(self.dense_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)   # C6

@@ -31,6 +31,9 @@ def parse(argv=None):
     ap.add_argument("--synthetic-users", type=int, default=10_000)
     ap.add_argument("--synthetic-items", type=int, default=10_000)
     ap.add_argument("--optimizer", default="adagrad", choices=["sgd", "adagrad"])
+    ap.add_argument("--category-buckets", type=int, default=0, metavar="N",
+                    help="add the hashed category feature: the pair's category (column category / main_category / "
+                         "category_encoded) hashed into N buckets, its embedding summed into the item tower input")
     ap.add_argument("--epochs", type=int, default=None, help="override model.training.epochs")
     ap.add_argument("--batch-size", type=int, default=None, help="override model.training.batch_size")
     ap.add_argument("--val-fraction", type=float, default=0.1)
@@ -53,10 +56,22 @@ def main(argv=None) -> int:
         ops.fill_ids_(i, args.seed, 4, args.synthetic_items, "Z")
         user_idx, item_idx = u.cpu().numpy(), i.cpu().numpy()
         n_users, n_items = args.synthetic_users, args.synthetic_items
+        cat = None
+        if args.category_buckets:
+            c = torch.empty(args.synthetic, dtype=torch.int64, device=dev)
+            ops.fill_ids_(c, args.seed, 6, args.category_buckets, "Z")
+            cat = c.cpu().numpy()
     else:
         user_idx, item_idx = datamod.read_interactions(args.data)
         n_users, n_items = int(user_idx.max()) + 1, int(item_idx.max()) + 1
+        cat = None
+        if args.category_buckets:
+            cv = datamod.read_category_values(args.data)
+            if cv is None:
+                raise SystemExit(f"--category-buckets: {args.data} has none of the columns {datamod.CATEGORY_COLUMNS}")
+            cat = datamod.category_buckets(cv[0], cv[1], args.category_buckets, torch.device(args.device))
     cfg, loop = cfgmod.model_config_from_dict(doc, n_users, n_items, optimizer=args.optimizer)
+    cfg.n_category_buckets = args.category_buckets
     if args.batch_size:
         cfg.batch_size = args.batch_size
     epochs = args.epochs if args.epochs is not None else loop["epochs"]
@@ -70,14 +85,19 @@ def main(argv=None) -> int:
     log.info("users %d items %d interactions %d (train %d, val %d); batch %d; optimizer %s", n_users, n_items, n,
              len(tr_idx), len(va_idx), cfg.batch_size, cfg.optimizer)
     trainer = TwoTowerTrainer(cfg, args.device, seed=args.seed)
-    train_it = datamod.BatchIterator(user_idx[tr_idx], item_idx[tr_idx], cfg.batch_size, trainer.dev, args.seed)
-    val_it = datamod.BatchIterator(user_idx[va_idx], item_idx[va_idx], cfg.batch_size, trainer.dev, args.seed, shuffle=False)
+    train_it = datamod.BatchIterator(user_idx[tr_idx], item_idx[tr_idx], cfg.batch_size, trainer.dev, args.seed,
+                                     category_bucket=None if cat is None else cat[tr_idx])
+    val_it = datamod.BatchIterator(user_idx[va_idx], item_idx[va_idx], cfg.batch_size, trainer.dev, args.seed, shuffle=False,
+                                   category_bucket=None if cat is None else cat[va_idx])
+
+    def kw(batch):
+        return {"category_ids": batch[2]} if len(batch) == 3 else {}
     best, bad, history = float("inf"), 0, []
     for epoch in range(epochs):
         t0 = time.perf_counter()
         tot = torch.zeros((), device=trainer.dev, dtype=torch.float64)
-        for u, i in train_it:
-            tot += trainer.step(u, i).double().squeeze()
+        for batch in train_it:
+            tot += trainer.step(batch[0], batch[1], **kw(batch)).double().squeeze()
         torch.cuda.synchronize()
         trainer.check_ids()
         dt = time.perf_counter() - t0
@@ -85,8 +105,8 @@ def main(argv=None) -> int:
                "pairs_per_sec": len(train_it) * cfg.batch_size / dt}
         if len(val_it) and (epoch + 1) % loop["validation_freq"] == 0:
             vt = torch.zeros((), device=trainer.dev, dtype=torch.float64)
-            for u, i in val_it:
-                vt += trainer.evaluate(u, i).double().squeeze()
+            for batch in val_it:
+                vt += trainer.evaluate(batch[0], batch[1], **kw(batch)).double().squeeze()
             rec["val_loss_per_pair"] = vt.item() / (len(val_it) * cfg.batch_size)
             if rec["val_loss_per_pair"] < best - 1e-6:
                 best, bad = rec["val_loss_per_pair"], 0
