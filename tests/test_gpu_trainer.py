@@ -365,6 +365,21 @@ def test_sharded_trainer_one_rank_rccl_collectives(dev, negatives, nb):
         assert torch.equal(sh.emb.accum_shard(0), tr.user_accum)
         if nb:      # replicated table, gradient through the all-reduce bucket + dense update == the sparse update, bit for bit
             assert torch.equal(sh.cat_table, tr.cat_table) and torch.equal(sh.cat_accum, tr.cat_accum)
+        # checkpoint of this rank's shard: save -> fresh trainer -> load -> the next step is bit-identical
+        import io
+        buf = io.BytesIO()
+        torch.save(sh.state_dict(), buf)
+        buf.seek(0)
+        sh2 = ShardedTwoTowerTrainer(TwoTowerConfig(**cfg.__dict__), dev, seed=99, negatives=negatives, force_collectives=True)
+        sh2.load_state_dict(torch.load(buf, weights_only=True))
+        u, i = tr.synthetic_batch(37, 7, "Z")
+        kw = {"category_ids": tr.synthetic_categories(37, 7)} if nb else {}
+        la, lb = sh.step(u, i, **kw).clone(), sh2.step(u, i, **kw).clone()
+        assert torch.equal(la, lb) and torch.equal(sh.emb.table, sh2.emb.table) and torch.equal(sh.dense_flat, sh2.dense_flat)
+        bad = sh.state_dict()
+        bad["world"] = 8
+        with pytest.raises(ValueError):
+            sh2.load_state_dict(bad)
     finally:
         dist.destroy_process_group()
 

@@ -460,5 +460,31 @@ class ShardedTwoTowerTrainer:
     def item_table(self) -> torch.Tensor:
         return self.emb.shard(1)
 
+    # ------------------------------------------------------------------ checkpoint
+    def state_dict(self) -> dict:
+        """THIS RANK's part of the checkpoint: its rows of both tables (global rows rank, rank+world, ...), their
+        Adagrad accumulators, and the replicated dense parameters (+ category table).  One file per rank; plain
+        tensors, so ``torch.load(..., weights_only=True)`` reads it back."""
+        sd = {"config": dict(self.cfg.__dict__), "world": self.world, "rank": self.rank, "negatives": self.negatives,
+              "step_index": self.step_index, "user_shard": self.emb.shard(0), "item_shard": self.emb.shard(1),
+              "dense": self.dense_flat}
+        if self.cfg.optimizer == "adagrad":
+            sd.update(user_accum=self.emb.accum_shard(0), item_accum=self.emb.accum_shard(1), dense_accum=self.dense_accum)
+        return sd
+
+    def load_state_dict(self, sd: dict):
+        for k in ("n_users", "n_items", "embedding_dim", "tower_dims", "item_tower_dims", "optimizer", "n_category_buckets"):
+            if sd["config"].get(k, 0 if k == "n_category_buckets" else None) != getattr(self.cfg, k):
+                raise ValueError(f"checkpoint {k}={sd['config'].get(k)!r} does not match the trainer's {getattr(self.cfg, k)!r}")
+        if (sd["world"], sd["rank"]) != (self.world, self.rank):
+            raise ValueError(f"checkpoint shard is rank {sd['rank']} of {sd['world']}, this is rank {self.rank} of {self.world} "
+                             "(row placement is id % world: re-shard through the single-GPU layout to change the world size)")
+        self.emb.shard(0).copy_(sd["user_shard"]); self.emb.shard(1).copy_(sd["item_shard"])
+        self.dense_flat.copy_(sd["dense"])
+        if self.cfg.optimizer == "adagrad":
+            self.emb.accum_shard(0).copy_(sd["user_accum"]); self.emb.accum_shard(1).copy_(sd["item_accum"])
+            self.dense_accum.copy_(sd["dense_accum"])
+        self.step_index = int(sd.get("step_index", 0))
+
     def check_ids(self):
         self.emb.check()
