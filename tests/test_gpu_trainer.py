@@ -243,9 +243,21 @@ def test_train_cli_synthetic_runs_and_learns(dev, tmp_path):
                     "    epochs: 3\n    patience: 5\n    validation_freq: 1\n  retrieval:\n    candidate_sampling: in_batch\n"
                     "    temperature: 0.1\n    top_k_eval: [1, 10]\n")
     ck = tmp_path / "ck.pt"
-    rc = train.main(["--config", str(cfgp), "--synthetic", "40000", "--synthetic-users", "2000", "--synthetic-items", "1500",
-                     "--save", str(ck)])
+    import contextlib, io, json
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        rc = train.main(["--config", str(cfgp), "--synthetic", "40000", "--synthetic-users", "2000", "--synthetic-items", "1500",
+                         "--save", str(ck)])
     assert rc == 0 and ck.exists()
+    res = json.loads(out.getvalue().strip().splitlines()[-1])
+    hist = res["history"]
+    assert hist[-1]["train_loss_per_pair"] < hist[0]["train_loss_per_pair"]
+    # top_k_eval of the YAML (configs/data_config.yaml:71): recall/ndcg of the held-out pairs against the whole corpus
+    vm = res["val_metrics"]
+    assert set(vm) == {"recall@1", "ndcg@1", "recall@10", "ndcg@10"}
+    assert 0.0 <= vm["recall@1"] <= vm["recall@10"] <= 1.0 and vm["ndcg@10"] <= vm["recall@10"] + 1e-12
+    # (no "better than random" bar: the synthetic pairs are drawn independently, and uncorrected in-batch negatives
+    # push popular items DOWN — the known bias candidate_sampling_probability exists to remove)
     sd = torch.load(ck, weights_only=True)
     assert sd["user_table"].shape == (2000, 32)
 
@@ -273,7 +285,11 @@ def test_train_cli_parquet_with_hashed_category_column(dev, tmp_path):
                     "    epochs: 2\n    patience: 5\n    validation_freq: 1\n  retrieval:\n    candidate_sampling: in_batch\n"
                     "    temperature: 0.1\n    top_k_eval: [1, 10]\n")
     ck = tmp_path / "ck.pt"
-    assert train.main(["--config", str(cfgp), "--data", str(p), "--category-buckets", "30", "--save", str(ck)]) == 0
+    import contextlib, io, json
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        assert train.main(["--config", str(cfgp), "--data", str(p), "--category-buckets", "30", "--save", str(ck)]) == 0
+    assert "recall@10" in json.loads(out.getvalue().strip().splitlines()[-1])["val_metrics"]   # corpus built with item categories
     sd = torch.load(ck, weights_only=True)
     assert sd["cat_table"].shape == (30, 32) and sd["config"]["n_category_buckets"] == 30
     touched = np.unique(want)

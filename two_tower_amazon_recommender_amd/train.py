@@ -117,10 +117,26 @@ def main(argv=None) -> int:
         if bad >= loop["patience"]:                      # early stopping (configs/data_config.yaml:65)
             log.info("early stop: no validation improvement for %d evaluations", bad)
             break
+    final = {"history": history}
+    if loop["top_k_eval"] and len(val_it):
+        # retrieval quality on the held-out pairs against the WHOLE item corpus (configs/data_config.yaml:71 top_k_eval)
+        from .metrics import FactorizedTopK
+        metric = FactorizedTopK(ks=tuple(loop["top_k_eval"]), temperature=cfg.temperature)
+        item_cat = None
+        if cat is not None:             # an item's category = the bucket of its first interaction (items never seen: bucket 0)
+            item_cat_np = np.zeros(n_items, dtype=np.int64)
+            first = np.unique(item_idx, return_index=True)
+            item_cat_np[first[0]] = cat[first[1]]
+            item_cat = torch.from_numpy(item_cat_np).to(trainer.dev)
+        corpus = trainer.item_corpus_embeddings(item_cat)
+        for batch in val_it:
+            trainer.evaluate_topk(batch[0], batch[1], metric, corpus)
+        final["val_metrics"] = {k: float(v) for k, v in metric.result().items()}
+        log.info(json.dumps(final["val_metrics"]))
     if args.save:
         torch.save(trainer.state_dict(), args.save)
         log.info("saved checkpoint to %s", args.save)
-    print(json.dumps({"history": history}))
+    print(json.dumps(final))
     return 0
 
 
