@@ -257,7 +257,14 @@ def test_train_cli_synthetic_runs_and_learns(dev, tmp_path):
     assert set(vm) == {"recall@1", "ndcg@1", "recall@10", "ndcg@10"}
     assert 0.0 <= vm["recall@1"] <= vm["recall@10"] <= 1.0 and vm["ndcg@10"] <= vm["recall@10"] + 1e-12
     # (no "better than random" bar: the synthetic pairs are drawn independently, and uncorrected in-batch negatives
-    # push popular items DOWN — the known bias candidate_sampling_probability exists to remove)
+    # push popular items DOWN — the known bias candidate_sampling_probability exists to remove; with the correction
+    # the model can at least learn popularity, so recall@10 must improve on the uncorrected run)
+    out2 = io.StringIO()
+    with contextlib.redirect_stdout(out2):
+        assert train.main(["--config", str(cfgp), "--synthetic", "40000", "--synthetic-users", "2000", "--synthetic-items", "1500",
+                           "--correct-sampling-bias"]) == 0
+    vm2 = json.loads(out2.getvalue().strip().splitlines()[-1])["val_metrics"]
+    assert vm2["recall@10"] > vm["recall@10"]
     sd = torch.load(ck, weights_only=True)
     assert sd["user_table"].shape == (2000, 32)
 

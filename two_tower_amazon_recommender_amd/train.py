@@ -34,6 +34,9 @@ def parse(argv=None):
     ap.add_argument("--category-buckets", type=int, default=0, metavar="N",
                     help="add the hashed category feature: the pair's category (column category / main_category / "
                          "category_encoded) hashed into N buckets, its embedding summed into the item tower input")
+    ap.add_argument("--correct-sampling-bias", action="store_true",
+                    help="pass every candidate's empirical frequency as candidate_sampling_probability (the logQ correction "
+                         "of tfrs.tasks.Retrieval): in-batch negatives otherwise push popular items down")
     ap.add_argument("--epochs", type=int, default=None, help="override model.training.epochs")
     ap.add_argument("--batch-size", type=int, default=None, help="override model.training.batch_size")
     ap.add_argument("--val-fraction", type=float, default=0.1)
@@ -90,8 +93,16 @@ def main(argv=None) -> int:
     val_it = datamod.BatchIterator(user_idx[va_idx], item_idx[va_idx], cfg.batch_size, trainer.dev, args.seed, shuffle=False,
                                    category_bucket=None if cat is None else cat[va_idx])
 
+    item_prob = None
+    if args.correct_sampling_bias:          # P(item j is drawn as an in-batch candidate) = its share of the training pairs
+        counts = np.bincount(item_idx[tr_idx], minlength=n_items).astype(np.float64)
+        item_prob = torch.from_numpy((counts / counts.sum()).astype(np.float32)).to(trainer.dev)
+
     def kw(batch):
-        return {"category_ids": batch[2]} if len(batch) == 3 else {}
+        k = {"category_ids": batch[2]} if len(batch) == 3 else {}
+        if item_prob is not None:
+            k["candidate_sampling_probability"] = item_prob[batch[1]]
+        return k
     best, bad, history = float("inf"), 0, []
     for epoch in range(epochs):
         t0 = time.perf_counter()
