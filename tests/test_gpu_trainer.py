@@ -269,6 +269,34 @@ def test_train_cli_synthetic_runs_and_learns(dev, tmp_path):
     assert sd["user_table"].shape == (2000, 32)
 
 
+def test_train_cli_distributed_one_rank_equals_single_gpu(dev, tmp_path):
+    """`train-model --distributed` (the torchrun path: row-sharded trainer, RCCL group, per-rank data slice, all-reduced
+    losses and metric tallies, per-rank checkpoint) with ONE rank reproduces the single-GPU run's numbers exactly."""
+    import contextlib, io, json
+    import torch.distributed as dist
+    from two_tower_amazon_recommender_amd import train
+    assert not dist.is_initialized()
+    cfgp = tmp_path / "cfg.yaml"
+    cfgp.write_text("model:\n  embedding_dim: 32\n  user_tower_dims: [64, 32]\n  item_tower_dims: [64, 32]\n"
+                    "  dropout_rate: 0.1\n  l2_regularization: 1e-6\n  training:\n    batch_size: 512\n    learning_rate: 0.05\n"
+                    "    epochs: 2\n    patience: 5\n    validation_freq: 1\n  retrieval:\n    candidate_sampling: in_batch\n"
+                    "    temperature: 0.1\n    top_k_eval: [1, 10, 100]\n")
+    common = ["--config", str(cfgp), "--synthetic", "30000", "--synthetic-users", "2000", "--synthetic-items", "1500",
+              "--category-buckets", "30", "--correct-sampling-bias"]
+    outs = []
+    for extra in ([], ["--distributed", "--save", str(tmp_path / "ck.pt")]):
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            assert train.main(common + extra) == 0
+        outs.append(json.loads(buf.getvalue().strip().splitlines()[-1]))
+    assert not dist.is_initialized()
+    for a, b in zip(outs[0]["history"], outs[1]["history"]):
+        assert a["train_loss_per_pair"] == b["train_loss_per_pair"] and a["val_loss_per_pair"] == b["val_loss_per_pair"]
+    assert outs[0]["val_metrics"] == outs[1]["val_metrics"]
+    sd = torch.load(tmp_path / "ck.pt.rank0of1", weights_only=True)
+    assert sd["user_shard"].shape == (2000, 32) and sd["world"] == 1
+
+
 def test_train_cli_parquet_with_hashed_category_column(dev, tmp_path):
     """train-model on a parquet shaped like prepare_training_data.py:216-218's output, with its `category` column
     hashed into 30 buckets on the GPU and fed to the item tower (BASELINE configs[4])."""

@@ -380,7 +380,17 @@ class ShardedTwoTowerTrainer:
                            start=(step * self.world + self.rank) * b)
         return out
 
-    def step(self, user_ids: torch.Tensor, item_ids: torch.Tensor, next_ids=None, category_ids=None) -> torch.Tensor:
+    def _cand_prob(self, p):
+        """candidate_sampling_probability of the candidates this rank scores against (all-gathered for global negatives)."""
+        if p is None or self.negatives == "local" or not self.collectives:
+            return p
+        if not hasattr(self, "p_all"):
+            self.p_all = torch.empty(self.cfg.batch_size * self.world, device=self.dev)
+        dist.all_gather_into_tensor(self.p_all, p.contiguous(), group=self.group)
+        return self.p_all
+
+    def step(self, user_ids: torch.Tensor, item_ids: torch.Tensor, next_ids=None, category_ids=None,
+             candidate_sampling_probability=None) -> torch.Tensor:
         """One train step on this rank's batch; returns this rank's (device, unsynchronised) loss.
         next_ids = (user_ids, item_ids) of the following step, if the input pipeline already has them: their
         routing and id all-to-all then run beside this step's scorer (pass the same tensors to the next call)."""
@@ -408,13 +418,14 @@ class ShardedTwoTowerTrainer:
             q = ut.forward((cfg.dropout_rate, self.dropout_seed, 0, row0))
             c = it.forward((cfg.dropout_rate, self.dropout_seed, 1, row0))
         inv_t = 1.0 / cfg.temperature
+        cp = self._cand_prob(candidate_sampling_probability)
         if self.negatives == "local" or not self.collectives:
-            ops.retrieval_fwd_bwd(q, c, inv_t, self.ws, self.lse, self.per_row, self.loss, ut.dz[-1], it.dz[-1])
+            ops.retrieval_fwd_bwd(q, c, inv_t, self.ws, self.lse, self.per_row, self.loss, ut.dz[-1], it.dz[-1], cand_prob=cp)
         else:
             dist.all_gather_into_tensor(self.c_all, c, group=self.group)                       # C4
             off = self.rank * b
             ops.retrieval_fwd_bwd(q, self.c_all, inv_t, self.ws, self.lse, self.per_row, self.loss, ut.dz[-1], self.dc_all,
-                                  diag_offset=off)
+                                  diag_offset=off, cand_prob=cp)
             dist.reduce_scatter_tensor(it.dz[-1], self.dc_all, op=dist.ReduceOp.SUM, group=self.group)   # C5
 
         # every dx first: the embedding gradient rows travel to their owners beside the dw GEMMs and the dense reduce
@@ -459,6 +470,63 @@ class ShardedTwoTowerTrainer:
     @property
     def item_table(self) -> torch.Tensor:
         return self.emb.shard(1)
+
+    # ------------------------------------------------------------------ validation loss / retrieval metrics
+    def _inputs(self, user_ids, item_ids, category_ids):
+        if (category_ids is None) != (self.cat_table is None):
+            raise ValueError("category_ids must be given exactly when cfg.n_category_buckets > 0")
+        self.emb.lookup((user_ids, item_ids), self.emb_in)
+        if category_ids is not None:
+            self.ops.embedding_gather_add_(self.item_tower.acts[0], self.cat_table, category_ids, self.emb.flags[0:1])
+
+    @torch.no_grad()
+    def evaluate(self, user_ids: torch.Tensor, item_ids: torch.Tensor, category_ids=None,
+                 candidate_sampling_probability=None) -> torch.Tensor:
+        """Forward only: this rank's validation loss (SUM over its batch; device tensor, unsynchronised).  Collective:
+        every rank must call it the same number of times."""
+        from .trainer import towers_forward
+        cfg, ops, ut, it = self.cfg, self.ops, self.user_tower, self.item_tower
+        self._inputs(user_ids, item_ids, category_ids)
+        q, c = towers_forward(ut, it) if cfg.symmetric else (ut.forward(), it.forward())
+        cp = self._cand_prob(candidate_sampling_probability)
+        if self.negatives == "local" or not self.collectives:
+            return ops.retrieval_fwd(q, c, 1.0 / cfg.temperature, self.ws, self.lse, self.per_row, self.loss, cand_prob=cp)
+        dist.all_gather_into_tensor(self.c_all, c, group=self.group)
+        return ops.retrieval_fwd(q, self.c_all, 1.0 / cfg.temperature, self.ws, self.lse, self.per_row, self.loss,
+                                 diag_offset=self.rank * cfg.batch_size, cand_prob=cp)
+
+    @torch.no_grad()
+    def item_corpus_embeddings(self, item_category_ids: torch.Tensor | None = None) -> torch.Tensor:
+        """Item-tower output of EVERY item in global id order ([n_items, scorer_dim], replicated on all ranks): every
+        rank runs the tower over its own rows, one all-gather interleaves them (global row = local * world + rank).
+        item_category_ids [n_items] (global order) is required iff the model has the category feature."""
+        cfg, it, b, w = self.cfg, self.item_tower, self.cfg.batch_size, self.world
+        if (item_category_ids is None) != (self.cat_table is None):
+            raise ValueError("item_category_ids must be given exactly when cfg.n_category_buckets > 0")
+        shard = self.emb.shard(1)
+        cap, sd = self.emb.rows_cap[1], it.dims[-1]
+        local = torch.zeros(cap, sd, device=self.dev)
+        my_cat = None if item_category_ids is None else item_category_ids[self.rank::w].contiguous()
+        for s in range(0, shard.shape[0], b):
+            e = min(s + b, shard.shape[0])
+            it.acts[0][:e - s].copy_(shard[s:e])
+            if my_cat is not None:
+                self.ops.embedding_gather_add_(it.acts[0][:e - s], self.cat_table, my_cat[s:e], self.emb.flags[0:1])
+            it.forward()
+            local[s:e].copy_(it.acts[-1][:e - s])
+        if not self.collectives:
+            return local[:cfg.n_items]
+        allr = torch.empty(w, cap, sd, device=self.dev)
+        dist.all_gather_into_tensor(allr, local, group=self.group)
+        return allr.permute(1, 0, 2).reshape(cap * w, sd)[:cfg.n_items].contiguous()
+
+    @torch.no_grad()
+    def evaluate_topk(self, user_ids: torch.Tensor, item_ids: torch.Tensor, metric, corpus: torch.Tensor):
+        """Updates ``metric`` (metrics.FactorizedTopK) with this rank's (user, true item) pairs ranked against the whole
+        corpus (from item_corpus_embeddings()); the user rows come through the exchange, so this is collective."""
+        self.emb.lookup((user_ids, item_ids), self.emb_in)
+        q = self.user_tower.forward()
+        return metric.update_state(q, corpus, item_ids)
 
     # ------------------------------------------------------------------ checkpoint (SURVEY.md §8f row 4)
     def state_dict(self) -> dict:

@@ -3,13 +3,16 @@ entry point the reference declares (``/root/reference/pyproject.toml:67`` ``trai
 "src.training.train:main"``; ``README.md:39`` ``python src/training/train.py --config ...``) but does not
 ship.  Reads the ``model:`` block of the reference's YAML schema (``configs/data_config.yaml:54-71``) and the
 parquet written by ``prepare_training_data.py:216-218``; runs every step on the HIP kernels (one GPU here;
-the row-sharded multi-GPU step is ``sharded.py``).
+under ``python -m torch.distributed.run --nproc-per-node N`` — or with ``--distributed`` — one process per GPU on the
+row-sharded trainer of ``sharded.py``: every rank trains on its slice of the interactions, tables are sharded by
+``id % N``, collectives go over RCCL).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import logging
+import os
 import sys
 import time
 
@@ -42,7 +45,13 @@ def parse(argv=None):
     ap.add_argument("--val-fraction", type=float, default=0.1)
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--device", default="cuda:0")
-    ap.add_argument("--save", default=None, help="write a checkpoint (torch.save of tensors) here at the end")
+    ap.add_argument("--save", default=None, help="write a checkpoint (torch.save of tensors) here at the end "
+                                                 "(distributed: one file per rank, <path>.rank<r>of<N>)")
+    ap.add_argument("--distributed", action="store_true",
+                    help="use the row-sharded multi-GPU trainer (implied when WORLD_SIZE > 1); batch_size is per rank")
+    ap.add_argument("--negatives", default="local", choices=["local", "global"],
+                    help="distributed: in-batch negatives of the rank's own batch (what tfrs.tasks.Retrieval sees under a "
+                         "data-parallel strategy) or of the all-gathered global batch")
     return ap.parse_args(argv)
 
 
@@ -50,6 +59,19 @@ def main(argv=None) -> int:
     args = parse(argv)
     logging.basicConfig(level=logging.INFO, format="%(asctime)s - %(levelname)s - %(message)s")
     doc = cfgmod.load_yaml(args.config)
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    distributed = args.distributed or world > 1
+    if distributed:
+        import torch.distributed as dist
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if world > 1 or "LOCAL_RANK" in os.environ:
+            args.device = f"cuda:{local_rank}"
+        torch.cuda.set_device(torch.device(args.device))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29511")):
+            os.environ.setdefault(k, v)
+        if not dist.is_initialized():
+            dist.init_process_group("nccl", device_id=torch.device(args.device))
     if args.synthetic:
         from . import ops
         dev = torch.device(args.device)
@@ -83,11 +105,27 @@ def main(argv=None) -> int:
     rng = np.random.default_rng(args.seed)
     perm = rng.permutation(n)
     tr_idx, va_idx = perm[n_val:], perm[:n_val]
-    if len(tr_idx) < cfg.batch_size:
-        raise SystemExit(f"only {len(tr_idx)} training interactions for batch_size {cfg.batch_size}")
     log.info("users %d items %d interactions %d (train %d, val %d); batch %d; optimizer %s", n_users, n_items, n,
              len(tr_idx), len(va_idx), cfg.batch_size, cfg.optimizer)
-    trainer = TwoTowerTrainer(cfg, args.device, seed=args.seed)
+    if distributed:
+        # every rank computed the same split; it trains on every world-th pair, cut so all ranks run the same number
+        # of (collective) steps
+        from .sharded import ShardedTwoTowerTrainer
+    # whole (global) batches only — the kernels' buffers are sized for one batch size — then every world-th pair
+    per = cfg.batch_size * world
+    tr_idx = tr_idx[:len(tr_idx) // per * per][rank::world]
+    va_idx = va_idx[:len(va_idx) // per * per][rank::world]
+    if len(tr_idx) < cfg.batch_size:
+        raise SystemExit(f"only {len(tr_idx)} training interactions per rank for batch_size {cfg.batch_size}")
+    if distributed:
+        trainer = ShardedTwoTowerTrainer(cfg, args.device, seed=args.seed, negatives=args.negatives)
+    else:
+        trainer = TwoTowerTrainer(cfg, args.device, seed=args.seed)
+
+    def total(x: torch.Tensor) -> float:        # sum over ranks of a device scalar
+        if distributed:
+            dist.all_reduce(x)
+        return x.item()
     train_it = datamod.BatchIterator(user_idx[tr_idx], item_idx[tr_idx], cfg.batch_size, trainer.dev, args.seed,
                                      category_bucket=None if cat is None else cat[tr_idx])
     val_it = datamod.BatchIterator(user_idx[va_idx], item_idx[va_idx], cfg.batch_size, trainer.dev, args.seed, shuffle=False,
@@ -95,8 +133,10 @@ def main(argv=None) -> int:
 
     item_prob = None
     if args.correct_sampling_bias:          # P(item j is drawn as an in-batch candidate) = its share of the training pairs
-        counts = np.bincount(item_idx[tr_idx], minlength=n_items).astype(np.float64)
-        item_prob = torch.from_numpy((counts / counts.sum()).astype(np.float32)).to(trainer.dev)
+        counts = torch.from_numpy(np.bincount(item_idx[tr_idx], minlength=n_items).astype(np.float64)).to(trainer.dev)
+        if distributed:                     # the candidates' frequencies over ALL ranks' training pairs
+            dist.all_reduce(counts)
+        item_prob = (counts / counts.sum()).to(torch.float32)
 
     def kw(batch):
         k = {"category_ids": batch[2]} if len(batch) == 3 else {}
@@ -112,13 +152,13 @@ def main(argv=None) -> int:
         torch.cuda.synchronize()
         trainer.check_ids()
         dt = time.perf_counter() - t0
-        rec = {"epoch": epoch + 1, "train_loss_per_pair": tot.item() / (len(train_it) * cfg.batch_size),
-               "pairs_per_sec": len(train_it) * cfg.batch_size / dt}
+        rec = {"epoch": epoch + 1, "train_loss_per_pair": total(tot) / (len(train_it) * cfg.batch_size * world),
+               "pairs_per_sec": len(train_it) * cfg.batch_size * world / dt}
         if len(val_it) and (epoch + 1) % loop["validation_freq"] == 0:
             vt = torch.zeros((), device=trainer.dev, dtype=torch.float64)
             for batch in val_it:
                 vt += trainer.evaluate(batch[0], batch[1], **kw(batch)).double().squeeze()
-            rec["val_loss_per_pair"] = vt.item() / (len(val_it) * cfg.batch_size)
+            rec["val_loss_per_pair"] = total(vt) / (len(val_it) * cfg.batch_size * world)
             if rec["val_loss_per_pair"] < best - 1e-6:
                 best, bad = rec["val_loss_per_pair"], 0
             else:
@@ -142,12 +182,19 @@ def main(argv=None) -> int:
         corpus = trainer.item_corpus_embeddings(item_cat)
         for batch in val_it:
             trainer.evaluate_topk(batch[0], batch[1], metric, corpus)
+        if distributed and metric._n:           # every rank ranked its own held-out pairs: sum the tallies
+            dist.all_reduce(metric._hits); dist.all_reduce(metric._dcg)
+            metric._n *= world
         final["val_metrics"] = {k: float(v) for k, v in metric.result().items()}
         log.info(json.dumps(final["val_metrics"]))
     if args.save:
-        torch.save(trainer.state_dict(), args.save)
-        log.info("saved checkpoint to %s", args.save)
-    print(json.dumps(final))
+        path = f"{args.save}.rank{rank}of{world}" if distributed else args.save
+        torch.save(trainer.state_dict(), path)
+        log.info("saved checkpoint to %s", path)
+    if rank == 0:
+        print(json.dumps(final))
+    if distributed:
+        dist.destroy_process_group()
     return 0
 
 
