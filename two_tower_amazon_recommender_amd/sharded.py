@@ -516,9 +516,9 @@ class ShardedTwoTowerTrainer:
             local[s:e].copy_(it.acts[-1][:e - s])
         if not self.collectives:
             return local[:cfg.n_items]
-        allr = torch.empty(w, cap, sd, device=self.dev)
+        allr = torch.empty(w * cap, sd, device=self.dev)                  # rank r's rows at [r*cap, (r+1)*cap)
         dist.all_gather_into_tensor(allr, local, group=self.group)
-        return allr.permute(1, 0, 2).reshape(cap * w, sd)[:cfg.n_items].contiguous()
+        return allr.view(w, cap, sd).permute(1, 0, 2).reshape(cap * w, sd)[:cfg.n_items].contiguous()
 
     @torch.no_grad()
     def evaluate_topk(self, user_ids: torch.Tensor, item_ids: torch.Tensor, metric, corpus: torch.Tensor):
