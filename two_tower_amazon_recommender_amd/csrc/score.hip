@@ -480,28 +480,60 @@ __global__ __launch_bounds__(256) void fused_combine_kernel(const float* __restr
   const int64_t row = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
   const int lane = threadIdx.x & 31;
   if (row >= n_r) return;
+  // The slab rows of the first 8 splits (33 of the kernel's 42 MB at cfg3) do not depend on the row statistics: their
+  // loads are issued first, the (max, sum) passes over part_m / part_l run underneath them.
+  constexpr int U = 8;
+  f32x4 v0[U];
+  f32x4 cp0 = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (lane < d4) {
+    cp0 = cpos[row * d4 + lane];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      v0[u] = u < nsplit ? slab[((int64_t)u * n_r + row) * d4 + lane] : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  float pm[U], pl[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    pm[u] = u < nsplit ? part_m[(int64_t)u * n_r + row] : kNegBig;
+    pl[u] = u < nsplit ? part_l[(int64_t)u * n_r + row] : 0.f;
+  }
+  const float p2 = pos2[row];
+  const float wr = (w != nullptr ? w[row] : 1.0f);
   float M = kNegBig;
-  for (int s = 0; s < nsplit; ++s) M = fmaxf(M, part_m[(int64_t)s * n_r + row]);
+#pragma unroll
+  for (int u = 0; u < U; ++u) M = fmaxf(M, pm[u]);
+  for (int s = U; s < nsplit; ++s) M = fmaxf(M, part_m[(int64_t)s * n_r + row]);
   float L = 0.f;
-  for (int s = 0; s < nsplit; ++s)
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    if (u < nsplit) L += pl[u] * __builtin_amdgcn_exp2f(pm[u] - M);
+  for (int s = U; s < nsplit; ++s)
     L += part_l[(int64_t)s * n_r + row] * __builtin_amdgcn_exp2f(part_m[(int64_t)s * n_r + row] - M);
   const float lse2 = M + __log2f(L);
-  const float wr = (w != nullptr ? w[row] : 1.0f);
   const float sr = wr * scale;
   if (lane == 0) {
     lse[row] = lse2 * kLn2;
-    per_row[row] = (lse2 - pos2[row]) * kLn2 * wr;
+    per_row[row] = (lse2 - p2) * kLn2 * wr;
     aq[row] = -lse2;
     sq[row] = sr;
   }
   const float inv_l = 1.0f / L;
   for (int c = lane; c < d4; c += 32) {
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < nsplit; ++s) {
-      const float wt = __builtin_amdgcn_exp2f(part_m[(int64_t)s * n_r + row] - M);
-      acc += slab[((int64_t)s * n_r + row) * d4 + c] * wt;
+    f32x4 cp;
+    if (c == lane) {                               // first column chunk: operands already in registers
+      cp = cp0;
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (u < nsplit) acc += v0[u] * __builtin_amdgcn_exp2f(pm[u] - M);
+    } else {
+      cp = cpos[row * d4 + c];
+      for (int s = 0; s < nsplit && s < U; ++s)
+        acc += slab[((int64_t)s * n_r + row) * d4 + c] * __builtin_amdgcn_exp2f(part_m[(int64_t)s * n_r + row] - M);
     }
-    dq[row * d4 + c] = (acc * inv_l - cpos[row * d4 + c]) * sr;
+    for (int s = U; s < nsplit; ++s)               // splits beyond the first 8, in order
+      acc += slab[((int64_t)s * n_r + row) * d4 + c] * __builtin_amdgcn_exp2f(part_m[(int64_t)s * n_r + row] - M);
+    dq[row * d4 + c] = (acc * inv_l - cp) * sr;
   }
 }
 
@@ -632,10 +664,32 @@ __global__ __launch_bounds__(1024) void sum_rows_kernel(const float* __restrict_
   if (threadIdx.x == 0) loss[0] = red[0];
 }
 
-// out[i] = sum_s slab[s][i], s ascending (float4)
+// out[i] = sum_s slab[s][i], s ascending (float4).  With per_row != NULL the launch has one EXTRA workgroup (the last)
+// that computes loss = sum_r per_row[r] in exactly sum_rows_kernel's order (1024 strided partial sums, then the
+// binary tree), so the fused training form needs no separate single-workgroup launch for the scalar.
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const f32x4* __restrict__ slab, f32x4* __restrict__ out,
-                                                           int64_t n4, int nsplit) {
-  const int64_t stride = (int64_t)gridDim.x * 256;
+                                                           int64_t n4, int nsplit, const float* __restrict__ per_row,
+                                                           int64_t n_rows, float* __restrict__ loss) {
+  if (per_row != nullptr && blockIdx.x == gridDim.x - 1) {
+    __shared__ float red[256];
+    const int t = threadIdx.x;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t r = t; r < n_rows; r += 1024) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (r + 256 * j < n_rows) a[j] += per_row[r + 256 * j];
+    }
+    red[t] = (a[0] + a[2]) + (a[1] + a[3]);          // tree steps s = 512 and s = 256
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+      if (t < s2) red[t] += red[t + s2];
+      __syncthreads();
+    }
+    if (t == 0) loss[0] = red[0];
+    return;
+  }
+  const int64_t nblk = per_row != nullptr ? gridDim.x - 1 : gridDim.x;
+  const int64_t stride = nblk * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
     f32x4 a = slab[i];
     for (int s = 1; s < nsplit; ++s) a += slab[(int64_t)s * n4 + i];
@@ -831,7 +885,7 @@ extern "C" int tt_retrieval_bwd_f32(const float* q, const float* c, int64_t nq, 
     {
       tt::ProfScope prof("score_aux", stream);
       hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
-                         reinterpret_cast<const f32x4*>(slab), reinterpret_cast<f32x4*>(dq), n4, a.nsplit);
+                         reinterpret_cast<const f32x4*>(slab), reinterpret_cast<f32x4*>(dq), n4, a.nsplit, nullptr, 0, nullptr);
     }
     if ((rc = tt::check_launch("reduce_slabs(dq)")) != TT_OK) return rc;
   }
@@ -853,7 +907,7 @@ extern "C" int tt_retrieval_bwd_f32(const float* q, const float* c, int64_t nq, 
     {
       tt::ProfScope prof("score_aux", stream);
       hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
-                         reinterpret_cast<const f32x4*>(slab), reinterpret_cast<f32x4*>(dc), n4, a.nsplit);
+                         reinterpret_cast<const f32x4*>(slab), reinterpret_cast<f32x4*>(dc), n4, a.nsplit, nullptr, 0, nullptr);
     }
     if ((rc = tt::check_launch("reduce_slabs(dc)")) != TT_OK) return rc;
   }
@@ -906,8 +960,7 @@ extern "C" int tt_retrieval_fwd_bwd_f32(const float* q, const float* c, int64_t 
                          reinterpret_cast<const f32x4*>(c + diag_offset * dim), nq, dim / 4, a.nsplit,
                          inv_temperature * grad_scale, lse, per_row, aq, sq, reinterpret_cast<f32x4*>(dq));
       if ((rc = tt::check_launch("fused_combine")) != TT_OK) return rc;
-      hipLaunchKernelGGL(sum_rows_kernel, dim3(1), dim3(1024), 0, stream, per_row, nq, loss);
-      if ((rc = tt::check_launch("sum_rows")) != TT_OK) return rc;
+      // loss = sum(per_row): by one extra workgroup of the dc slab reduction below
     }
   }
   float* hq = nullptr;
@@ -931,8 +984,8 @@ extern "C" int tt_retrieval_fwd_bwd_f32(const float* q, const float* c, int64_t 
     const int64_t n4 = nc * dim / 4;
     const int64_t blocks = (n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048;
     tt::ProfScope prof("score_aux", stream);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
-                       reinterpret_cast<const f32x4*>(slab), reinterpret_cast<f32x4*>(dc), n4, a.nsplit);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks + 1), dim3(256), 0, stream,
+                       reinterpret_cast<const f32x4*>(slab), reinterpret_cast<f32x4*>(dc), n4, a.nsplit, per_row, nq, loss);
     if ((rc = tt::check_launch("reduce_slabs(dc)")) != TT_OK) return rc;
   }
   return TT_OK;
