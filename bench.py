@@ -150,16 +150,29 @@ def main():
     torch.cuda.synchronize()
     trainer.check_ids()
 
-    tags = "score_fused,score_bwd,gather,sparse_plan,sparse_apply"
-    _lib.profile_enable(tags, capacity=2 * args.steps + 8)
+    # Timed region: only the DOMINANT kernel carries hipEvent brackets (each event record is a barrier packet that
+    # costs the stream ~4-7 us: bracketing all five kernel families inflated the step by 33 us = 4 %).  The other
+    # kernels' durations come from an untimed detail pass of the same steps right after it.
+    all_tags = "score_fused,score_bwd,gather,sparse_plan,sparse_apply".split(",")
+    timed_tags = os.environ.get("TT_BENCH_TAGS", "score_fused")
+    _lib.profile_enable(timed_tags, capacity=2 * args.steps + 8)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for s in range(args.warmup, total):
         step(s)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    prof = {t: _lib.profile_read(t, 2 * args.steps + 8)[0] for t in tags.split(",")}
+    prof = {t: _lib.profile_read(t, 2 * args.steps + 8)[0] for t in timed_tags.split(",") if t in all_tags}
+    detail_steps = min(args.steps, 50)
+    rest = [t for t in all_tags if t not in prof]
+    _lib.profile_enable(",".join(rest), capacity=2 * detail_steps + 8)
+    for s in range(total - detail_steps, total):          # the same id batches again (state has moved on; shapes equal)
+        step(s)
+    torch.cuda.synchronize()
+    for t in rest:
+        prof[t] = _lib.profile_read(t, 2 * detail_steps + 8)[0]
     _lib.profile_enable("")
+    steps_of = {t: (args.steps if t in timed_tags.split(",") else detail_steps) for t in all_tags}
     loss = float(trainer.loss.item())
     trainer.check_ids()
 
@@ -195,7 +208,7 @@ def main():
         gs_bytes += 8 * batch * dim
 
     def per_step(tag):                 # ms per STEP (a step may launch a tagged kernel more than once)
-        return sum(prof[tag]) / args.steps
+        return sum(prof[tag]) / steps_of[tag]
     t_gs = max((per_step("gather") + per_step("sparse_apply")) * 1e-3, 1e-12)
     out = {
         "metric": "user-item pairs/sec (train step) + embedding-gather HBM GB/s, 1/2/4/8 MI355X",
@@ -208,6 +221,8 @@ def main():
                                + (f", + {cfg.n_category_buckets}-bucket hashed category feature summed into the item input"
                                   if cfg.n_category_buckets else ""),
                    "global_batch": batch, "parallelism": "single GPU"},
+        "timing_note": f"hipEvent brackets inside the timed region: {timed_tags} only; score_bwd / gather / sparse_* durations "
+                       f"from an untimed detail pass of {detail_steps} further steps",
         "roofline": dominant,
         "roofline_hbm": {"bound": "hbm", "kernel": "gather2 + sparse_update2 (K1 + K2 apply; both tables; hipEvent brackets add "
                                                    "~3 us to kernels this short, see profiles/ for rocprof durations)",
