@@ -674,10 +674,20 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const f32x4* __restri
     __shared__ float red[256];
     const int t = threadIdx.x;
     float a[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int64_t r = t; r < n_rows; r += 1024) {
+    for (int64_t r0 = t; r0 < n_rows; r0 += 8 * 1024) {        // 32 loads in flight per thread, adds in row order
+      float v[8][4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (r + 256 * j < n_rows) a[j] += per_row[r + 256 * j];
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int64_t r = r0 + 1024 * i + 256 * j;
+          v[i][j] = r < n_rows ? per_row[r] : 0.f;
+        }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (r0 + 1024 * i + 256 * j < n_rows) a[j] += v[i][j];
     }
     red[t] = (a[0] + a[2]) + (a[1] + a[3]);          // tree steps s = 512 and s = 256
     __syncthreads();
