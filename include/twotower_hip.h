@@ -51,7 +51,7 @@ const char* tt_last_error(void);
  * Built-in kernel timing (SURVEY.md §5 "Tracing / profiling": the reference has none).
  * tt_profile_enable("score_bwd,gather", 4096) makes every launch of the kernels carrying one
  * of those tags record a hipEvent pair on ITS OWN stream (capacity = launches kept per tag);
- * tags: fill, gather, sparse_plan, sparse_apply, dense_fwd, dense_bwd_dx, dense_bwd_dw,
+ * tags: fill, gather, sparse_plan, sparse_apply, dense_fwd, dense_bwd (dx+dw in one launch), dense_bwd_dx, dense_bwd_dw,
  * dense_update, score_fwd, score_bwd, score_fused, score_rank, score_aux, route, scatter_rows, encode_ids.  An empty string (or NULL) disables it.
  * tt_profile_read synchronises on the recorded events, writes up to `cap` durations in
  * milliseconds (launch order) to the HOST array `ms`, stores the number of launches seen in
@@ -210,7 +210,8 @@ int tt_dense_bwd_scaled_f32(const float* x, const float* w, const float* dz,
                             int64_t m, int32_t k, int32_t n, tt_stream_t stream);
 
 /* Batched forms: the same layer of the user AND the item tower (identical shapes) in one launch each —
- * fwd: 1 launch, bwd: 2 launches (dx, dw+db) — instead of twice as many half-size launches.
+ * fwd: 1 launch, bwd: 1 launch (the dx tiles and the dw+db tiles of the layer side by side; 2 launches when
+ * only dx or only dw is asked for) — instead of twice as many half-size launches.
  * `probs` is a HOST array of n_probs (1 or 2) entries.                                                     */
 typedef struct tt_dense_fwd_args {
   const float* x; const float* w; const float* b; float* y;

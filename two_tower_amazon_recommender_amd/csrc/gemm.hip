@@ -100,17 +100,15 @@ struct GemmBatch {
   int splits;
 };
 
+// one 64x64 output tile (bx, by) of problem p, k-range of split zsplit
 template <bool A_KC, bool B_KC, bool COLSUM>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmBatch pb) {
-  const int zsplit = blockIdx.z % pb.splits;
-  const GemmArgs& p = pb.a[blockIdx.z / pb.splits];
-  __shared__ __attribute__((aligned(16))) float smem[2 * 2 * TILE_F];
+__device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int zsplit, const int bx, const int by, float* smem) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, ln = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
-  const int64_t m0 = (int64_t)blockIdx.x * BM;
-  const int64_t n0 = (int64_t)blockIdx.y * BN;
+  const int64_t m0 = (int64_t)bx * BM;
+  const int64_t n0 = (int64_t)by * BN;
   const int64_t kbeg = (int64_t)zsplit * p.k_per_split;
   int64_t kend = kbeg + p.k_per_split;
   if (kend > p.K) kend = p.K;
@@ -155,7 +153,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmBatch pb) {
         }
         if constexpr (COLSUM) {
           // db: column sums of the dz tile, once per n-tile (m-tile 0 only); rows beyond kend are zero-filled
-          if (blockIdx.x == 0 && tid < BN) {
+          if (bx == 0 && tid < BN) {
 #pragma unroll 8
             for (int kk = 0; kk < BK; ++kk) colsum += TB[kk * LS_MC + tid];
           }
@@ -184,7 +182,48 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmBatch pb) {
     }
   }
   if constexpr (COLSUM) {
-    if (blockIdx.x == 0 && tid < BN && n0 + tid < p.N) p.db_slabs[(int64_t)zsplit * p.N + n0 + tid] = colsum;
+    if (bx == 0 && tid < BN && n0 + tid < p.N) p.db_slabs[(int64_t)zsplit * p.N + n0 + tid] = colsum;
+  }
+}
+
+template <bool A_KC, bool B_KC, bool COLSUM>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmBatch pb) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * 2 * TILE_F];
+  gemm_tile<A_KC, B_KC, COLSUM>(pb.a[blockIdx.z / pb.splits], blockIdx.z % pb.splits, blockIdx.x, blockIdx.y, smem);
+}
+
+// dx AND dw+db of one layer (of both towers) in ONE launch: the two kinds of tiles are independent given dz, so
+// one launch ramp is saved and the output stores of one kind run under the MFMAs of the other.  Flat workgroup
+// index -> (kind, problem, split, x, y); dw tiles are TN and split over the batch, dx tiles NT.
+struct BwdBatch {
+  GemmArgs ax[2], aw[2];
+  int nprob, splits;
+  int dx_gm, dx_gn;      // dx tiles per problem: dx_gm x dx_gn
+  int dw_gm, dw_gn;      // dw tiles per problem and split
+  int dw_first;          // 1: the dw tiles take the first workgroup indices (when their k-range is the longer one)
+};
+
+__global__ __launch_bounds__(256) void gemm_bwd_kernel(BwdBatch pb) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * 2 * TILE_F];
+  const int per_split = pb.dw_gm * pb.dw_gn;
+  const int per_w = per_split * pb.splits;
+  const int per_x = pb.dx_gm * pb.dx_gn;
+  const int n_dw = pb.nprob * per_w, n_dx = pb.nprob * per_x;
+  // longest tiles first: workgroups are dispatched in index order, so the short tiles fill the tail
+  int b = blockIdx.x;
+  const bool is_dw = pb.dw_first ? b < n_dw : b >= n_dx;
+  if (is_dw) {
+    if (!pb.dw_first) b -= n_dx;
+    const int prob = b / per_w;
+    b -= prob * per_w;
+    const int split = b / per_split;
+    b -= split * per_split;
+    gemm_tile<false, false, true>(pb.aw[prob], split, b % pb.dw_gm, b / pb.dw_gm, smem);
+  } else {
+    if (pb.dw_first) b -= n_dw;
+    const int prob = b / per_x;
+    b -= prob * per_x;
+    gemm_tile<true, true, false>(pb.ax[prob], 0, b % pb.dx_gm, b / pb.dx_gm, smem);
   }
 }
 
@@ -294,6 +333,19 @@ extern "C" int tt_dense_bwd_batched_f32(const tt_dense_bwd_args* probs, int32_t 
     aw[i].mask_scale = 1.f;
   }
   int rc;
+  if (want_dx && want_dw) {
+    BwdBatch pb{};
+    for (int i = 0; i < n_probs; ++i) { pb.ax[i] = ax[i]; pb.aw[i] = aw[i]; }
+    pb.nprob = n_probs; pb.splits = splits;
+    pb.dx_gm = (int)((ax[0].M + BM - 1) / BM); pb.dx_gn = (int)((ax[0].N + BN - 1) / BN);
+    pb.dw_gm = (int)((aw[0].M + BM - 1) / BM); pb.dw_gn = (int)((aw[0].N + BN - 1) / BN);
+    pb.dw_first = aw[0].k_per_split > ax[0].k_per_split;     // k-tiles per tile: batch/splits rows vs n columns
+    const int64_t blocks = (int64_t)n_probs * ((int64_t)pb.dx_gm * pb.dx_gn + (int64_t)pb.dw_gm * pb.dw_gn * splits);
+    TT_REQUIRE(blocks <= 0x7fffffff && (ax[0].M + BM - 1) / BM <= 0x3fffffff, "tt_dense_bwd_f32: grid too large");
+    tt::ProfScope prof("dense_bwd", stream);
+    hipLaunchKernelGGL(gemm_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, pb);
+    return tt::check_launch("tt_dense_bwd_f32(dx+dw)");
+  }
   if (want_dx && (rc = launch<true, true, false>(ax, n_probs, 1, stream, "tt_dense_bwd_f32(dx)", "dense_bwd_dx")) != TT_OK) return rc;
   if (!want_dw) return TT_OK;
   return launch<false, false, true>(aw, n_probs, splits, stream, "tt_dense_bwd_f32(dw)", "dense_bwd_dw");
