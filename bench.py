@@ -155,6 +155,8 @@ def main():
     # kernels' durations come from an untimed detail pass of the same steps right after it.
     all_tags = "score_fused,score_bwd,gather,sparse_plan,sparse_apply".split(",")
     timed_tags = os.environ.get("TT_BENCH_TAGS", "score_fused")
+    stride = 4 if args.steps >= 40 else 1            # the dominant kernel is sampled every 4th step (>= 10 samples)
+    _lib.profile_set_stride(stride)
     _lib.profile_enable(timed_tags, capacity=2 * args.steps + 8)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -165,6 +167,7 @@ def main():
     prof = {t: _lib.profile_read(t, 2 * args.steps + 8)[0] for t in timed_tags.split(",") if t in all_tags}
     detail_steps = min(args.steps, 50)
     rest = [t for t in all_tags if t not in prof]
+    _lib.profile_set_stride(1)
     _lib.profile_enable(",".join(rest), capacity=2 * detail_steps + 8)
     for s in range(total - detail_steps, total):          # the same id batches again (state has moved on; shapes equal)
         step(s)
@@ -221,7 +224,8 @@ def main():
                                + (f", + {cfg.n_category_buckets}-bucket hashed category feature summed into the item input"
                                   if cfg.n_category_buckets else ""),
                    "global_batch": batch, "parallelism": "single GPU"},
-        "timing_note": f"hipEvent brackets inside the timed region: {timed_tags} only; score_bwd / gather / sparse_* durations "
+        "timing_note": f"hipEvent brackets inside the timed region: {timed_tags} only, every {stride}th step "
+                       f"({len(prof['score_fused'])} samples); score_bwd / gather / sparse_* durations "
                        f"from an untimed detail pass of {detail_steps} further steps",
         "roofline": dominant,
         "roofline_hbm": {"bound": "hbm", "kernel": "gather2 + sparse_update2 (K1 + K2 apply; both tables; hipEvent brackets add "

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TT_ABI_VERSION 3
+#define TT_ABI_VERSION 4
 
 enum {
   TT_OK = 0,
@@ -54,10 +54,14 @@ const char* tt_last_error(void);
  * tags: fill, gather, sparse_plan, sparse_apply, dense_fwd, dense_bwd (dx+dw in one launch), dense_bwd_dx, dense_bwd_dw,
  * dense_update, score_fwd, score_bwd, score_fused, score_rank, score_aux, route, scatter_rows, encode_ids.  An empty string (or NULL) disables it.
  * tt_profile_read synchronises on the recorded events, writes up to `cap` durations in
- * milliseconds (launch order) to the HOST array `ms`, stores the number of launches seen in
+ * milliseconds (launch order) to the HOST array `ms`, stores the number of durations written in
  * *count (HOST) and clears the tag.  Disabled = one predictable branch per launch.           */
 int tt_profile_enable(const char* tags_csv, int32_t capacity_per_tag);
 int tt_profile_read(const char* tag, float* ms, int32_t cap, int32_t* count);
+/* Bracket only every stride-th launch of a tag (default 1 = every launch).  A hipEventRecord is a barrier packet
+ * that costs the stream 4-7 us: a whole-step throughput measurement that also wants live kernel durations
+ * samples them (bench.py: every 4th step).                                                                  */
+int tt_profile_set_stride(int32_t stride);
 
 /* ---------------------------------------------------------------------------------------
  * Synthetic inputs (SURVEY.md §8d "Synthetic inputs"; no reference counterpart).

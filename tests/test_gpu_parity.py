@@ -100,6 +100,37 @@ def test_gather_add_and_hash_buckets_bit_exact(dev):
     assert hashing.fnv1a64(b"foobar") == 0x85944171F73967E8
 
 
+def test_builtin_kernel_timing_stride_and_counts(dev):
+    """tt_profile_*: every launch bracketed by default, every stride-th with tt_profile_set_stride; the count returned is
+    the number of durations written; disabled tags cost nothing and read as an error."""
+    table = torch.zeros(1000, 128, device=dev)
+    ids = torch.randint(0, 1000, (4096,), device=dev)
+    out = torch.empty(4096, 128, device=dev)
+    try:
+        _lib.profile_enable("gather", 64)
+        for _ in range(12):
+            ops.embedding_gather(table, ids, out=out)
+        ms, n = _lib.profile_read("gather", 64)
+        assert n == 12 and len(ms) == 12 and all(0.0 < x < 5.0 for x in ms)
+        _lib.profile_set_stride(4)
+        for _ in range(12):
+            ops.embedding_gather(table, ids, out=out)
+        ms, n = _lib.profile_read("gather", 64)
+        assert n == 3 and len(ms) == 3 and all(0.0 < x < 5.0 for x in ms)
+        _lib.profile_enable("gather", 2)                       # capacity 2: later launches are dropped, not overwritten
+        _lib.profile_set_stride(1)
+        for _ in range(5):
+            ops.embedding_gather(table, ids, out=out)
+        assert _lib.profile_read("gather", 64)[1] == 2
+        with pytest.raises(ValueError):
+            _lib.profile_read("sparse_apply", 8)               # not enabled
+        with pytest.raises(ValueError):
+            _lib.profile_set_stride(0)
+    finally:
+        _lib.profile_set_stride(1)
+        _lib.profile_enable("")
+
+
 def test_ops_reject_cpu_tensors():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.embedding_gather(torch.zeros(4, 4), torch.zeros(2, dtype=torch.int64))

@@ -14,7 +14,7 @@ import threading
 
 _PKG = pathlib.Path(__file__).resolve().parent
 LIB_PATH = _PKG / "libtwotower_hip.so"
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 TT_OK, TT_ERR_INVALID_ARG, TT_ERR_LAUNCH, TT_ERR_UNSUPPORTED, TT_ERR_WORKSPACE = range(5)
 TT_OPT_SGD, TT_OPT_ADAGRAD = 0, 1
@@ -54,6 +54,7 @@ SIGNATURES = {
     "tt_last_error": (C.c_char_p, []),
     "tt_profile_enable": (C.c_int, [C.c_char_p, _i32]),
     "tt_profile_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_float), _i32, C.POINTER(_i32)]),
+    "tt_profile_set_stride": (C.c_int, [_i32]),
     "tt_fill_uniform_f32": (C.c_int, [_p, _i64, _u64, _u64, _i64, _f, _f, _p]),
     "tt_fill_uniform_rows_f32": (C.c_int, [_p, _i64, _i32, _i64, _i64, _u64, _u64, _f, _f, _p]),
     "tt_fill_ids_i64": (C.c_int, [_p, _i64, _u64, _u64, _i64, _i64, _i32, _p]),
@@ -149,8 +150,13 @@ def profile_enable(tags: str = "", capacity: int = 4096) -> None:
     check(load().tt_profile_enable(tags.encode(), capacity), "tt_profile_enable")
 
 
+def profile_set_stride(stride: int) -> None:
+    """Bracket only every stride-th launch of a tag with hipEvents (each record stalls the stream for 4-7 us)."""
+    check(load().tt_profile_set_stride(stride), "tt_profile_set_stride")
+
+
 def profile_read(tag: str, capacity: int = 4096) -> tuple[list[float], int]:
-    """(durations in ms of the recorded launches, launches seen); synchronises and clears the tag."""
+    """(durations in ms of the recorded launches, their number); synchronises and clears the tag."""
     buf = (C.c_float * capacity)()
     n = _i32(0)
     check(load().tt_profile_read(tag.encode(), buf, capacity, C.byref(n)), "tt_profile_read")

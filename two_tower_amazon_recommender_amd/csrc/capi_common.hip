@@ -18,12 +18,14 @@ int fail(int code, const char* fmt, ...) {
 
 // ---- kernel timing --------------------------------------------------------------------------
 bool g_prof_on = false;
+int g_prof_stride = 1;
 namespace {
 struct ProfTag {
   std::string name;
   std::vector<hipEvent_t> ev;   // 2 per launch: begin, end
   int used = 0;                 // launches recorded
   int seen = 0;                 // launches seen (may exceed capacity)
+  bool skip = false;            // the begin of the launch in flight was not recorded (stride / capacity)
 };
 std::mutex g_prof_mu;
 std::vector<ProfTag> g_prof_tags;
@@ -39,16 +41,25 @@ void prof_record(const char* tag, hipStream_t stream, bool end) {
   ProfTag* t = find_tag(tag);
   if (t == nullptr) return;
   if (!end) {
-    if (2 * (t->used + 1) > (int)t->ev.size()) { ++t->seen; return; }
+    // every hipEventRecord is a barrier packet on the stream (4-7 us): with a stride only every n-th launch pays it
+    t->skip = (g_prof_stride > 1 && t->seen % g_prof_stride != 0) || 2 * (t->used + 1) > (int)t->ev.size();
+    if (t->skip) { ++t->seen; return; }
     (void)hipEventRecord(t->ev[2 * t->used], stream);
   } else {
-    if (t->seen > t->used) return;            // begin was dropped (capacity)
+    if (t->skip) { t->skip = false; return; }
     (void)hipEventRecord(t->ev[2 * t->used + 1], stream);
     ++t->used;
     ++t->seen;
   }
 }
 }  // namespace tt
+
+extern "C" int tt_profile_set_stride(int32_t stride) {
+  if (stride < 1) return tt::fail(TT_ERR_INVALID_ARG, "tt_profile_set_stride: stride must be >= 1");
+  std::lock_guard<std::mutex> lk(tt::g_prof_mu);
+  tt::g_prof_stride = stride;
+  return TT_OK;
+}
 
 extern "C" int tt_profile_enable(const char* tags_csv, int32_t capacity_per_tag) {
   std::lock_guard<std::mutex> lk(tt::g_prof_mu);
@@ -83,7 +94,7 @@ extern "C" int tt_profile_read(const char* tag, float* ms, int32_t cap, int32_t*
   std::lock_guard<std::mutex> lk(tt::g_prof_mu);
   tt::ProfTag* t = tt::find_tag(tag);
   if (t == nullptr) return tt::fail(TT_ERR_INVALID_ARG, "tt_profile_read: tag '%s' is not enabled", tag);
-  *count = t->seen;
+  *count = t->used < cap ? t->used : cap;
   for (int i = 0; i < t->used && i < cap; ++i) {
     if (hipEventSynchronize(t->ev[2 * i + 1]) != hipSuccess ||
         hipEventElapsedTime(&ms[i], t->ev[2 * i], t->ev[2 * i + 1]) != hipSuccess)
