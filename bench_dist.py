@@ -39,20 +39,22 @@ def run_distributed(args, rank, world, dev):
     iids = torch.empty(total, batch, dtype=torch.int64, device=dev)
     for s in range(total):
         trainer.synthetic_batch(seed, s, args.ids, out=(uids[s], iids[s]))
-    # TT_PREFETCH=1: hand the next batch's ids to step(): their routing + id all-to-all then run beside this step's
-    # scorer.  Off by default: on one rank (forced RCCL calls) the concurrent kernels cost the scorer more (+15 us)
-    # than the exposed exchange they hide; to be re-measured on a multi-GPU node.
-    prefetch = os.environ.get("TT_PREFETCH", "0") == "1"
+    # TT_PREFETCH=1: the next batch's ids are handed to step(), which routes them on a side stream beside this step's
+    # scorer; TT_PREFETCH=2 also issues their id all-to-all early.  Measured on one rank (forced RCCL calls) both cost
+    # more than they hide (0.888 -> 0.896 / 0.907 ms: every cross-stream hand-off is a 4-7 us bubble in the GPU queue
+    # and the early collective disturbs the scorer), so neither is the default until measured on a multi-GPU node.
+    pf = os.environ.get("TT_PREFETCH", "0")
+    prefetch, pf_exchange = pf in ("1", "2"), pf == "2"
     batches = [(uids[s], iids[s]) for s in range(total)] + [None]
     for s in range(args.warmup):
-        trainer.step(*batches[s], next_ids=batches[s + 1] if prefetch else None)
+        trainer.step(*batches[s], next_ids=batches[s + 1] if prefetch else None, prefetch_exchange=pf_exchange)
     torch.cuda.synchronize()
     trainer.check_ids()
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for s in range(args.warmup, total):
-        trainer.step(*batches[s], next_ids=batches[s + 1] if prefetch else None)
+        trainer.step(*batches[s], next_ids=batches[s + 1] if prefetch else None, prefetch_exchange=pf_exchange)
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()

@@ -406,8 +406,8 @@ def test_sharded_trainer_one_rank_rccl_collectives(dev, negatives, nb):
             u, i = batches[step]
             kw = {"category_ids": tr.synthetic_categories(37, step)} if nb else {}
             l1 = tr.step(u, i, **kw).clone()
-            # steps 0-1 hand the next step's ids over (route + id all-to-all run beside the scorer), step 2 does not
-            l2 = sh.step(u, i, next_ids=batches[step + 1] if step < 2 else None, **kw).clone()
+            # steps 0-1 hand the next step's ids over (routed beside the scorer; step 0 also issues their id all-to-all early)
+            l2 = sh.step(u, i, next_ids=batches[step + 1] if step < 2 else None, prefetch_exchange=(step == 0), **kw).clone()
             assert torch.equal(l1, l2)
         sh.check_ids()
         assert torch.equal(sh.user_table, tr.user_table) and torch.equal(sh.item_table, tr.item_table)

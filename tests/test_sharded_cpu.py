@@ -236,7 +236,7 @@ def _worker_combined(rank, world, port, ret):
                 em.lookup_rows()
                 em.lookup_finish(out)
                 if step + 1 < n_steps:
-                    em.lookup_prefetch(mine[step + 1])          # next step's route + id exchange, issued mid-step
+                    em.lookup_prefetch(mine[step + 1], exchange=(step % 2 == 0))   # next step's route (+ id exchange), issued mid-step
                 for t in range(2):
                     assert np.array_equal(out.numpy()[t * batch:(t + 1) * batch], fulls[t][ids[t][sl]])
                 em.grads_start(torch.from_numpy(np.concatenate([grads[0][sl], grads[1][sl]])))

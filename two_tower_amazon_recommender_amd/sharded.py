@@ -43,8 +43,11 @@ class HipRowBackend:
         self.ops = ops
         self.device = device
         self._plans = {}
-        self._side = torch.cuda.Stream(device=device)
-        self._pre = torch.cuda.Stream(device=device)
+        # High-priority streams: ROCm keeps a separate hardware-queue pool per priority, so these never land on the
+        # main stream's queue (with the default priority the sort plan ended up serialised behind the compute kernels
+        # whenever the stream -> queue round-robin happened to collide, e.g. after RCCL had created its streams)
+        self._side = torch.cuda.Stream(device=device, priority=-1)
+        self._pre = torch.cuda.Stream(device=device, priority=-1)
         self._pending = None
 
     @contextlib.contextmanager
@@ -120,6 +123,9 @@ class ShardedTables:
         self.backend = backend if backend is not None else HipRowBackend(device)
         n = w * nt * self.cap
         self.collectives = self.collectives or w > 1
+        import os
+        # TT_SYNC_OPS_INLINE=0: issue every exchange as an asynchronous op (the behaviour before r01h)
+        self.sync_ops_inline = os.environ.get("TT_SYNC_OPS_INLINE", "1") == "1"
         self.rows_out = torch.empty(n, dim, device=device)        # owner side: gathered rows / received grads
         # requester side: received rows / grads to send (one rank without collectives: the exchange is the identity)
         self.rows_in = torch.empty(n, dim, device=device) if self.collectives else self.rows_out
@@ -149,12 +155,18 @@ class ShardedTables:
     def accum_shard(self, t: int) -> torch.Tensor:
         return self.accum[self.offsets[t]:self.offsets[t] + shard_rows(self.num_rows[t], self.world, self.rank)]
 
-    def _a2a(self, out, inp):
-        """Asynchronous all-to-all (returns the work handle; None on one rank).  ``wait()`` on an NCCL work makes the
-        current stream wait for the collective without blocking the host, so independent kernels issued before
-        the wait overlap the transfer."""
-        if self.collectives:
+    def _a2a(self, out, inp, overlap: bool = True):
+        """All-to-all; returns a work handle to ``wait()`` on, or None.
+        overlap=True: asynchronous (the collective runs on the backend's own stream; ``wait()`` makes the current
+        stream wait for it without blocking the host, so kernels issued before the wait overlap the transfer).
+        overlap=False: for an exchange whose result is needed at once — issued as a synchronous op, which
+        ProcessGroupNCCL (torch >= 2.7) enqueues on the CURRENT stream: no event hand-offs to and from a second
+        stream (each costs the GPU queue 4-7 us); the host is not blocked either way."""
+        if not self.collectives:
+            return None
+        if overlap or not self.sync_ops_inline:
             return dist.all_to_all_single(out, inp, group=self.group, async_op=True)
+        dist.all_to_all_single(out, inp, group=self.group, async_op=False)
         return None
 
     @staticmethod
@@ -170,29 +182,33 @@ class ShardedTables:
         pre, self._prefetched = self._prefetched, None
         if pre is not None and len(pre[0]) == len(ids_list) and all(a is b for a, b in zip(pre[0], ids_list)):
             self._cur = 1 - self._cur
-            self._w = pre[1]
             self.backend.join_prefetch()
+            # routed ahead of time; the id exchange is either already on its way or starts now
+            self._w = pre[1] if pre[2] else self._a2a(self.recv_ids, self.send_ids, overlap=False)
             return
         if pre is not None:                       # prefetched for other ids: let that exchange finish, then ignore it
             self._wait(pre[1])
             self.backend.join_prefetch()
         self.backend.route(ids_list, self.world, self.num_rows, self.offsets, self.cap, self.send_ids, self.pos_flats,
                            self.flags)
-        self._w = self._a2a(self.recv_ids, self.send_ids)                          # C1
+        self._w = self._a2a(self.recv_ids, self.send_ids, overlap=False)           # C1
 
-    def lookup_prefetch(self, ids_list):
-        """route + C1 of the NEXT step's ids (they do not depend on the tables) into the other id-buffer set, on a side
-        stream: the id exchange leaves the next step's critical path.  Call it after lookup_finish(), when the
-        collective queue is idle and the long scorer kernels are about to run."""
+    def lookup_prefetch(self, ids_list, exchange: bool = False):
+        """Route the NEXT step's ids (they do not depend on the tables) into the other id-buffer set on a side stream,
+        so the single-workgroup routing kernel (~12 us) leaves the next step's critical path.  exchange=True also
+        issues their id all-to-all (C1) there; on one rank that costs more than it hides (the collective's kernel
+        disturbs the scorer), so it is off by default.  Call it after lookup_finish()."""
         ids_list = list(ids_list)
         nxt = 1 - self._cur
         if self._idbufs[nxt] is None:
             self._idbufs[nxt] = self._make_idbufs()
         send, recv, _, pos_flats = self._idbufs[nxt]
+        work = None
         with self.backend.prefetch_stream():
             self.backend.route(ids_list, self.world, self.num_rows, self.offsets, self.cap, send, pos_flats, self.flags)
-            work = self._a2a(recv, send)                                           # C1 of the next step
-        self._prefetched = (ids_list, work)
+            if exchange:
+                work = self._a2a(recv, send)                                       # C1 of the next step
+        self._prefetched = (ids_list, work, exchange)
 
     def lookup_rows(self):
         """owner side: sort plan (side stream), K1 gather, C2 (rows back to the requesters)."""
@@ -200,7 +216,7 @@ class ShardedTables:
         be = self.backend
         be.plan(self.recv_ids, self.table.shape[0])
         be.gather(self.table, self.recv_ids, self.rows_out, self.flags[0:1])       # K1
-        self._w = self._a2a(self.rows_in, self.rows_out)                           # C2
+        self._w = self._a2a(self.rows_in, self.rows_out, overlap=False)            # C2
 
     def lookup_finish(self, out: torch.Tensor):
         """K1': out[t*batch + p, :] = row of position p of table t."""
@@ -250,8 +266,8 @@ class ShardedEmbedding(ShardedTables):
     def lookup_start(self, ids):
         super().lookup_start([ids])
 
-    def lookup_prefetch(self, ids):
-        super().lookup_prefetch([ids])
+    def lookup_prefetch(self, ids, exchange: bool = False):
+        super().lookup_prefetch([ids], exchange)
 
     def lookup(self, ids, out):
         self.lookup_start(ids)
@@ -390,10 +406,11 @@ class ShardedTwoTowerTrainer:
         return self.p_all
 
     def step(self, user_ids: torch.Tensor, item_ids: torch.Tensor, next_ids=None, category_ids=None,
-             candidate_sampling_probability=None) -> torch.Tensor:
+             candidate_sampling_probability=None, prefetch_exchange: bool = False) -> torch.Tensor:
         """One train step on this rank's batch; returns this rank's (device, unsynchronised) loss.
-        next_ids = (user_ids, item_ids) of the following step, if the input pipeline already has them: their
-        routing and id all-to-all then run beside this step's scorer (pass the same tensors to the next call)."""
+        next_ids = (user_ids, item_ids) of the following step, if the input pipeline already has them: they are
+        routed beside this step's scorer (and, with prefetch_exchange, their id all-to-all is issued there too); pass
+        the same tensors to the next call."""
         from .trainer import towers_forward, towers_backward
         cfg, ops, ut, it, em = self.cfg, self.ops, self.user_tower, self.item_tower, self.emb
         b, w = cfg.batch_size, self.world
@@ -410,7 +427,7 @@ class ShardedTwoTowerTrainer:
         if category_ids is not None:
             ops.embedding_gather_add_(it.acts[0], self.cat_table, category_ids, em.flags[0:1])
         if next_ids is not None:
-            em.lookup_prefetch(next_ids)
+            em.lookup_prefetch(next_ids, prefetch_exchange)
         row0 = (self.step_index * w + self.rank) * b          # first global batch row of this rank
         if cfg.symmetric:
             q, c = towers_forward(ut, it, (cfg.dropout_rate, self.dropout_seed, row0))
@@ -456,9 +473,15 @@ class ShardedTwoTowerTrainer:
                                         cfg.adagrad_epsilon)
         else:
             ops.dense_update_(self._segs_reduce, cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon, apply=False)
-            ar = dist.all_reduce(self.dense_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)   # C6
-            em.grads_finish(cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon)
-            ar.wait()
+            if em.sync_ops_inline:
+                # C6 on the current stream, after the owner update (which waits for C3): the ~12 us of sparse update it
+                # could have overlapped are less than the two cross-stream hand-offs of an asynchronous op cost
+                em.grads_finish(cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon)
+                dist.all_reduce(self.dense_grad, op=dist.ReduceOp.SUM, group=self.group)                   # C6
+            else:
+                ar = dist.all_reduce(self.dense_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                em.grads_finish(cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon)
+                ar.wait()
             ops.dense_update_(self._segs_apply, cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon, apply=True)
         return self.loss
 

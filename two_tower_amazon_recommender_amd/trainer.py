@@ -222,7 +222,9 @@ class TwoTowerTrainer:
             self.cat_table = torch.empty(cfg.n_category_buckets, d, device=dev)
             self.cat_accum = torch.full_like(self.cat_table, cfg.adagrad_initial_accumulator) if adagrad else None
             self.cat_plan = ops.SparsePlan(b, dev)
-        self._side = torch.cuda.Stream(device=dev)
+        # high priority = a hardware queue of its own (ROCm pools queues per priority): the sort plans always run BESIDE
+        # the main stream's kernels, whatever other streams the process has created
+        self._side = torch.cuda.Stream(device=dev, priority=-1)
         self.step_index = 0                      # counter of the dropout stream (global batch row = step*batch + r)
         self.dropout_seed = 0 if seed is None else seed
         self._segs = self.user_tower.segments(cfg.l2_regularization) + self.item_tower.segments(cfg.l2_regularization)
