@@ -33,7 +33,8 @@ def run_distributed(args, rank, world, dev):
     # TT_FORCE_COLLECTIVES=1: issue the RCCL calls even on one rank (their launch cost without any xGMI traffic)
     trainer = ShardedTwoTowerTrainer(cfg, dev, seed=seed, negatives=negatives,
                                      capacity_factor=float(os.environ.get("TT_CAPACITY_FACTOR", 2.0)),
-                                     force_collectives=bool(os.environ.get("TT_FORCE_COLLECTIVES")))
+                                     force_collectives=bool(os.environ.get("TT_FORCE_COLLECTIVES")),
+                                     sync_ops_inline=os.environ.get("TT_SYNC_OPS_INLINE", "1") == "1")
     total = args.warmup + args.steps
     uids = torch.empty(total, batch, dtype=torch.int64, device=dev)
     iids = torch.empty(total, batch, dtype=torch.int64, device=dev)

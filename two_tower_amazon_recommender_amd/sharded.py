@@ -99,7 +99,7 @@ class ShardedTables:
 
     def __init__(self, num_rows, dim: int, batch: int, device, group=None, capacity_factor: float = 2.0,
                  backend=None, table: torch.Tensor | None = None, accum: torch.Tensor | None = None,
-                 force_collectives: bool = False):
+                 force_collectives: bool = False, sync_ops_inline: bool = True):
         self.group = group
         # force_collectives: issue the collectives even in a one-rank group (exercises the RCCL calls on one GPU)
         self.collectives = force_collectives and dist.is_initialized()
@@ -123,9 +123,8 @@ class ShardedTables:
         self.backend = backend if backend is not None else HipRowBackend(device)
         n = w * nt * self.cap
         self.collectives = self.collectives or w > 1
-        import os
-        # TT_SYNC_OPS_INLINE=0: issue every exchange as an asynchronous op (the behaviour before r01h)
-        self.sync_ops_inline = os.environ.get("TT_SYNC_OPS_INLINE", "1") == "1"
+        # sync_ops_inline=False: issue every exchange as an asynchronous op (the behaviour before r01h)
+        self.sync_ops_inline = sync_ops_inline
         self.rows_out = torch.empty(n, dim, device=device)        # owner side: gathered rows / received grads
         # requester side: received rows / grads to send (one rank without collectives: the exchange is the identity)
         self.rows_in = torch.empty(n, dim, device=device) if self.collectives else self.rows_out
@@ -291,7 +290,7 @@ class ShardedTwoTowerTrainer:
     """
 
     def __init__(self, cfg, device, group=None, seed: int | None = None, negatives: str = "local",
-                 capacity_factor: float = 2.0, force_collectives: bool = False):
+                 capacity_factor: float = 2.0, force_collectives: bool = False, sync_ops_inline: bool = True):
         from . import ops
         from .trainer import Tower, TID_USER_TABLE, TID_ITEM_TABLE
         cfg.validate()
@@ -307,7 +306,7 @@ class ShardedTwoTowerTrainer:
         adagrad = cfg.optimizer == "adagrad"
         # both tables behind one set of exchange buffers: 3 all-to-alls per step, one owner-side gather/sort/update
         self.emb = ShardedTables([cfg.n_users, cfg.n_items], d, b, dev, group, capacity_factor,
-                                 force_collectives=force_collectives)
+                                 force_collectives=force_collectives, sync_ops_inline=sync_ops_inline)
         self.collectives = self.emb.collectives
         if adagrad:
             self.emb.accum = torch.full_like(self.emb.table, cfg.adagrad_initial_accumulator)
