@@ -29,6 +29,7 @@ namespace {
 
 using tt::f32x4;
 using tt::f32x16;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr float kLog2e = 1.44269504088896340736f;
 constexpr float kLn2 = 0.69314718055994530942f;
@@ -276,10 +277,20 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? 2 : 1))) 
       run_m = m_new;
     } else {
       if constexpr (MODE == MODE_BWD) {
+        // the fma and the add as packed f32 pairs (v_pk_fma_f32 / v_pk_add_f32: same roundings, half the VALU
+        // issue slots — VALU cycles are not hidden behind f32 MFMAs)
+        float tvs[16];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const f32x2 x2 = f32x2{X[2 * q], X[2 * q + 1]}, a2 = f32x2{ac[2 * q], ac[2 * q + 1]};
+          const f32x2 t2 = __builtin_elementwise_fma(x2, f32x2{p.c1, p.c1}, a2) + f32x2{ar, ar};
+          tvs[2 * q] = t2[0];
+          tvs[2 * q + 1] = t2[1];
+        }
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
           const float w = sc[reg] * sr;
-          float tv = __builtin_fmaf(X[reg], p.c1, ac[reg]) + ar;
+          float tv = tvs[reg];
           if constexpr (hn) tv = (tv < hth[reg] && tt::acc_row(reg, 0) != dloc) ? kNegBig : tv;
           float e = __builtin_amdgcn_exp2f(tv) * w;
           if constexpr (HAS_IDS) e = dup[reg] ? 0.f : e;
@@ -295,9 +306,17 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? 2 : 1))) 
         // carry sum_c p*K[c] at scale m_row.  Both lane halves of a row share ONE running max (GEMM2 sums
         // over both halves' c).  Lazy rescale (threshold kRescaleThr): wave-uniform branch.
         float mx = kNegBig;
+        float vs[16];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {      // packed f32 pairs: v_pk_fma_f32
+          const f32x2 x2 = f32x2{X[2 * q], X[2 * q + 1]}, a2 = f32x2{ac[2 * q], ac[2 * q + 1]};
+          const f32x2 t2 = __builtin_elementwise_fma(x2, f32x2{p.c1, p.c1}, a2);
+          vs[2 * q] = t2[0];
+          vs[2 * q + 1] = t2[1];
+        }
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
-          float v = __builtin_fmaf(X[reg], p.c1, ac[reg]);
+          float v = vs[reg];
           if constexpr (HAS_IDS) v = dup[reg] ? kNegBig : v;
           if constexpr (hn) v = (v < hth[reg] && tt::acc_row(reg, 0) != dloc) ? kNegBig : v;
           coef[reg] = v;
@@ -321,10 +340,15 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? 2 : 1))) 
         }
         float sum = 0.f;
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          coef[reg] = __builtin_amdgcn_exp2f(coef[reg] - run_m);
-          sum += coef[reg];
+        for (int q = 0; q < 8; ++q) {      // the subtraction as packed pairs (v_pk_add_f32 with negated operand)
+          const f32x2 d2 = f32x2{coef[2 * q], coef[2 * q + 1]} - f32x2{run_m, run_m};
+          coef[2 * q] = __builtin_amdgcn_exp2f(d2[0]);
+          coef[2 * q + 1] = __builtin_amdgcn_exp2f(d2[1]);
         }
+        f32x2 s2 = f32x2{coef[0], coef[1]};           // 8 packed adds + 1 instead of 16 sequential ones
+#pragma unroll
+        for (int q = 1; q < 8; ++q) s2 += f32x2{coef[2 * q], coef[2 * q + 1]};
+        sum = s2[0] + s2[1];
         run_l += sum;
       }
     }
