@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TT_ABI_VERSION 4
+#define TT_ABI_VERSION 5
 
 enum {
   TT_OK = 0,
@@ -117,23 +117,42 @@ int tt_hash_bucket_u8(const uint8_t* rows_u8, int64_t n, int32_t width, int64_t 
  * duplicates summed before the update; configs/data_config.yaml:63 learning_rate).
  *
  * tt_sparse_plan: stable sort of (id, position) by id.  Outputs
- *   sorted_ids [n_ids] int64, order [n_ids] int32 (positions, ascending inside equal ids).
- * Only the ids are needed, so the plan can run before / beside the forward pass.
+ *   sorted_ids [n_ids] int64 ascending, order [n_ids] int32 (positions, ascending inside equal ids).
+ *   Every id outside [0, num_rows) (the padding id -1 included) is written to sorted_ids as the sentinel
+ *   2^bits - 1 >= num_rows (bits = bit length of num_rows): such ids sort last, can never cut the run of a
+ *   valid id, and the apply kernels skip them.
+ * Only the ids are needed, so the plan can run before / beside the forward pass.  Up to
+ * tt_sparse_plan_max_lds_ids() ids per table the sort is ONE launch of a hand-written LDS radix sort (one
+ * workgroup per table; tt_sparse_plan_batched sorts up to 4 tables — user, item, hashed category — in that one
+ * launch) and needs no workspace; longer lists fall back to rocPRIM's device radix sort (workspace required).
  *
  * tt_sparse_{sgd,adagrad}_f32: for every distinct id u (rows >= num_rows are skipped):
  *   g  = sum of grads[p, :] over the positions p of u in ascending p.  Order of the f32 adds: the run of u in
  *        the sorted list is cut at global multiples of 64 sorted slots; each piece is summed sequentially, then
- *        the pieces are added in order (a run inside one 64-slot block is a plain sequential sum).
+ *        the pieces are added in order (a run inside one 64-slot block is a plain sequential sum).  The pieces
+ *        of a run that crosses a block boundary are summed by different lane groups; the last one to arrive
+ *        (a ticket in apply_ws) adds them in index order and applies the update — one launch in every case.
  *   apply_ws: tt_sparse_apply_workspace_bytes(n_ids, dim) bytes per table, 256-byte aligned (piece sums);
  *        ZERO it once after allocation — the kernels leave it zeroed.
  *   SGD:      w[u] = w[u] - fl(lr*g)
  *   Adagrad:  acc[u] += g*g ; w[u] -= fl(lr*g) / sqrt(acc[u] + eps)      (Keras 2.15)
  * In place.  The `2` forms update the user and the item table in one launch.             */
+typedef struct tt_sparse_plan_args {
+  const int64_t* ids;        /* [n_ids] */
+  int64_t n_ids;
+  int64_t num_rows;
+  void* workspace;           /* tt_sparse_plan_workspace_bytes(n_ids) bytes; may be NULL when n_ids <= max_lds_ids */
+  int64_t workspace_bytes;
+  int64_t* sorted_ids;       /* [n_ids] out */
+  int32_t* order;            /* [n_ids] out */
+} tt_sparse_plan_args;
+int32_t tt_sparse_plan_max_lds_ids(void);
 int64_t tt_sparse_plan_workspace_bytes(int64_t n_ids);
 int64_t tt_sparse_apply_workspace_bytes(int64_t n_ids, int32_t dim);
 int tt_sparse_plan(const int64_t* ids, int64_t n_ids, int64_t num_rows,
                    void* workspace, int64_t workspace_bytes,
                    int64_t* sorted_ids, int32_t* order, tt_stream_t stream);
+int tt_sparse_plan_batched(const tt_sparse_plan_args* tables, int32_t n_tables, tt_stream_t stream);
 int tt_sparse_sgd_f32(float* table, int64_t num_rows, int32_t dim,
                       const float* grads, const int64_t* sorted_ids, const int32_t* order,
                       int64_t n_ids, float lr, void* apply_ws, tt_stream_t stream);

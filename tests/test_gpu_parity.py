@@ -158,6 +158,64 @@ def test_sparse_sgd_bit_exact(dev, rows, dim, n, variant):
         assert np.array_equal(d_table.cpu().numpy(), ref)     # untouched rows unchanged
 
 
+def _np_plan(ids, rows):
+    """The plan's contract: stable sort by the CLAMPED key (ids outside [0, rows) -> sentinel 2^bits - 1, sorted last)."""
+    bits = 1
+    while (1 << bits) < rows + 1:
+        bits += 1
+    key = np.where((ids >= 0) & (ids < rows), ids, (1 << bits) - 1)
+    o = np.argsort(key, kind="stable")
+    return key[o], o.astype(np.int32)
+
+
+@pytest.mark.parametrize("n,rows,variant", [(1, 10, "U"), (63, 30, "Z"), (513, 1000, "U"), (4096, 1 << 20, "U"),
+                                            (8192, 10_000_000, "U"), (8192, 5_000_000, "Z"), (8192, 30, "Z"),
+                                            (8192, 100_000_000, "Z"), (16384, 100_000_000, "U"), (12345, 70_000, "Z"),
+                                            (16385, 10_000_000, "Z"), (40000, 257, "U")])
+def test_sort_plan_is_a_stable_sort_for_every_size_and_key_width(dev, n, rows, variant):
+    """<= 16384 ids: the hand-written one-launch LDS radix sort (1-4 passes of 8/9-bit digits); above: rocPRIM."""
+    ids = synth.batch_ids(31, 3, 0, n, rows, variant)
+    plan = ops.SparsePlan(n, dev).run(T(ids, dev), rows)
+    sk, so = _np_plan(ids, rows)
+    assert np.array_equal(plan.sorted_ids.cpu().numpy(), sk)
+    assert np.array_equal(plan.order.cpu().numpy(), so)
+
+
+def test_sort_plan_batched_three_tables_one_launch_with_padding_and_out_of_range_ids(dev):
+    n = 8192
+    rows = [5_000_000, 10_000_000, 30]
+    ids = [synth.batch_ids(32, 3 + t, 0, n, r, "Z" if t else "U") for t, r in enumerate(rows)]
+    ids[0][100:200] = -1                          # padding slots of the sharded exchange
+    ids[1][7] = 10_000_000 + 5                    # out of range
+    ids[1][9] = -77
+    plans = [ops.SparsePlan(n, dev) for _ in rows]
+    ops.sparse_plan_batched(plans, [T(i, dev) for i in ids], rows)
+    for p, i, r in zip(plans, ids, rows):
+        sk, so = _np_plan(i, r)
+        assert np.array_equal(p.sorted_ids.cpu().numpy(), sk)
+        assert np.array_equal(p.order.cpu().numpy(), so)
+
+
+def test_out_of_range_id_cannot_alias_a_valid_row(dev):
+    """ids = {v, v + 2^bits, v}: the out-of-range id shares v's low bits; it must not cut v's run (two heads would
+    both read-modify-write row v).  Row v receives exactly the summed gradient, once."""
+    rows, dim, v = 1000, 64, 5                    # bits = 10
+    ids = np.array([v, v + 1024, v, 3, v + 2048, v], dtype=np.int64)
+    grads = synth.uniform_f32(33, 9, len(ids) * dim, -1.0, 2.0).reshape(len(ids), dim)
+    table = synth.embedding_table(33, 1, rows, dim)
+    for opt in ("sgd", "adagrad"):
+        d_table, d_acc = T(table, dev), torch.full((rows, dim), 0.1, device=dev)
+        plan = ops.SparsePlan(len(ids), dev).run(T(ids, dev), rows)
+        valid = ids < rows
+        if opt == "sgd":
+            ops.sparse_sgd_(d_table, T(grads, dev), plan, lr=0.01)
+            ref = tt.sparse_sgd(table.copy(), ids[valid], grads[valid], 0.01)
+        else:
+            ops.sparse_adagrad_(d_table, d_acc, T(grads, dev), plan, lr=0.01)
+            ref, _ = tt.sparse_adagrad(table.copy(), np.full_like(table, np.float32(0.1)), ids[valid], grads[valid], 0.01)
+        assert np.array_equal(d_table.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+
+
 @pytest.mark.parametrize("variant", ["U", "Z"])
 def test_sparse_adagrad_within_2ulp(dev, variant):
     rows, dim, n = 500_000, 128, 8192
@@ -197,11 +255,12 @@ def test_sparse_update2_both_tables_one_launch(dev):
             assert np.allclose(da.cpu().numpy(), ra, rtol=3e-7, atol=0) and np.allclose(db.cpu().numpy(), rb, rtol=3e-7, atol=0)
 
 
-@pytest.mark.parametrize("opt", ["sgd", "adagrad"])
-def test_sparse_heavy_hitters_are_split_into_pieces_bit_exact(dev, opt):
+@pytest.mark.parametrize("opt,n", [("sgd", 20000), ("adagrad", 20000), ("sgd", 15000), ("adagrad", 16384)])
+def test_sparse_heavy_hitters_are_split_into_pieces_bit_exact(dev, opt, n):
     """One id repeated thousands of times (runs far longer than 64 sorted slots, starting mid-block, several in a row)
-    must give exactly the oracle's piecewise sum — and fast (many lane groups work on one run)."""
-    rows, dim, n = 1000, 128, 20000
+    must give exactly the oracle's piecewise sum — and fast (many lane groups work on one run; the last piece to
+    arrive adds them in index order).  n = 20000: rocPRIM plan; <= 16384: the LDS sort."""
+    rows, dim = 1000, 128
     rng = np.random.default_rng(11)
     ids = np.concatenate([np.full(7000, 17), np.full(129, 18), np.full(64, 400), np.full(5000, 999),
                           rng.integers(0, rows, n - 7000 - 129 - 64 - 5000)]).astype(np.int64)

@@ -14,7 +14,7 @@ import threading
 
 _PKG = pathlib.Path(__file__).resolve().parent
 LIB_PATH = _PKG / "libtwotower_hip.so"
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 TT_OK, TT_ERR_INVALID_ARG, TT_ERR_LAUNCH, TT_ERR_UNSUPPORTED, TT_ERR_WORKSPACE = range(5)
 TT_OPT_SGD, TT_OPT_ADAGRAD = 0, 1
@@ -36,6 +36,12 @@ class DenseBwdArgs(C.Structure):
 class RouteTable(C.Structure):
     """Mirror of ``tt_route_table`` (include/twotower_hip.h)."""
     _fields_ = [("ids", C.c_void_p), ("num_rows", C.c_int64), ("local_offset", C.c_int64), ("pos_flat", C.c_void_p)]
+
+
+class SparsePlanArgs(C.Structure):
+    """Mirror of ``tt_sparse_plan_args``."""
+    _fields_ = [("ids", C.c_void_p), ("n_ids", C.c_int64), ("num_rows", C.c_int64), ("workspace", C.c_void_p),
+                ("workspace_bytes", C.c_int64), ("sorted_ids", C.c_void_p), ("order", C.c_void_p)]
 
 
 class DenseSeg(C.Structure):
@@ -69,6 +75,8 @@ SIGNATURES = {
     "tt_scatter_rows_f32": (C.c_int, [_p, _p, _i64, _i32, _p, _i64, _p]),
     "tt_sparse_plan_workspace_bytes": (_i64, [_i64]),
     "tt_sparse_plan": (C.c_int, [_p, _i64, _i64, _p, _i64, _p, _p, _p]),
+    "tt_sparse_plan_batched": (C.c_int, [_p, _i32, _p]),
+    "tt_sparse_plan_max_lds_ids": (_i32, []),
     "tt_sparse_apply_workspace_bytes": (_i64, [_i64, _i32]),
     "tt_sparse_sgd_f32": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _i64, _f, _p, _p]),
     "tt_sparse_adagrad_f32": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _i64, _f, _f, _p, _p]),

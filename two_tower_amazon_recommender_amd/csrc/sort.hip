@@ -1,0 +1,263 @@
+// K2 plan — stable sort of (id, position) by id for the fused sparse optimizer.
+//
+// One launch, one 512/1024-thread workgroup per TABLE (user, item and the hashed-category table of a step sort side by
+// side on three CUs): an LSD radix sort that lives entirely in LDS.  Keys are the ids clamped to 32 bits — every id
+// outside [0, num_rows) becomes the sentinel 2^bits - 1 >= num_rows, so an out-of-range id can never alias (and cut
+// the run of) a valid one; the apply kernel skips the sentinel like any other out-of-range id.  ceil(bits / 9) passes
+// of 8- or 9-bit digits (24 bits = 10 M rows: 3 passes; 27 bits = 100 M rows: 3 passes).  Per pass and wave:
+//   rank   the 64 lanes of a round find their equal-digit peers with DBITS ballots (match-any), the first peer bumps
+//          the wave's digit counter in LDS — rounds in element order, so equal digits keep their order (stable);
+//   scan   digit-major, wave-minor exclusive scan of the 16 x 2^DBITS counters;
+//   move   keys and positions (u16) scatter inside LDS.
+// Integer-only, LDS-bound; 8192 ids: ~8 us on one CU, on a side stream beside the forward pass (rocPRIM's device radix
+// sort needs 6 launches / ~65 us for the same job).  Above 16384 ids (32-bit keys + 16-bit positions + counters no
+// longer fit 160 KiB of LDS) tt_sparse_plan falls back to rocPRIM with the same clamped keys.
+#include "common.h"
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
+
+namespace {
+
+constexpr int kMaxLdsSortIds = 16384;
+constexpr int kMaxTables = 4;
+
+int id_bits(int64_t num_rows) {
+  int bits = 1;
+  while (bits < 63 && ((int64_t)1 << bits) < num_rows) ++bits;
+  return bits;
+}
+
+struct SortTable {
+  const int64_t* ids;
+  int64_t* sorted_ids;
+  int32_t* order;
+  int64_t num_rows;
+  int32_t n;
+  int32_t npass;
+  uint32_t sentinel;
+};
+struct SortBatch {
+  SortTable t[kMaxTables];
+};
+
+template <int DBITS>
+__device__ __forceinline__ uint64_t match_any(uint32_t d) {
+  // per bit: the lane's bit as an all-ones / all-zeros word (v_bfe_i32), one v_cmp (= the ballot), and for each half
+  // of the mask  peers &= ~(ballot ^ word)  (v_xnor + v_and): 6 VALU instructions per bit
+  uint32_t lo = ~0u, hi = ~0u;
+#pragma unroll
+  for (int b = 0; b < DBITS; ++b) {
+    const int32_t word = ((int32_t)(d << (31 - b))) >> 31;
+    const uint64_t m = __builtin_amdgcn_ballot_w64(word != 0);
+    lo &= ~((uint32_t)m ^ (uint32_t)word);
+    hi &= ~((uint32_t)(m >> 32) ^ (uint32_t)word);
+  }
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// element i of the workgroup's sequence sits in (wave, round, lane) = (i / (64*ITEMS), (i / 64) % ITEMS, i % 64)
+template <int ITEMS, int DBITS>
+__global__ __launch_bounds__(1024) void lds_sort_kernel(SortBatch batch) {
+  constexpr int RADIX = 1 << DBITS;
+  constexpr int MAXW = 16;
+  const SortTable t = batch.t[blockIdx.x];
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const int T = blockDim.x, W = T >> 6;
+  const int cap = T * ITEMS;
+  uint32_t* keys = smem;                                   // [cap]
+  uint32_t* cnt = keys + cap;                              // [W][RADIX]
+  uint32_t* wtot = cnt + W * RADIX;                        // [16]
+  uint16_t* poss = reinterpret_cast<uint16_t*>(wtot + 16); // [cap]
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int n = t.n;
+  uint32_t* mycnt = cnt + w * RADIX;
+  uint32_t key[ITEMS], pos[ITEMS];
+#pragma unroll
+  for (int r = 0; r < ITEMS; ++r) {
+    const int i = (w * ITEMS + r) * 64 + lane;
+    pos[r] = (uint32_t)i;
+    const int64_t id = t.ids[i < n ? i : 0];               // unconditional: all ITEMS loads in flight together
+    // slots past n get the sentinel too and sort behind everything (stable: their pos is >= n)
+    key[r] = (i < n && id >= 0 && id < t.num_rows) ? (uint32_t)id : t.sentinel;
+  }
+
+  for (int p = 0; p < t.npass; ++p) {
+    const int shift = p * DBITS;
+    for (int j = lane; j < RADIX; j += 64) mycnt[j] = 0u;
+    // ---- rank inside the wave.  All ballots first (VALU/SALU only), then the leaders' counter bumps as LDS atomics
+    // issued back to back: the LDS executes one wave's instructions in order, so round r sees the bumps of rounds < r
+    // without a round trip per round; the old value reaches the other peers through one ds_bpermute each. ----
+    uint32_t dg[ITEMS], rk[ITEMS], lead[ITEMS], old[ITEMS];
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+      dg[r] = (key[r] >> shift) & (RADIX - 1);
+      const uint64_t peers = match_any<DBITS>(dg[r]);
+      rk[r] = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+      lead[r] = (uint32_t)__ffsll((unsigned long long)peers) - 1u;
+      old[r] = (uint32_t)__popcll(peers);                  // the leader's increment
+    }
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+      if (rk[r] == 0u) old[r] = atomicAdd(&mycnt[dg[r]], old[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) old[r] = (uint32_t)__shfl((int)old[r], (int)lead[r]) + rk[r];   // rank inside this wave
+    __syncthreads();
+    // ---- exclusive scan, digit-major / wave-minor; the base of the digit is folded into the per-wave offsets ----
+    uint32_t v[MAXW], total = 0u;
+    if (tid < RADIX) {
+#pragma unroll
+      for (int ww = 0; ww < MAXW; ++ww) v[ww] = ww < W ? cnt[ww * RADIX + tid] : 0u;
+#pragma unroll
+      for (int ww = 0; ww < MAXW; ++ww) {
+        const uint32_t x = v[ww];
+        v[ww] = total;
+        total += x;
+      }
+    }
+    uint32_t incl = total;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+      if (lane >= o) incl += up;
+    }
+    if (lane == 63) wtot[w] = incl;
+    __syncthreads();
+    if (tid < RADIX) {
+      uint32_t base = incl - total;
+      for (int ww = 0; ww < w; ++ww) base += wtot[ww];
+#pragma unroll
+      for (int ww = 0; ww < MAXW; ++ww)
+        if (ww < W) cnt[ww * RADIX + tid] = base + v[ww];
+    }
+    __syncthreads();
+    // ---- move ----
+    if (p + 1 < t.npass) {
+      uint32_t dst[ITEMS];
+#pragma unroll
+      for (int r = 0; r < ITEMS; ++r) dst[r] = mycnt[dg[r]] + old[r];
+#pragma unroll
+      for (int r = 0; r < ITEMS; ++r) {
+        keys[dst[r]] = key[r];
+        poss[dst[r]] = (uint16_t)pos[r];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < ITEMS; ++r) {
+        const int i = (w * ITEMS + r) * 64 + lane;
+        key[r] = keys[i];
+        pos[r] = poss[i];
+      }
+    } else {
+      // last pass: straight to global (8-byte / 4-byte scattered stores; n <= 16384 of them)
+#pragma unroll
+      for (int r = 0; r < ITEMS; ++r) {
+        const uint32_t dst = mycnt[dg[r]] + old[r];
+        if (dst < (uint32_t)n) {
+          t.sorted_ids[dst] = (int64_t)key[r];
+          t.order[dst] = (int32_t)pos[r];
+        }
+      }
+    }
+  }
+}
+
+int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+struct ClampKey {
+  int64_t rows, sentinel;
+  __host__ __device__ int64_t operator()(int64_t id) const { return (id >= 0 && id < rows) ? id : sentinel; }
+};
+using ClampIt = rocprim::transform_iterator<const int64_t*, ClampKey, int64_t>;
+
+size_t rocprim_temp_bytes(int64_t n_ids) {
+  size_t bytes = 0;
+  int64_t* kout = nullptr;
+  int32_t* vout = nullptr;
+  ClampIt kin(nullptr, ClampKey{1, 1});
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, rocprim::counting_iterator<int32_t>(0), vout, (size_t)n_ids, 0u, 64u,
+                                  (hipStream_t) nullptr, false);
+  return bytes;
+}
+
+template <int ITEMS, int DBITS>
+int launch_lds_sort(const SortBatch& b, int n_tables, int threads, hipStream_t stream) {
+  const int W = threads / 64, cap = threads * ITEMS, radix = 1 << DBITS;
+  const int lds = (cap + W * radix + 16) * 4 + cap * 2;
+  auto kern = lds_sort_kernel<ITEMS, DBITS>;
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+    return tt::fail(TT_ERR_LAUNCH, "tt_sparse_plan: hipFuncSetAttribute(LDS %d) failed", lds);
+  tt::ProfScope prof("sparse_plan", stream);
+  hipLaunchKernelGGL(kern, dim3((unsigned)n_tables), dim3((unsigned)threads), lds, stream, b);
+  return tt::check_launch("tt_sparse_plan");
+}
+
+int plan_rocprim(const tt_sparse_plan_args& a, hipStream_t stream) {
+  const size_t temp = rocprim_temp_bytes(a.n_ids);
+  if ((int64_t)temp > a.workspace_bytes)
+    return tt::fail(TT_ERR_WORKSPACE, "tt_sparse_plan: workspace %lld < %lld bytes", (long long)a.workspace_bytes, (long long)temp);
+  TT_REQUIRE(a.workspace != nullptr, "tt_sparse_plan: null workspace");
+  const int bits = id_bits(a.num_rows + 1);
+  ClampIt kin(a.ids, ClampKey{a.num_rows, ((int64_t)1 << bits) - 1});
+  size_t tb = temp;
+  tt::ProfScope prof("sparse_plan", stream);
+  hipError_t e = rocprim::radix_sort_pairs(a.workspace, tb, kin, a.sorted_ids, rocprim::counting_iterator<int32_t>(0), a.order,
+                                           (size_t)a.n_ids, 0u, (unsigned)bits, stream, false);
+  if (e != hipSuccess) return tt::fail(TT_ERR_LAUNCH, "tt_sparse_plan: rocprim radix sort: %s", hipGetErrorString(e));
+  return TT_OK;
+}
+
+}  // namespace
+
+extern "C" int32_t tt_sparse_plan_max_lds_ids(void) { return kMaxLdsSortIds; }
+
+extern "C" int64_t tt_sparse_plan_workspace_bytes(int64_t n_ids) {
+  if (n_ids <= kMaxLdsSortIds) return 256;         // the LDS sort needs no global scratch
+  return align_up((int64_t)rocprim_temp_bytes(n_ids), 256) + 256;
+}
+
+extern "C" int tt_sparse_plan_batched(const tt_sparse_plan_args* tables, int32_t n_tables, tt_stream_t stream_) {
+  TT_REQUIRE(tables != nullptr && n_tables >= 1 && n_tables <= kMaxTables, "tt_sparse_plan_batched: 1..%d tables", kMaxTables);
+  hipStream_t stream = tt::as_stream(stream_);
+  SortBatch b{};
+  int nb = 0, max_n = 0, max_bits = 0;
+  for (int i = 0; i < n_tables; ++i) {
+    const tt_sparse_plan_args& a = tables[i];
+    TT_REQUIRE(a.n_ids >= 0 && a.num_rows > 0, "tt_sparse_plan: bad n_ids/num_rows");
+    TT_REQUIRE(a.n_ids <= 0x7fffffff, "tt_sparse_plan: n_ids must fit in int32");
+    if (a.n_ids == 0) continue;
+    TT_REQUIRE(a.ids && a.sorted_ids && a.order, "tt_sparse_plan: null pointer");
+    const int bits = id_bits(a.num_rows + 1);
+    if (a.n_ids > kMaxLdsSortIds || bits > 31) {   // large id lists: rocPRIM, one table at a time
+      const int rc = plan_rocprim(a, stream);
+      if (rc != TT_OK) return rc;
+      continue;
+    }
+    SortTable& t = b.t[nb++];
+    t.ids = a.ids; t.sorted_ids = a.sorted_ids; t.order = a.order; t.num_rows = a.num_rows; t.n = (int32_t)a.n_ids;
+    t.sentinel = (uint32_t)(((uint64_t)1 << bits) - 1);
+    if ((int)a.n_ids > max_n) max_n = (int)a.n_ids;
+    if (bits > max_bits) max_bits = bits;
+  }
+  if (nb == 0) return TT_OK;
+  // digits: 8 bits when the passes needed are the same as with 9 (fewer ballots, smaller counter table)
+  const int npass9 = (max_bits + 8) / 9, npass8 = (max_bits + 7) / 8;
+  const bool nine = npass9 < npass8;
+  for (int i = 0; i < nb; ++i) {
+    const int bits = id_bits(b.t[i].num_rows + 1);
+    b.t[i].npass = nine ? (bits + 8) / 9 : (bits + 7) / 8;
+  }
+  const int items = max_n > 8192 ? 16 : 8;
+  const int threads = max_n <= 512 * items ? 512 : 1024;
+  if (items == 8) return nine ? launch_lds_sort<8, 9>(b, nb, threads, stream) : launch_lds_sort<8, 8>(b, nb, threads, stream);
+  return nine ? launch_lds_sort<16, 9>(b, nb, threads, stream) : launch_lds_sort<16, 8>(b, nb, threads, stream);
+}
+
+extern "C" int tt_sparse_plan(const int64_t* ids, int64_t n_ids, int64_t num_rows, void* workspace, int64_t workspace_bytes,
+                              int64_t* sorted_ids, int32_t* order, tt_stream_t stream) {
+  const tt_sparse_plan_args a{ids, n_ids, num_rows, workspace, workspace_bytes, sorted_ids, order};
+  return tt_sparse_plan_batched(&a, 1, stream);
+}

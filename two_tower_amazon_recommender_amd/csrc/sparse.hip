@@ -1,31 +1,24 @@
 // K2 — fused sparse optimizer on embedding rows.
 //
-// plan  : stable LSD radix sort of (id, position) by id (rocPRIM device radix sort — integer index
-//         plumbing; only the ids are needed, so it runs before / beside the forward pass).
+// plan  : stable LSD radix sort of (id, position) by id — csrc/sort.hip (one launch, LDS-resident; only the ids are
+//         needed, so it runs before / beside the forward pass).
 // apply : one group of dim/4 lanes per sorted slot.  A slot that starts a run of equal ids walks the
 //         run, summing the gradient rows in ascending position order (the IndexedSlices
 //         de-duplication Keras performs before the update; bitwise reproducible), then
 //         read-modify-writes the table row (and the Adagrad accumulator row) once.  Runs are cut
 //         into pieces at global multiples of 64 sorted slots so that a hot id is summed by many lane
-//         groups in parallel (pieces sequential inside, added in order by a small second launch);
+//         groups in parallel (pieces sequential inside; the LAST piece of a run to finish — an arrival ticket per
+//         run — adds the pieces in index order and applies the update: order fixed, no second launch);
 //         a run inside one 64-slot block is a plain sequential sum, bit-equal to np.add.at.
 //         No float atomics: Adagrad is non-linear in g, so duplicates MUST be summed first.
 // HBM-bound.  Algorithmic bytes per distinct row: 4*dim (grad) + 4*dim (row read) + 4*dim (row write)
 // [+ 8*dim accumulator read/write for Adagrad] + 12 (sorted id + position).
 #include "common.h"
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/iterator/counting_iterator.hpp>
 
 namespace {
 
 using tt::f32x4;
-
-int id_bits(int64_t num_rows) {
-  int bits = 1;
-  while (bits < 63 && ((int64_t)1 << bits) < num_rows) ++bits;
-  return bits;
-}
 
 constexpr int kPiece = 64;   // sorted slots per piece: runs are cut at global multiples of 64 slots
 
@@ -39,7 +32,7 @@ struct ApplyArgs {
   // per-table piece workspace (tt_sparse_apply_workspace_bytes): sums of the pieces of runs that cross a 64-slot boundary
   float* p_sum[2];      // [nblk][dim]  first piece of a run that continues past its block (head in block j)
   float* s_sum[2];      // [nblk][dim]  piece starting exactly at slot 64*j
-  int32_t* p_flag[2];   // [nblk]       1 = block j holds the head of a deferred run
+  int32_t* p_flag[2];   // [nblk]       arrival ticket of the deferred run whose head is in block j (0 between launches)
 };
 
 template <int OPT>
@@ -66,6 +59,12 @@ __device__ __forceinline__ void update_row(f32x4* __restrict__ table, f32x4* __r
 // into PIECES at global multiples of 64 slots; every piece is summed sequentially in slot (= ascending position) order,
 // then the pieces are added in order.  A run inside one 64-slot block — the common case — is a plain sequential sum
 // (bit-equal to np.add.at).  A hot id repeated thousands of times is summed by many lane groups in parallel.
+//
+// A run that crosses a block boundary is finished INSIDE this launch: every piece stores its sum (p_sum / s_sum of its
+// block), releases it (agent scope) and takes a ticket on the run's counter p_flag[head block]; the piece that draws
+// the last ticket acquires, adds the pieces in INDEX order (never arrival order: bitwise reproducible) and applies the
+// update.  A block holds at most one run head that continues past its end, so the counter is unambiguous; the last
+// arriver leaves it at 0 for the next launch.
 template <int OPT>
 __global__ __launch_bounds__(256, 8) void sparse_apply_kernel(ApplyArgs a, int dim4, int lpr_log2, int64_t n_ids, float lr,
                                                            float eps) {
@@ -86,7 +85,7 @@ __global__ __launch_bounds__(256, 8) void sparse_apply_kernel(ApplyArgs a, int d
   const bool run_head = (k == 0) || (sid[k - 1] != id);
   const bool boundary = (k % kPiece) == 0;
   if (!run_head && !boundary) return;             // inside a piece
-  if (id < 0 || id >= rows) return;               // out-of-range / padding ids are skipped (flagged by the gather)
+  if (id < 0 || id >= rows) return;               // out-of-range / padding ids (the plan's sentinel) are skipped
   int64_t pend = (k / kPiece + 1) * kPiece;       // this piece ends at the next 64-slot boundary at the latest
   if (pend > n_ids) pend = n_ids;
   int64_t e = k + 1;                              // end of this piece: one id load for the usual run of length 1,
@@ -99,6 +98,8 @@ __global__ __launch_bounds__(256, 8) void sparse_apply_kernel(ApplyArgs a, int d
     e = lo;
   }
   const bool continues = (e == pend) && (pend < n_ids) && (sid[pend] == id);
+  const bool whole = run_head && !continues;      // the usual case: the whole run is this piece
+  const int64_t blk = k / kPiece;
 
   for (int c = l; c < dim4; c += lpr) {
     f32x4 g = grads[(int64_t)order[k] * dim4 + c];
@@ -121,41 +122,58 @@ __global__ __launch_bounds__(256, 8) void sparse_apply_kernel(ApplyArgs a, int d
       for (int e = 0; e < 4; ++e) g[e] = __fadd_rn(g[e], g1[e]);
       ++j;
     }
-    if (run_head && !continues) {
+    if (whole) {
       update_row<OPT>(table, accum, id * dim4 + c, g, lr, eps);           // whole run summed: fused update
     } else if (run_head) {
-      reinterpret_cast<f32x4*>(a.p_sum[t])[(k / kPiece) * dim4 + c] = g;  // first piece of a long run
+      reinterpret_cast<f32x4*>(a.p_sum[t])[blk * dim4 + c] = g;           // first piece of a long run
     } else {
-      reinterpret_cast<f32x4*>(a.s_sum[t])[(k / kPiece) * dim4 + c] = g;  // later piece (starts at slot 64*(k/64))
+      reinterpret_cast<f32x4*>(a.s_sum[t])[blk * dim4 + c] = g;           // later piece (starts at slot 64*blk)
     }
   }
-  if (run_head && continues && l == 0) a.p_flag[t][k / kPiece] = 1;
-}
+  if (whole) return;
 
-// second launch: one lane group per 64-slot block; a block that holds the head of a deferred run adds the run's pieces in
-// order and applies the update.  (Almost always nothing to do.)
-template <int OPT>
-__global__ __launch_bounds__(256) void sparse_finish_kernel(ApplyArgs a, int dim4, int lpr_log2, int64_t n_ids, int64_t nblk,
-                                                            float lr, float eps) {
-  const int t = blockIdx.y;
-  const int lpr = 1 << lpr_log2;
-  const int groups = 256 >> lpr_log2;
-  const int64_t j = (int64_t)blockIdx.x * groups + (threadIdx.x >> lpr_log2);   // block index
-  const int l = threadIdx.x & (lpr - 1);
-  if (j >= nblk || a.p_flag[t][j] == 0) return;
-  if (l == 0) a.p_flag[t][j] = 0;                  // leave the workspace zeroed for the next call
-  const int64_t* __restrict__ sid = a.sorted_ids[t];
-  const int64_t id = sid[(j + 1) * kPiece - 1];   // the deferred run reaches the end of block j
-  const f32x4* __restrict__ P = reinterpret_cast<const f32x4*>(a.p_sum[t]);
-  const f32x4* __restrict__ S = reinterpret_cast<const f32x4*>(a.s_sum[t]);
+  // ---- a piece of a run that spans several blocks: find the run's extent, publish, take a ticket ----
+  int64_t first = k;                              // first slot of the run (lower bound of id in the sorted ids)
+  if (!run_head) {
+    int64_t lo = 0, hi = k;                       // sid[k] == id, and the slot before a boundary piece holds id too
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (sid[mid] < id) lo = mid + 1; else hi = mid;
+    }
+    first = lo;
+  }
+  int64_t last = e;                               // one past the last slot of the run
+  if (continues) {
+    int64_t lo = pend + 1, hi = n_ids;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (sid[mid] <= id) lo = mid + 1; else hi = mid;      // sentinel / valid ids ascend; nothing sorts below 0
+    }
+    last = lo;
+  }
+  const int64_t jh = first / kPiece, jl = (last - 1) / kPiece;
+  const int npieces = (int)(jl - jh + 1);
+  // release: this lane group's stores (all in this wave) are written back before the ticket is drawn
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  int ticket = 0;
+  if (l == 0) ticket = atomicAdd(&a.p_flag[t][jh], 1);
+  ticket = __shfl(ticket, (int)(threadIdx.x & 63u & ~(unsigned)(lpr - 1)));
+  if (ticket != npieces - 1) return;
+  // last arriver: every piece of the run is published
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (l == 0) a.p_flag[t][jh] = 0;                // leave the workspace zeroed for the next call
+  const f32x4* P = reinterpret_cast<const f32x4*>(a.p_sum[t]);
+  const f32x4* S = reinterpret_cast<const f32x4*>(a.s_sum[t]);
   for (int c = l; c < dim4; c += lpr) {
-    f32x4 g = P[j * dim4 + c];
-    for (int64_t m = j + 1; m < nblk && sid[m * kPiece] == id; ++m) {
+    f32x4 g = P[jh * dim4 + c];
+    for (int64_t m = jh + 1; m <= jl; ++m) {
       const f32x4 s = S[m * dim4 + c];
 #pragma unroll
       for (int e = 0; e < 4; ++e) g[e] = __fadd_rn(g[e], s[e]);
     }
-    update_row<OPT>(reinterpret_cast<f32x4*>(a.table[t]), reinterpret_cast<f32x4*>(a.accum[t]), id * dim4 + c, g, lr, eps);
+    update_row<OPT>(table, accum, id * dim4 + c, g, lr, eps);
   }
 }
 
@@ -191,67 +209,23 @@ int launch_apply(int opt, ApplyArgs a, void* const ws[2], int n_tables, int32_t 
     a.p_sum[t] = reinterpret_cast<float*>(base + w.off_p);
     a.s_sum[t] = reinterpret_cast<float*>(base + w.off_s);
   }
-  const int64_t fblocks = (w.nblk + groups - 1) / groups;
   tt::ProfScope prof("sparse_apply", stream);
-  if (opt == TT_OPT_SGD) {
+  if (opt == TT_OPT_SGD)
     hipLaunchKernelGGL(sparse_apply_kernel<TT_OPT_SGD>, dim3((unsigned)blocks, n_tables), dim3(256), 0, stream, a, dim4,
                        lpr_log2, n_ids, lr, eps);
-    hipLaunchKernelGGL(sparse_finish_kernel<TT_OPT_SGD>, dim3((unsigned)fblocks, n_tables), dim3(256), 0, stream, a, dim4,
-                       lpr_log2, n_ids, w.nblk, lr, eps);
-  } else {
+  else
     hipLaunchKernelGGL(sparse_apply_kernel<TT_OPT_ADAGRAD>, dim3((unsigned)blocks, n_tables), dim3(256), 0, stream, a,
                        dim4, lpr_log2, n_ids, lr, eps);
-    hipLaunchKernelGGL(sparse_finish_kernel<TT_OPT_ADAGRAD>, dim3((unsigned)fblocks, n_tables), dim3(256), 0, stream, a,
-                       dim4, lpr_log2, n_ids, w.nblk, lr, eps);
-  }
   return tt::check_launch(what);
 }
 
 int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
-
-size_t sort_temp_bytes(int64_t n_ids) {
-  size_t bytes = 0;
-  const int64_t* kin = nullptr;
-  int64_t* kout = nullptr;
-  int32_t* vout = nullptr;
-  (void)rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, rocprim::counting_iterator<int32_t>(0), vout, (size_t)n_ids, 0u,
-                            64u, (hipStream_t) nullptr, false);
-  return bytes;
-}
 
 }  // namespace
 
 extern "C" int64_t tt_sparse_apply_workspace_bytes(int64_t n_ids, int32_t dim) {
   if (n_ids <= 0 || dim <= 0) return 256;
   return piece_ws(n_ids, dim).total;
-}
-
-extern "C" int64_t tt_sparse_plan_workspace_bytes(int64_t n_ids) {
-  if (n_ids <= 0) return 256;
-  return align_up((int64_t)sort_temp_bytes(n_ids), 256) + 256;
-}
-
-extern "C" int tt_sparse_plan(const int64_t* ids, int64_t n_ids, int64_t num_rows, void* workspace, int64_t workspace_bytes,
-                              int64_t* sorted_ids, int32_t* order, tt_stream_t stream) {
-  TT_REQUIRE(n_ids >= 0 && num_rows > 0, "tt_sparse_plan: bad n_ids/num_rows");
-  TT_REQUIRE(n_ids <= 0x7fffffff, "tt_sparse_plan: n_ids must fit in int32");
-  if (n_ids == 0) return TT_OK;
-  TT_REQUIRE(ids && workspace && sorted_ids && order, "tt_sparse_plan: null pointer");
-  size_t temp = sort_temp_bytes(n_ids);
-  if ((int64_t)temp > workspace_bytes)
-    return tt::fail(TT_ERR_WORKSPACE, "tt_sparse_plan: workspace %lld < %lld bytes", (long long)workspace_bytes,
-                    (long long)temp);
-  // Only the low bits that an id < num_rows can set are sorted.  Ids outside [0,num_rows) then land
-  // somewhere in the order, possibly splitting into several runs — harmless, because the apply kernel
-  // skips every out-of-range id (the gather has already flagged them).
-  // +1: 2^bits - 1 (the low bits of the padding id -1) is then never a valid id, so padding slots cannot
-  // interleave with (and split) a run of equal valid ids.
-  const int bits = id_bits(num_rows + 1);
-  tt::ProfScope prof("sparse_plan", tt::as_stream(stream));
-  hipError_t e = rocprim::radix_sort_pairs(workspace, temp, ids, sorted_ids, rocprim::counting_iterator<int32_t>(0), order,
-                                           (size_t)n_ids, 0u, (unsigned)bits, tt::as_stream(stream), false);
-  if (e != hipSuccess) return tt::fail(TT_ERR_LAUNCH, "tt_sparse_plan: rocprim radix sort: %s", hipGetErrorString(e));
-  return TT_OK;
 }
 
 extern "C" int tt_sparse_sgd_f32(float* table, int64_t num_rows, int32_t dim, const float* grads, const int64_t* sorted_ids,

@@ -227,6 +227,20 @@ class SparsePlan:
         return self
 
 
+def sparse_plan_batched(plans, ids_list, num_rows_list):
+    """Sort up to 4 id lists (user, item, hashed category, ...) in ONE launch: one workgroup per table."""
+    n = len(plans)
+    args = []
+    for plan, ids, rows in zip(plans, ids_list, num_rows_list):
+        _chk(ids, torch.int64, "ids", 1)
+        if ids.numel() != plan.n_ids:
+            raise RuntimeError(f"SparsePlan: built for {plan.n_ids} ids, got {ids.numel()}")
+        args.append(_lib.SparsePlanArgs(_p(ids), plan.n_ids, int(rows), _p(plan.workspace), plan.ws_bytes,
+                                        _p(plan.sorted_ids), _p(plan.order)))
+    arr = (_lib.SparsePlanArgs * n)(*args)
+    _lib.check(_lib.load().tt_sparse_plan_batched(arr, n, _stream()), "tt_sparse_plan_batched")
+
+
 def sparse_sgd_(table, grads, plan: SparsePlan, lr: float):
     _chk(table, torch.float32, "table", 2)
     _chk(grads, torch.float32, "grads", 2)
