@@ -20,8 +20,6 @@ import os
 import sys
 import time
 
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -30,8 +28,8 @@ CONFIGS = {
     "cfg1": (10_000, 10_000, 32, [32], 256),
     "cfg2": (1_000_000, 1_000_000, 64, [64], 4096),
     "cfg3": (5_000_000, 10_000_000, 128, [256, 128], 8192),
-    # BASELINE configs[3] / [4] are 8-GPU configurations; their tables also fit ONE MI355X (288 GB), so they can be
-    # measured un-sharded too (the N>1 driver runs use bench_dist.py's per-GPU cfg3 family instead)
+    # BASELINE configs[3] / [4] are 8-GPU configurations (`--gpus N --config cfg4|cfg5`: bench_dist.py); their tables
+    # also fit ONE MI355X (288 GB), so N=1 measures them un-sharded
     "cfg4": (5_000_000, 100_000_000, 128, [256, 128], 16384),
     "cfg5": (54_000_000, 48_000_000, 256, [512, 256], 32768),
 }
@@ -46,12 +44,39 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
-    ap.add_argument("--optimizer", default="sgd", choices=["sgd", "adagrad"])
+    ap.add_argument("--optimizer", default=None, choices=["sgd", "adagrad"],
+                    help="default: sgd (cfg5: adagrad — BASELINE configs[4] names the fused sparse Adagrad)")
     ap.add_argument("--ids", default="U", choices=["U", "Z"], help="uniform / power-law id batches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
+    ap.add_argument("--negatives", default="global", choices=["global", "local"],
+                    help="N>1: in-batch negatives over the all-gathered GLOBAL batch (parity with the single-device loss; "
+                         "default) or over each rank's own batch")
     return ap.parse_args()
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` from a bare shell: start the N ranks (one per GPU) through torch.distributed.run as a
+    CHILD process — before this process has touched the GPU or imported torch — relay rank 0's JSON line and exit with
+    the child's code.  (Never an exec: a process must not be replaced once it may have initialised the GPU.)"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        if line.lstrip().startswith("{"):
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(line)
+    return proc.wait()
 
 
 def cpu_share() -> int:
@@ -103,12 +128,17 @@ def cpu_baseline(trainer, cfg, seed, args, batch):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:       # not under a launcher: become one
+        raise SystemExit(self_launch(args))
+    import torch                        # (imported here, not at module level: the self-launching parent never loads it)
+    globals()["torch"] = torch
+    if args.optimizer is None:
+        args.optimizer = "adagrad" if args.config == "cfg5" else "sgd"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 

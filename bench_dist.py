@@ -1,10 +1,17 @@
-"""N>1 leg of bench.py: one rank per GPU (torch.distributed.run), RCCL over xGMI.
+"""N>1 leg of bench.py: one rank per GPU (torch.distributed.run), tables row-sharded, RCCL over xGMI.
 
-Workload family (weak scaling, consistent with the N=1 line = BASELINE cfg3): per-GPU batch 8192,
-tables row-sharded with 5M users and 10M items PER GPU (N=8: 40M x 80M rows; BASELINE cfg4's 100M-row item
-table is `--items-per-gpu 12500000`), emb_dim 128, towers 128->256->128, in-batch negatives per rank
-(`--negatives local`, what tfrs.tasks.Retrieval sees under a data-parallel strategy) or all-gathered
-(`--negatives global`).  value = world * batch * steps / max-over-ranks time.
+Workloads (``--config``):
+  cfg3 (default)  the weak-scaled family of the N=1 line (BASELINE configs[2] per GPU): per-GPU batch 8192, 5M users
+                  and 10M items PER GPU, emb_dim 128, towers 128->256->128, SGD          -> "scaling": "weak"
+  cfg4            BASELINE configs[3]: 100M-row item table (5M users) row-sharded over the N GPUs, emb_dim 128,
+                  GLOBAL batch 16384 (16384/N per GPU), towers 128->256->128, SGD       -> "scaling": "strong"
+  cfg5            BASELINE configs[4]: 54M users x 48M items, emb_dim 256, GLOBAL batch 32768, towers
+                  256->512->256, fused sparse Adagrad, 30-bucket hashed category feature -> "scaling": "strong"
+In-batch negatives are GLOBAL by default (candidates all-gathered, dC reduce-scattered: the loss equals the
+single-device loss on the global batch); ``--negatives local`` scores each rank's queries against its
+own candidates only and says so in ``config.workload``.
+value = global batch * steps / max-over-ranks time.  The line carries the scorer's ``roofline`` on the per-GPU slab
+(B_local x B_global) from live hipEvent brackets on rank 0, and per-collective stream time from an untimed detail pass.
 """
 import json
 import os
@@ -13,23 +20,82 @@ import time
 import torch
 import torch.distributed as dist
 
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+# name: (n_users, n_items, emb_dim, tower_dims, global_batch or None (= 8192 per GPU), optimizer, category buckets)
+DIST_CONFIGS = {
+    "cfg3": (5_000_000, 10_000_000, 128, [256, 128], None, "sgd", 0),        # rows and batch are PER GPU
+    "cfg4": (5_000_000, 100_000_000, 128, [256, 128], 16384, "sgd", 0),
+    "cfg5": (54_000_000, 48_000_000, 256, [512, 256], 32768, "adagrad", 30),
+}
+
+
+def _timed(fn, stream_events):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    out = fn()
+    b.record()
+    stream_events.append((a, b))
+    return out
+
+
+def collective_detail(trainer, batches, steps):
+    """Per-collective stream time (us, mean over `steps` steps) of rank 0: every torch.distributed call of a step is
+    bracketed with events on the stream it is enqueued on (the asynchronous gradient all-to-all is issued inline for
+    this pass, so its bracket is the collective alone).  Untimed: runs after the measured region."""
+    names = ("all_to_all_single", "all_gather_into_tensor", "reduce_scatter_tensor", "all_reduce")
+    rec = {n: [] for n in names}
+    orig = {n: getattr(dist, n) for n in names}
+
+    def wrap(n):
+        def f(*a, **k):
+            k.pop("async_op", None)
+            _timed(lambda: orig[n](*a, **k), rec[n])
+            return None
+        return f
+    for n in names:
+        setattr(dist, n, wrap(n))
+    trainer.emb._wait = lambda w: None            # (instance attribute: shadows the class's static method)
+    try:
+        for s in range(steps):
+            trainer.step(*batches[s][:2], **batches[s][2])
+        torch.cuda.synchronize()
+    finally:
+        for n in names:
+            setattr(dist, n, orig[n])
+        del trainer.emb._wait
+    out = {}
+    for n, ev in rec.items():
+        if ev:
+            us = [a.elapsed_time(b) * 1e3 for a, b in ev]
+            out[n] = {"calls_per_step": len(us) / steps, "us_per_call": sum(us) / len(us), "us_per_step": sum(us) / steps}
+    return out
+
 
 def run_distributed(args, rank, world, dev):
+    from two_tower_amazon_recommender_amd import _lib
     from two_tower_amazon_recommender_amd.sharded import ShardedTwoTowerTrainer
     from two_tower_amazon_recommender_amd.trainer import TwoTowerConfig
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if world == 1:                      # TT_FORCE_DIST=1 without a launcher: a one-rank group
+    if "RANK" not in os.environ:        # TT_FORCE_DIST=1 without a launcher: a one-rank group
         for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):
             os.environ.setdefault(k, v)
     dist.init_process_group("nccl", device_id=dev)
-    negatives = os.environ.get("TT_NEGATIVES", "local")
-    users_per_gpu = int(os.environ.get("TT_USERS_PER_GPU", 5_000_000))
-    items_per_gpu = int(os.environ.get("TT_ITEMS_PER_GPU", 10_000_000))
-    batch, dim, tower_dims = 8192, 128, [256, 128]
-    seed = 1003
-    cfg = TwoTowerConfig(n_users=users_per_gpu * world, n_items=items_per_gpu * world, embedding_dim=dim,
-                         tower_dims=tower_dims, temperature=0.1, l2_regularization=1e-6, learning_rate=0.001,
-                         optimizer=args.optimizer, batch_size=batch)
+    name = args.config if args.config in DIST_CONFIGS else "cfg3"
+    n_users, n_items, dim, tower_dims, gbatch, opt, buckets = DIST_CONFIGS[name]
+    negatives = args.negatives
+    if name == "cfg3":                  # weak scaling: fixed work per GPU
+        n_users, n_items = int(os.environ.get("TT_USERS_PER_GPU", n_users)) * world, int(os.environ.get("TT_ITEMS_PER_GPU", n_items)) * world
+        batch, scaling = 8192, "weak"
+        opt = args.optimizer or "sgd"
+    else:                               # BASELINE's 8-GPU configurations: fixed global problem
+        if gbatch % world:
+            raise SystemExit(f"{name}: global batch {gbatch} is not divisible by {world} ranks")
+        batch, scaling = gbatch // world, "strong"
+    seed = 1000 + int(name[3:])
+    cfg = TwoTowerConfig(n_users=n_users, n_items=n_items, embedding_dim=dim, tower_dims=tower_dims, temperature=0.1,
+                         l2_regularization=1e-6, learning_rate=0.001, optimizer=opt, batch_size=batch,
+                         n_category_buckets=buckets)
     # TT_FORCE_COLLECTIVES=1: issue the RCCL calls even on one rank (their launch cost without any xGMI traffic)
     trainer = ShardedTwoTowerTrainer(cfg, dev, seed=seed, negatives=negatives,
                                      capacity_factor=float(os.environ.get("TT_CAPACITY_FACTOR", 2.0)),
@@ -38,24 +104,37 @@ def run_distributed(args, rank, world, dev):
     total = args.warmup + args.steps
     uids = torch.empty(total, batch, dtype=torch.int64, device=dev)
     iids = torch.empty(total, batch, dtype=torch.int64, device=dev)
+    cids = torch.empty(total, batch, dtype=torch.int64, device=dev) if buckets else None
     for s in range(total):
         trainer.synthetic_batch(seed, s, args.ids, out=(uids[s], iids[s]))
+        if cids is not None:
+            trainer.synthetic_categories(seed, s, out=cids[s])
     # TT_PREFETCH=1: the next batch's ids are handed to step(), which routes them on a side stream beside this step's
-    # scorer; TT_PREFETCH=2 also issues their id all-to-all early.  Measured on one rank (forced RCCL calls) both cost
-    # more than they hide (0.888 -> 0.896 / 0.907 ms: every cross-stream hand-off is a 4-7 us bubble in the GPU queue
-    # and the early collective disturbs the scorer), so neither is the default until measured on a multi-GPU node.
+    # scorer; TT_PREFETCH=2 also issues their id all-to-all early (off by default: see DESIGN.md §6).
     pf = os.environ.get("TT_PREFETCH", "0")
     prefetch, pf_exchange = pf in ("1", "2"), pf == "2"
-    batches = [(uids[s], iids[s]) for s in range(total)] + [None]
+    batches = []
+    for s in range(total):
+        kw = {} if cids is None else {"category_ids": cids[s]}
+        if prefetch and s + 1 < total:
+            kw.update(next_ids=(uids[s + 1], iids[s + 1]), prefetch_exchange=pf_exchange)
+        batches.append((uids[s], iids[s], kw))
+
+    def step(s):
+        return trainer.step(batches[s][0], batches[s][1], **batches[s][2])
     for s in range(args.warmup):
-        trainer.step(*batches[s], next_ids=batches[s + 1] if prefetch else None, prefetch_exchange=pf_exchange)
+        step(s)
     torch.cuda.synchronize()
     trainer.check_ids()
+    stride = 4 if args.steps >= 40 else 1
+    if rank == 0:
+        _lib.profile_set_stride(stride)
+        _lib.profile_enable("score_fused", capacity=2 * args.steps + 8)
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for s in range(args.warmup, total):
-        trainer.step(*batches[s], next_ids=batches[s + 1] if prefetch else None, prefetch_exchange=pf_exchange)
+        step(s)
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
@@ -64,19 +143,44 @@ def run_distributed(args, rank, world, dev):
     loss = trainer.loss.double().clone()
     dist.all_reduce(loss, op=dist.ReduceOp.SUM)
     trainer.check_ids()
+    fused = []
+    if rank == 0:
+        fused = _lib.profile_read("score_fused", 2 * args.steps + 8)[0]
+        _lib.profile_enable("")
+    detail_steps = min(args.steps, 20)
+    coll = collective_detail(trainer, batches[total - detail_steps:], detail_steps) if trainer.collectives else {}
+    trainer.check_ids()
     if rank == 0:
         sec = dt.item()
+        sd = tower_dims[-1]
+        nc = batch * world if (negatives == "global" and trainer.collectives) else batch
+        roofline = None
+        if fused:
+            t = sum(fused) / len(fused) * 1e-3
+            flops = 4.0 * batch * nc * sd                  # pass 1 on this GPU's slab: logits + dq (algorithmic = executed)
+            a = flops / t / 1e12
+            roofline = {"bound": "mfma", "kernel": f"score_kernel<{sd},FUSED> on rank 0's slab [{batch} queries x {nc} candidates] "
+                                                   "(loss + dq pass; algorithmic 4*Bq*Bc*D per launch)",
+                        "achieved": a, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": a / MFMA_F32_PEAK_TFLOPS,
+                        "traffic": None, "avg_launch_us": t * 1e6, "samples": len(fused), "dtype": "f32-input MFMA"}
+        tower = f"{dim}->" + "->".join(map(str, tower_dims))
         out = {
             "metric": "user-item pairs/sec (train step) + embedding-gather HBM GB/s, 1/2/4/8 MI355X",
             "value": world * batch * args.steps / sec, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": sec / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": sec / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"cfg3 per GPU, row-sharded: {cfg.n_users} users x {cfg.n_items} items over {world} GPUs "
-                                   f"(owner = id % {world}), emb_dim {dim}, towers {dim}->256->128, batch {batch}/GPU, "
-                                   f"in-batch negatives {negatives}, {args.optimizer} lr 1e-3, ids {args.ids}",
-                       "global_batch": world * batch, "parallelism": f"dp{world} + row-sharded tables (all-to-all)"},
-            "roofline": None, "cpu_baseline": None,
+            "config": {"workload": (f"{name}{' per GPU (weak-scaled family of the N=1 line)' if name == 'cfg3' else ''}, row-sharded: "
+                                    f"{cfg.n_users} users x {cfg.n_items} items over {world} GPUs (owner = id % {world}), "
+                                    f"emb_dim {dim}, towers {tower}, batch {batch}/GPU (global {world * batch}), in-batch "
+                                    f"negatives {negatives.upper()}, {opt} lr 1e-3, ids {args.ids}"
+                                    + (f", + {buckets}-bucket hashed category feature" if buckets else "")),
+                       "global_batch": world * batch, "parallelism": f"dp{world} + row-sharded tables (all-to-all)",
+                       "negatives": negatives},
+            "roofline": roofline, "cpu_baseline": None,
+            "collectives": coll or None,
+            "timing_note": f"hipEvent brackets inside the timed region: score_fused on rank 0, every {stride}th step; "
+                           f"collectives: stream time per call, untimed detail pass of {detail_steps} steps",
             "loss_per_pair": loss.item() / (world * batch),
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     dist.destroy_process_group()

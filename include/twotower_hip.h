@@ -289,6 +289,9 @@ int tt_dense_update_f32(const tt_dense_seg* segs, int32_t n_segs, int32_t opt, i
  * Outputs: lse [nq], per_row [nq], loss [1]; dq [nq,dim], dc [nc,dim].
  * Workspace: tt_retrieval_workspace_bytes(nq, nc, dim) bytes, 256-byte aligned.          */
 int64_t tt_retrieval_workspace_bytes(int64_t nq, int64_t nc, int32_t dim);
+/* What tt_retrieval_rank_f32 alone needs (no gradient slabs: those make the full workspace as large as the candidate
+ * corpus once nc >= 65536).                                                                                   */
+int64_t tt_retrieval_rank_workspace_bytes(int64_t nq, int64_t nc, int32_t dim);
 int tt_retrieval_fwd_f32(const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
                          int64_t diag_offset, float inv_temperature,
                          const float* sample_weight, const float* cand_prob, const int64_t* cand_ids,
@@ -327,7 +330,7 @@ int tt_retrieval_fwd_bwd_f32(const float* q, const float* c, int64_t nq, int64_t
 /* Retrieval metrics (configs/data_config.yaml:71 top_k_eval; tfrs.metrics.FactorizedTopK's role):
  * rank[i] = number of candidates j != pos_index[i] with s_ij > s_{i,pos_index[i]} over ALL nc candidates
  * (nc may be the whole item corpus; nq <= or > nc both allowed).  Recall@K = mean(rank < K),
- * NDCG@K = mean([rank < K] / log2(rank + 2)).  Same workspace size as the loss entry points.           */
+ * NDCG@K = mean([rank < K] / log2(rank + 2)).  Workspace: tt_retrieval_rank_workspace_bytes(nq, nc, dim).     */
 int tt_retrieval_rank_f32(const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
                           float inv_temperature, const float* cand_prob, const int64_t* pos_index,
                           void* workspace, int64_t workspace_bytes, int32_t* rank, tt_stream_t stream);

@@ -69,16 +69,27 @@ def _install_host_bounce():
     dist.all_gather_into_tensor, dist.reduce_scatter_tensor = ag, rs
 
 
-def _worker(rank, world, port, opt, variant, negatives, nb, ret):
+def _init(rank, world, port, real):
+    """real=False: two ranks share cuda:0, collectives bounced through gloo.  real=True: one GPU per rank, the product's
+    own RCCL collectives with their real stream ordering (needs >= world GPUs); objects travel over a gloo side group."""
     sys.path.insert(0, str(ROOT))
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if real:
+        dev = torch.device("cuda", rank)
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        return dev, dist.new_group(backend="gloo")
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    _install_host_bounce()
+    return torch.device("cuda:0"), None
+
+
+def _worker(rank, world, port, opt, variant, negatives, nb, ret, real=False):
     try:
-        _install_host_bounce()
+        dev, og = _init(rank, world, port, real)
         from oracle import synth, two_tower as tt
         from two_tower_amazon_recommender_amd.sharded import ShardedTwoTowerTrainer
         from two_tower_amazon_recommender_amd.trainer import TwoTowerConfig
-        dev = torch.device("cuda:0")
         n_users, n_items, dim, tower_dims, b, seed = 3001, 2000, 64, [128, 64], 1024, 41
         cfg = TwoTowerConfig(n_users=n_users, n_items=n_items, embedding_dim=dim, tower_dims=tower_dims, temperature=0.1,
                              l2_regularization=1e-6, learning_rate=0.001, optimizer=opt, batch_size=b, n_category_buckets=nb)
@@ -109,7 +120,7 @@ def _worker(rank, world, port, opt, variant, negatives, nb, ret):
                 ids_i = np.concatenate([synth.batch_ids(seed, synth.TID_ITEM_IDS, step * world + r, b, n_items, variant) for r in range(world)])
                 masks = tuple([(t.acts[l + 1] > 0).cpu().numpy() for l in range(t.n_layers - 1)] for t in (tr.user_tower, tr.item_tower))
                 allm = [None] * world
-                dist.all_gather_object(allm, masks)
+                dist.all_gather_object(allm, masks, group=og)
                 gm = tuple([np.concatenate([allm[r][t][l] for r in range(world)]) for l in range(len(tower_dims) - 1)] for t in (0, 1))
                 ids_c = np.concatenate([cats(step, r) for r in range(world)]) if nb else None
                 fb = tt.forward_backward(ref, ids_u, ids_i, temperature=0.1, l2=0.0, relu_masks=gm, category_ids=ids_c)
@@ -124,7 +135,7 @@ def _worker(rank, world, port, opt, variant, negatives, nb, ret):
                     masks = tuple([(t.acts[l + 1] > 0).cpu().numpy() for l in range(t.n_layers - 1)]
                                   for t in (tr.user_tower, tr.item_tower))
                 allm = [None] * world
-                dist.all_gather_object(allm, masks if r == rank else None)
+                dist.all_gather_object(allm, masks if r == rank else None, group=og)
                 fb = tt.forward_backward(ref, ids_u, ids_i, temperature=0.1, l2=0.0, relu_masks=allm[r], category_ids=cats(step, r))
                 if r == rank:
                     assert abs(loss - fb["loss"]) <= 1e-4 * abs(fb["loss"]), (loss, fb["loss"])
@@ -185,7 +196,7 @@ def _worker(rank, world, port, opt, variant, negatives, nb, ret):
         assert (ranks >= lo).all() and (ranks <= hi).all()
         # replicas of the dense parameters stay bit-identical across ranks
         flat = [None] * world
-        dist.all_gather_object(flat, tr.dense_flat.cpu().numpy())
+        dist.all_gather_object(flat, tr.dense_flat.cpu().numpy(), group=og)
         assert np.array_equal(flat[0], flat[1])
         ret[rank] = "ok"
     except Exception:                                             # noqa: BLE001
@@ -193,6 +204,101 @@ def _worker(rank, world, port, opt, variant, negatives, nb, ret):
         ret[rank] = traceback.format_exc()
     finally:
         dist.destroy_process_group()
+
+
+def _worker_options(rank, world, port, negatives, ret, real=False):
+    """sample_weight + candidate_sampling_probability + accidental-hit removal through the SHARDED step (weights stay
+    with the rank's queries; probabilities and candidate ids are all-gathered with the candidates when negatives are
+    global) against the f64 oracle on the global batch."""
+    try:
+        dev, og = _init(rank, world, port, real)
+        from oracle import synth, two_tower as tt
+        from two_tower_amazon_recommender_amd.sharded import ShardedTwoTowerTrainer
+        from two_tower_amazon_recommender_amd.trainer import TwoTowerConfig
+        n_users, n_items, dim, tower_dims, b, seed = 3001, 300, 64, [64], 512, 43      # 300 items: many accidental hits
+        cfg = TwoTowerConfig(n_users=n_users, n_items=n_items, embedding_dim=dim, tower_dims=tower_dims, temperature=0.1,
+                             l2_regularization=0.0, learning_rate=0.01, optimizer="sgd", batch_size=b)
+        tr = ShardedTwoTowerTrainer(cfg, dev, seed=seed, negatives=negatives, capacity_factor=4.0)
+        ref = tt.synthetic_state(seed, n_users, n_items, dim, tower_dims, dtype=np.float64, optimizer="sgd")
+        w_all = synth.uniform_f32(seed, 77, world * b, 0.5, 1.0)
+        p_all = synth.uniform_f32(seed, 78, world * b, 0.001, 0.5)
+        u, i = tr.synthetic_batch(seed, 0, "Z")
+        sl = slice(rank * b, (rank + 1) * b)
+        loss = tr.step(u, i, sample_weight=torch.from_numpy(w_all[sl].copy()).to(dev),
+                       candidate_sampling_probability=torch.from_numpy(p_all[sl].copy()).to(dev), candidate_ids=i).item()
+        tr.check_ids()
+        ids_u = [synth.batch_ids(seed, synth.TID_USER_IDS, r, b, n_users, "Z") for r in range(world)]
+        ids_i = [synth.batch_ids(seed, synth.TID_ITEM_IDS, r, b, n_items, "Z") for r in range(world)]
+        assert np.array_equal(i.cpu().numpy(), ids_i[rank])
+        if negatives == "global":
+            au, ai = np.concatenate(ids_u), np.concatenate(ids_i)
+            fb = tt.forward_backward(ref, au, ai, temperature=0.1, sample_weight=w_all, candidate_sampling_probability=p_all,
+                                     candidate_ids=ai, remove_accidental_hits=True)
+            want = fb["per_row"][sl].sum()
+            gu, gi, iu, ii = fb["due"], fb["die"], au, ai
+        else:
+            fbs = [tt.forward_backward(ref, ids_u[r], ids_i[r], temperature=0.1, sample_weight=w_all[r * b:(r + 1) * b],
+                                       candidate_sampling_probability=p_all[r * b:(r + 1) * b], candidate_ids=ids_i[r],
+                                       remove_accidental_hits=True) for r in range(world)]
+            want = fbs[rank]["loss"]
+            gu, gi = np.concatenate([f["due"] for f in fbs]), np.concatenate([f["die"] for f in fbs])
+            iu, ii = np.concatenate(ids_u), np.concatenate(ids_i)
+        assert abs(loss - want) <= 1e-4 * abs(want), (loss, want)
+        tt.sparse_sgd(ref.user_table, iu, gu, 0.01); tt.sparse_sgd(ref.item_table, ii, gi, 0.01)
+        for shard, full in ((tr.user_table, ref.user_table), (tr.item_table, ref.item_table)):
+            err = np.abs(shard.cpu().numpy() - full[rank::world]).max()
+            assert err <= 3e-6, err
+        # a wrong-length option vector is refused before anything is enqueued
+        with pytest.raises(ValueError):
+            tr.step(u, i, sample_weight=torch.ones(b - 1, device=dev))
+        ret[rank] = "ok"
+    except Exception:                                             # noqa: BLE001
+        import traceback
+        ret[rank] = traceback.format_exc()
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def _spawn(fn, args, world=2):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(fn, args=(world, _free_port()) + args + (ret,), nprocs=world, join=True)
+    for r in range(world):
+        assert ret.get(r) == "ok", f"rank {r}: {ret.get(r)}"
+
+
+@pytest.mark.parametrize("negatives", ["global", "local"])
+def test_sharded_step_sample_weight_logq_and_accidental_hits_two_ranks(negatives):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    _spawn(_worker_options, (negatives,))
+
+
+def _worker_real(rank, world, port, opt, variant, negatives, nb, ret):
+    _worker(rank, world, port, opt, variant, negatives, nb, ret, real=True)
+
+
+def _worker_options_real(rank, world, port, negatives, ret):
+    _worker_options(rank, world, port, negatives, ret, real=True)
+
+
+@pytest.mark.parametrize("opt,variant,negatives,nb", [("sgd", "U", "local", 0), ("adagrad", "Z", "global", 0),
+                                                      ("sgd", "Z", "global", 30)])
+def test_sharded_trainer_real_rccl_one_gpu_per_rank(opt, variant, negatives, nb):
+    """The same 2-step comparison against the f64 oracle with the product's OWN collectives: a real "nccl" (RCCL) group,
+    one GPU per rank, inline synchronous C1/C2/C6, asynchronous C3 beside the dw GEMMs, the side-stream sort plans.
+    Needs >= 2 visible GPUs: skipped on the 1-GPU test box, runs the first time a multi-GPU lease is available."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (multi-GPU RCCL correctness is UNVERIFIED until this runs)")
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_real, args=(2, _free_port(), opt, variant, negatives, nb, ret), nprocs=2, join=True)
+    for r in range(2):
+        assert ret.get(r) == "ok", f"rank {r}: {ret.get(r)}"
+    mp.spawn(_worker_options_real, args=(2, _free_port(), negatives, ret), nprocs=2, join=True)
+    for r in range(2):
+        assert ret.get(r) == "ok", f"rank {r}: {ret.get(r)}"
 
 
 @pytest.mark.parametrize("opt,variant,negatives,nb", [("sgd", "U", "local", 0), ("adagrad", "Z", "local", 30),

@@ -5,6 +5,7 @@ import pytest
 import torch
 
 from oracle import synth, two_tower as tt
+from two_tower_amazon_recommender_amd import ops
 from two_tower_amazon_recommender_amd.trainer import TwoTowerConfig, TwoTowerTrainer
 
 pytestmark = pytest.mark.gpu
@@ -164,6 +165,125 @@ def test_full_size_train_step_properties_cfg3(dev):
         del tr, before_u, before_i
         torch.cuda.empty_cache()
     assert sums[0] == sums[1], "the train step is not bit-reproducible"
+
+
+def test_full_size_train_step_properties_cfg5(dev):
+    """BASELINE configs[4] at FULL size on one GPU: 54M users x 48M items x 256 (+ Adagrad accumulators: 209 GB of
+    tables), towers 256->512->256, batch 32768, fused sparse Adagrad, 30-bucket hashed category feature.  Properties
+    that need no O(B^2) host work and no second copy of the tables: the batch's rows (and their accumulators) change
+    and sampled rows outside the batch do not, the first loss is ~ln(B), and the step is bit-reproducible from the seed."""
+    free, total_mem = torch.cuda.mem_get_info()
+    if total_mem < 250e9:
+        pytest.skip("needs a 288 GB MI355X")
+    nu, ni, d, dims, b, nb = 54_000_000, 48_000_000, 256, [512, 256], 32768, 30
+    sums = []
+    for rep in range(2):
+        cfg = TwoTowerConfig(n_users=nu, n_items=ni, embedding_dim=d, tower_dims=dims, temperature=0.1, l2_regularization=1e-6,
+                             learning_rate=0.001, optimizer="adagrad", batch_size=b, n_category_buckets=nb)
+        tr = TwoTowerTrainer(cfg, dev, seed=1005)
+        u, i = tr.synthetic_batch(1005, 0, "Z")
+        c = tr.synthetic_categories(1005, 0)
+        probe = {}
+        for name, table, accum, ids, rows in (("user", tr.user_table, tr.user_accum, u, nu), ("item", tr.item_table, tr.item_accum, i, ni)):
+            uniq = torch.unique(ids)
+            other = torch.randint(0, rows, (200_000,), device=dev, generator=torch.Generator(device=dev).manual_seed(rep))
+            other = other[~torch.isin(other, uniq)]
+            probe[name] = (uniq, other, table[uniq].clone(), table[other].clone())
+        cat_before, dense_before = tr.cat_table.clone(), tr.dense_flat.clone()
+        loss = tr.step(u, i, category_ids=c).item()
+        tr.check_ids()
+        assert abs(loss / b - np.log(b)) < 0.05, loss / b
+        for name, table, accum in (("user", tr.user_table, tr.user_accum), ("item", tr.item_table, tr.item_accum)):
+            uniq, other, rows_before, other_before = probe[name]
+            assert torch.equal(table[other], other_before), f"{name}: a row outside the batch was modified"
+            assert torch.equal(accum[other], torch.full_like(other_before, 0.1))
+            changed = (table[uniq] != rows_before).any(dim=1)
+            assert changed.float().mean().item() >= 0.99
+            assert (accum[uniq] >= 0.1).all() and (accum[uniq] > 0.1).any(dim=1).float().mean().item() >= 0.99
+            assert torch.isfinite(table[uniq]).all()
+        assert (tr.cat_table != cat_before).any() and (tr.dense_flat != dense_before).float().mean().item() > 0.5
+        loss2 = tr.step(*tr.synthetic_batch(1005, 1, "Z"), category_ids=tr.synthetic_categories(1005, 1)).item()
+        sums.append((loss, loss2, tr.user_table[probe["user"][0]].view(torch.int32).sum(dtype=torch.int64).item(),
+                     tr.item_table[probe["item"][0]].view(torch.int32).sum(dtype=torch.int64).item(),
+                     tr.item_accum[probe["item"][0]].view(torch.int32).sum(dtype=torch.int64).item(),
+                     tr.cat_table.view(torch.int32).sum(dtype=torch.int64).item(),
+                     tr.dense_flat.view(torch.int32).sum(dtype=torch.int64).item()))
+        del tr, probe, table, accum, uniq, other, rows_before, other_before      # (loop variables keep 49 GB tables alive)
+        torch.cuda.empty_cache()
+    assert sums[0] == sums[1], "the cfg5 train step is not bit-reproducible"
+
+
+def test_wrong_length_batches_are_refused(dev):
+    """The tower buffers hold exactly batch_size rows: a longer batch would write past them, a shorter one would leave
+    stale rows that the scorer still reads — both raise before anything is enqueued (evaluate, evaluate_topk and the
+    option vectors too)."""
+    from two_tower_amazon_recommender_amd.metrics import FactorizedTopK
+    cfg, tr, _ = make(dev, 500, 400, 32, [32], 256, "sgd", 5)
+    u, i = tr.synthetic_batch(5, 0)
+    for bad_u, bad_i in ((u[:200], i[:200]), (torch.cat([u, u]), torch.cat([i, i]))):
+        with pytest.raises(ValueError):
+            tr.step(bad_u, bad_i)
+        with pytest.raises(ValueError):
+            tr.evaluate(bad_u, bad_i)
+        with pytest.raises(ValueError):
+            tr.evaluate_topk(bad_u, bad_i, FactorizedTopK(ks=(1,)), corpus=torch.zeros(400, 32, device=dev))
+    with pytest.raises(ValueError):
+        tr.step(u, i, sample_weight=torch.ones(255, device=dev))
+    with pytest.raises(ValueError):
+        tr.evaluate(u, i, candidate_ids=i[:100])
+    # ops level: the kernels index outputs / option vectors by n_ids / nq / nc without looking at their shapes
+    with pytest.raises(RuntimeError):
+        ops.embedding_gather(tr.user_table, u, out=torch.empty(128, 32, device=dev))
+    with pytest.raises(RuntimeError):
+        ops.embedding_gather2(tr.user_table, u, torch.empty(256, 32, device=dev), tr.item_table, i, torch.empty(255, 32, device=dev))
+    q = torch.zeros(64, 32, device=dev)
+    ws = torch.empty(ops.retrieval_workspace_bytes(64, 64, 32), dtype=torch.uint8, device=dev)
+    v = lambda n: torch.empty(n, device=dev)
+    with pytest.raises(RuntimeError):
+        ops.retrieval_fwd(q, q, 1.0, ws, v(64), v(64), v(1), sample_weight=v(63))
+    with pytest.raises(RuntimeError):
+        ops.retrieval_fwd_bwd(q, q, 1.0, ws, v(64), v(64), v(1), torch.empty(64, 32, device=dev), torch.empty(63, 32, device=dev))
+    tr.step(u, i)                # and the trainer still works afterwards
+    tr.check_ids()
+
+
+def test_checkpoint_resume_continues_the_dropout_stream(dev):
+    """state_dict carries step_index and dropout_seed: after a resume the counter-based dropout masks continue where the
+    checkpoint stopped (no replayed masks), so resumed training is bit-identical to uninterrupted training."""
+    def fresh():
+        return make(dev, 800, 700, 32, [64, 32], 256, "adagrad", 17, dropout=0.2)[1]
+    a = fresh()
+    for s in range(3):
+        a.step(*a.synthetic_batch(17, s))
+    sd = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in a.state_dict().items()}
+    assert sd["step_index"] == 3 and sd["dropout_seed"] == 17
+    for s in range(3, 5):
+        a.step(*a.synthetic_batch(17, s))
+    b2 = fresh()
+    b2.load_state_dict(sd)
+    assert b2.step_index == 3
+    for s in range(3, 5):
+        b2.step(*b2.synthetic_batch(17, s))
+    assert torch.equal(a.user_table, b2.user_table) and torch.equal(a.item_table, b2.item_table)
+    assert torch.equal(a.dense_flat, b2.dense_flat) and torch.equal(a.dense_accum, b2.dense_accum)
+
+
+def test_out_of_range_id_is_reported_by_the_periodic_poll_with_its_step(dev):
+    """No per-epoch wait: step() polls the flag every `flag_poll_every` steps through an asynchronous 4-byte copy and
+    raises one interval later, naming the step range."""
+    cfg, tr, _ = make(dev, 100, 100, 32, [32], 256, "sgd", 5)
+    tr.flag_poll_every = 2
+    u, i = tr.synthetic_batch(5, 0)
+    bad = u.clone()
+    bad[7] = 100
+    tr.step(u, i)                                   # step 0: poll starts a (clean) copy
+    tr.step(bad, i)                                 # step 1: the bad id
+    with pytest.raises(IndexError, match="step"):
+        for _ in range(6):                          # polls at steps 2, 4, 6: copy the raised flag, then see it
+            tr.step(u, i)
+            torch.cuda.synchronize()
+    tr.step(u, i)
+    tr.check_ids()                                  # flag was cleared by the raise
 
 
 def test_out_of_range_id_is_reported(dev):

@@ -1,5 +1,8 @@
 """Host-side logic that needs no GPU: the reference's YAML schema, the parquet reader, the task object's
 argument validation (error behaviour mirrors tfrs.tasks.Retrieval)."""
+import os
+import pathlib
+
 import numpy as np
 import pandas as pd
 import pytest
@@ -96,3 +99,49 @@ def test_trainer_refuses_cpu_device():
         TwoTowerTrainer(cfg, device="cpu")
     with pytest.raises(ValueError):
         TwoTowerConfig(n_users=10, n_items=10, embedding_dim=32, tower_dims=[48], batch_size=8).validate()
+
+
+def test_early_stopping_follows_the_patience_of_the_reference_schema():
+    """configs/data_config.yaml:65 `patience: 5`: stop after 5 evaluations in a row without improvement."""
+    from two_tower_amazon_recommender_amd.train import EarlyStopping
+    es = EarlyStopping(patience=3)
+    assert [es.update(v) for v in (5.0, 4.0, 4.5, 4.2, 3.9)] == [False] * 5 and es.best == 3.9 and es.bad == 0
+    assert [es.update(v) for v in (3.9, 3.95, 3.8999995)] == [False, False, True]     # within min_delta is no improvement
+    es2 = EarlyStopping(patience=3)
+    es2.load_state_dict(es.state_dict())
+    assert (es2.best, es2.bad) == (es.best, es.bad) and es2.update(9.9)
+    one = EarlyStopping(patience=1)
+    assert one.update(1.0) is False and one.update(1.0) is True
+
+
+def test_bench_self_launches_ranks_and_relays_one_json_line(tmp_path):
+    """`python bench.py --gpus N` from a bare shell starts N ranks through torch.distributed.run as a child process,
+    prints rank 0's JSON line on stdout and exits with the child's code — exercised here with a stand-in rank script
+    (gloo, no GPU)."""
+    import json
+    import subprocess
+    import sys
+    root = pathlib.Path(__file__).resolve().parents[1]
+    script = tmp_path / "fake_rank.py"
+    script.write_text(
+        "import json, os, sys\n"
+        "import torch.distributed as dist\n"
+        "dist.init_process_group('gloo')\n"
+        "r, w = dist.get_rank(), dist.get_world_size()\n"
+        "print('noise from rank', r)\n"
+        "dist.barrier()\n"
+        "if r == 0: print(json.dumps({'value': 1.5, 'n_gpus': w, 'argv': sys.argv[1:]}))\n"
+        "dist.destroy_process_group()\n"
+        "sys.exit(int(os.environ.get('FAKE_RC', '0')) if r == w - 1 else 0)\n")
+    driver = ("import sys; sys.path.insert(0, %r); import bench; sys.argv = ['bench.py', '--gpus', '2', '--steps', '3'];\n"
+              "bench.__file__ = %r; args = bench.parse(); raise SystemExit(bench.self_launch(args))") % (str(root), str(script))
+    for rc in (0, 3):
+        env = dict(os.environ, FAKE_RC=str(rc))
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        res = subprocess.run([sys.executable, "-c", driver], capture_output=True, text=True, env=env, timeout=240)
+        lines = [l for l in res.stdout.splitlines() if l.strip()]
+        assert len(lines) == 1, (res.stdout, res.stderr[-2000:])
+        out = json.loads(lines[0])
+        assert out["n_gpus"] == 2 and out["argv"] == ["--gpus", "2", "--steps", "3"]
+        assert (res.returncode == 0) == (rc == 0), (rc, res.returncode, res.stderr[-2000:])

@@ -57,7 +57,7 @@ class OracleRowBackend:
         ok = i >= 0
         dst.numpy()[i[ok]] = src.numpy()[ok]
 
-    def plan(self, ids, num_rows):
+    def plan(self, ids, num_rows, key=None):
         pass
 
     def prefetch_stream(self):
@@ -67,7 +67,7 @@ class OracleRowBackend:
     def join_prefetch(self):
         pass
 
-    def apply(self, opt, table, accum, ids, grads, lr, eps):
+    def apply(self, opt, table, accum, ids, grads, lr, eps, key=None):
         from oracle import two_tower as tt
         i = ids.numpy()
         keep = i >= 0
@@ -184,6 +184,18 @@ def _worker_flags(rank, world, port, ret):
             ret[rank] = "no oob error"
         except IndexError:
             assert not out[5].any()
+        # poll(): the asynchronous form — the copy started by one poll is examined by the next, the error names the step
+        emb.poll(10)                                              # clean flags: nothing to report
+        emb.lookup(ids, out)                                      # sets the out-of-range flag again
+        emb.poll(60)                                              # looks at the copy of step 10 (clean), copies again
+        try:
+            emb.poll(110)
+            ret[rank] = "poll reported nothing"
+        except IndexError as e:
+            if "step 60" not in str(e):
+                ret[rank] = f"poll error does not name the step: {e}"
+        emb.poll(160)
+        emb.poll(210)                                             # flags were cleared by the raise: quiet again
     except Exception:                                             # noqa: BLE001
         import traceback
         ret[rank] = traceback.format_exc()

@@ -90,6 +90,7 @@ SIGNATURES = {
     "tt_dense_bwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
     "tt_dense_update_f32": (C.c_int, [C.POINTER(DenseSeg), _i32, _i32, _i32, _f, _f, _p]),
     "tt_retrieval_workspace_bytes": (_i64, [_i64, _i64, _i32]),
+    "tt_retrieval_rank_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "tt_retrieval_fwd_f32": (C.c_int, [_p, _p, _i64, _i64, _i32, _i64, _f, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p]),
     "tt_retrieval_fwd_bwd_f32": (C.c_int, [_p, _p, _i64, _i64, _i32, _i64, _f, _p, _p, _p, _p, _f, _p, _i64, _p, _p, _p, _p, _p, _p]),
     "tt_retrieval_hard_negative_thresholds_f32": (C.c_int, [_p, _p, _i64, _i64, _i32, _i64, _f, _p, _p, _i32, _p, _i64, _p, _i64, _p, _p]),

@@ -833,6 +833,12 @@ extern "C" int64_t tt_retrieval_workspace_bytes(int64_t nq, int64_t nc, int32_t 
   return ws_layout(nq, nc, dim).total;
 }
 
+// the rank (metric) pass uses the regions in front of the gradient slabs only: bias, threshold, per-split counts
+extern "C" int64_t tt_retrieval_rank_workspace_bytes(int64_t nq, int64_t nc, int32_t dim) {
+  if (nq <= 0 || nc <= 0 || dim <= 0) return 0;
+  return ws_layout(nq, nc, dim).off_pl;
+}
+
 extern "C" int tt_retrieval_fwd_f32(const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
                                     int64_t diag_offset, float inv_temperature, const float* sample_weight,
                                     const float* cand_prob, const int64_t* cand_ids, const float* hard_thr,
@@ -1031,16 +1037,18 @@ extern "C" int tt_retrieval_fwd_bwd_f32(const float* q, const float* c, int64_t 
 extern "C" int tt_retrieval_rank_f32(const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
                                      float inv_temperature, const float* cand_prob, const int64_t* pos_index,
                                      void* workspace, int64_t workspace_bytes, int32_t* rank, tt_stream_t stream_) {
-  int rc = check_common("tt_retrieval_rank_f32", q, c, nq, nc, dim, 0, workspace, workspace_bytes);
-  if (rc != TT_OK && !(nq > nc)) return rc;
+  // (not check_common: a rank pass has no diagonal, so nq > nc is fine, and it needs only the front of the workspace)
+  int rc;
   TT_REQUIRE(q && c && workspace && pos_index && rank, "tt_retrieval_rank_f32: null pointer");
   TT_REQUIRE(nq > 0 && nc > 0, "tt_retrieval_rank_f32: nq and nc must be positive");
   TT_REQUIRE(dim == 32 || dim == 64 || dim == 128 || dim == 256, "tt_retrieval_rank_f32: dim %d not in {32,64,128,256}", dim);
-  if (workspace_bytes < ws_layout(nq, nc, dim).total)
-    return tt::fail(TT_ERR_WORKSPACE, "tt_retrieval_rank_f32: workspace %lld < %lld bytes", (long long)workspace_bytes,
-                    (long long)ws_layout(nq, nc, dim).total);
-  hipStream_t stream = tt::as_stream(stream_);
+  TT_REQUIRE(tt::aligned16(q) && tt::aligned16(c), "tt_retrieval_rank_f32: q/c must be 16-byte aligned");
+  TT_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0, "tt_retrieval_rank_f32: workspace must be 256-byte aligned");
   const WsLayout w = ws_layout(nq, nc, dim);
+  if (workspace_bytes < w.off_pl)
+    return tt::fail(TT_ERR_WORKSPACE, "tt_retrieval_rank_f32: workspace %lld < %lld bytes", (long long)workspace_bytes,
+                    (long long)w.off_pl);
+  hipStream_t stream = tt::as_stream(stream_);
   char* ws = static_cast<char*>(workspace);
   float* bias = reinterpret_cast<float*>(ws + w.off_bias);
   float* thr = reinterpret_cast<float*>(ws + w.off_aq);

@@ -18,6 +18,7 @@ class FactorizedTopK:
         self.reset_state()
 
     def reset_state(self):
+        self._ws = getattr(self, "_ws", None)       # (key, buffer) of the rank pass, kept across batches and resets
         self._n = 0
         self._hits = None
         self._dcg = None
@@ -25,8 +26,12 @@ class FactorizedTopK:
     def update_state(self, query_embeddings: torch.Tensor, candidate_embeddings: torch.Tensor,
                      true_candidate_index: torch.Tensor, candidate_sampling_probability=None) -> torch.Tensor:
         """Accumulates the metrics of one query batch against the candidate corpus; returns the int32 ranks."""
-        rank = ops.retrieval_rank(query_embeddings.contiguous(), candidate_embeddings.contiguous(), self.inv_t,
-                                  true_candidate_index.contiguous(), cand_prob=candidate_sampling_probability)
+        q, c = query_embeddings.contiguous(), candidate_embeddings.contiguous()
+        key = (q.shape[0], c.shape[0], q.shape[1], str(q.device))
+        if self._ws is None or self._ws[0] != key:         # one small buffer per shape, not one allocation per batch
+            self._ws = (key, torch.empty(ops.retrieval_rank_workspace_bytes(*key[:3]), dtype=torch.uint8, device=q.device))
+        rank = ops.retrieval_rank(q, c, self.inv_t, true_candidate_index.contiguous(), workspace=self._ws[1],
+                                  cand_prob=candidate_sampling_probability)
         r = rank.to(torch.float64)
         ks = torch.tensor(self.ks, dtype=torch.float64, device=r.device)
         inside = (r[:, None] < ks[None, :]).to(torch.float64)                   # [nq, len(ks)]

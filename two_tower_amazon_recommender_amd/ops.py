@@ -108,6 +108,8 @@ def embedding_gather(table: torch.Tensor, ids: torch.Tensor, out: torch.Tensor |
     if out is None:
         out = torch.empty((n, d), dtype=torch.float32, device=table.device)
     _chk(out, torch.float32, "out", 2)
+    if tuple(out.shape) != (n, d):
+        raise RuntimeError(f"embedding_gather: out must be [{n}, {d}] (n_ids, dim), got {tuple(out.shape)}")
     if oob_flag is not None:
         _chk(oob_flag, torch.int32, "oob_flag")
     lib = _lib.load()
@@ -124,6 +126,10 @@ def embedding_gather2(table_a, ids_a, out_a, table_b, ids_b, out_b, oob_flag=Non
     _chk(ids_b, torch.int64, "ids_b", 1)
     if ids_a.numel() != ids_b.numel() or table_a.shape[1] != table_b.shape[1]:
         raise RuntimeError("embedding_gather2: both lookups must share n_ids and dim")
+    want = (ids_a.numel(), table_a.shape[1])
+    if tuple(out_a.shape) != want or tuple(out_b.shape) != want:
+        raise RuntimeError(f"embedding_gather2: outputs must be [{want[0]}, {want[1]}] (n_ids, dim), got "
+                           f"{tuple(out_a.shape)} and {tuple(out_b.shape)}")
     lib = _lib.load()
     _lib.check(lib.tt_embedding_gather2_f32(_p(table_a), table_a.shape[0], _p(ids_a), _p(out_a),
                                             _p(table_b), table_b.shape[0], _p(ids_b), _p(out_b),
@@ -360,18 +366,39 @@ def retrieval_workspace_bytes(nq: int, nc: int, dim: int) -> int:
     return int(_lib.load().tt_retrieval_workspace_bytes(nq, nc, dim))
 
 
-def retrieval_fwd(q, c, inv_temperature: float, workspace, lse, per_row, loss, sample_weight=None,
-                  cand_prob=None, cand_ids=None, diag_offset: int = 0, hard_thr=None):
+def _chk_retrieval(q, c, sample_weight=None, cand_prob=None, cand_ids=None, hard_thr=None, lse=None, per_row=None,
+                   dq=None, dc=None):
+    """dtype / device / shape checks shared by the retrieval entry points: the kernels index the optional vectors by
+    query (nq) or candidate (nc) without looking at their length."""
     _chk(q, torch.float32, "query_embeddings", 2)
     _chk(c, torch.float32, "candidate_embeddings", 2)
     if q.shape[1] != c.shape[1]:
         raise RuntimeError(f"retrieval: embedding dims differ: {q.shape[1]} vs {c.shape[1]}")
-    if sample_weight is not None:
-        _chk(sample_weight, torch.float32, "sample_weight", 1)
-    if cand_prob is not None:
-        _chk(cand_prob, torch.float32, "candidate_sampling_probability", 1)
-    if cand_ids is not None:
-        _chk(cand_ids, torch.int64, "candidate_ids", 1)
+    nq, nc = q.shape[0], c.shape[0]
+    for t, dt, name, n in ((sample_weight, torch.float32, "sample_weight", nq), (hard_thr, torch.float32, "hard_thr", nq),
+                           (lse, torch.float32, "lse", nq), (per_row, torch.float32, "per_row", nq),
+                           (cand_prob, torch.float32, "candidate_sampling_probability", nc),
+                           (cand_ids, torch.int64, "candidate_ids", nc)):
+        if t is not None:
+            _chk(t, dt, name, 1)
+            if t.numel() != n:
+                raise RuntimeError(f"retrieval: {name} must have {n} entries, got {t.numel()}")
+    for t, name, ref in ((dq, "dq", q), (dc, "dc", c)):
+        if t is not None:
+            _chk(t, torch.float32, name, 2)
+            if tuple(t.shape) != tuple(ref.shape):
+                raise RuntimeError(f"retrieval: {name} must be {tuple(ref.shape)}, got {tuple(t.shape)}")
+
+
+def retrieval_rank_workspace_bytes(nq: int, nc: int, dim: int) -> int:
+    """Workspace of the metric (rank) pass alone: no gradient slabs (those make the full workspace as large as the
+    candidate corpus when nc >= 65536)."""
+    return int(_lib.load().tt_retrieval_rank_workspace_bytes(nq, nc, dim))
+
+
+def retrieval_fwd(q, c, inv_temperature: float, workspace, lse, per_row, loss, sample_weight=None,
+                  cand_prob=None, cand_ids=None, diag_offset: int = 0, hard_thr=None):
+    _chk_retrieval(q, c, sample_weight, cand_prob, cand_ids, hard_thr, lse, per_row)
     lib = _lib.load()
     _lib.check(lib.tt_retrieval_fwd_f32(_p(q), _p(c), q.shape[0], c.shape[0], q.shape[1], diag_offset, inv_temperature,
                                         _p(sample_weight), _p(cand_prob), _p(cand_ids), _p(hard_thr), _p(workspace),
@@ -381,6 +408,7 @@ def retrieval_fwd(q, c, inv_temperature: float, workspace, lse, per_row, loss, s
 
 def retrieval_bwd(q, c, inv_temperature: float, workspace, lse, dq, dc, sample_weight=None, cand_prob=None,
                   cand_ids=None, diag_offset: int = 0, grad_scale: float = 1.0, hard_thr=None):
+    _chk_retrieval(q, c, sample_weight, cand_prob, cand_ids, hard_thr, lse, None, dq, dc)
     lib = _lib.load()
     _lib.check(lib.tt_retrieval_bwd_f32(_p(q), _p(c), q.shape[0], c.shape[0], q.shape[1], diag_offset, inv_temperature,
                                         _p(sample_weight), _p(cand_prob), _p(cand_ids), _p(hard_thr), _p(lse), grad_scale,
@@ -392,16 +420,7 @@ def retrieval_bwd(q, c, inv_temperature: float, workspace, lse, dq, dc, sample_w
 def retrieval_fwd_bwd(q, c, inv_temperature: float, workspace, lse, per_row, loss, dq, dc, sample_weight=None,
                       cand_prob=None, cand_ids=None, diag_offset: int = 0, grad_scale: float = 1.0, hard_thr=None):
     """Loss and both gradients in two fused passes (training form)."""
-    _chk(q, torch.float32, "query_embeddings", 2)
-    _chk(c, torch.float32, "candidate_embeddings", 2)
-    if q.shape[1] != c.shape[1]:
-        raise RuntimeError(f"retrieval: embedding dims differ: {q.shape[1]} vs {c.shape[1]}")
-    if sample_weight is not None:
-        _chk(sample_weight, torch.float32, "sample_weight", 1)
-    if cand_prob is not None:
-        _chk(cand_prob, torch.float32, "candidate_sampling_probability", 1)
-    if cand_ids is not None:
-        _chk(cand_ids, torch.int64, "candidate_ids", 1)
+    _chk_retrieval(q, c, sample_weight, cand_prob, cand_ids, hard_thr, lse, per_row, dq, dc)
     lib = _lib.load()
     _lib.check(lib.tt_retrieval_fwd_bwd_f32(_p(q), _p(c), q.shape[0], c.shape[0], q.shape[1], diag_offset, inv_temperature,
                                             _p(sample_weight), _p(cand_prob), _p(cand_ids), _p(hard_thr), grad_scale, _p(workspace),
@@ -418,8 +437,12 @@ def retrieval_rank(q, c, inv_temperature: float, pos_index, workspace=None, cand
     if cand_prob is not None:
         _chk(cand_prob, torch.float32, "candidate_sampling_probability", 1)
     nq, nc, d = q.shape[0], c.shape[0], q.shape[1]
-    if workspace is None:
-        workspace = torch.empty(retrieval_workspace_bytes(nq, nc, d), dtype=torch.uint8, device=q.device)
+    if q.shape[1] != c.shape[1]:
+        raise RuntimeError(f"retrieval: embedding dims differ: {q.shape[1]} vs {c.shape[1]}")
+    if pos_index.numel() != nq or (cand_prob is not None and cand_prob.numel() != nc):
+        raise RuntimeError("retrieval_rank: pos_index needs nq entries and candidate_sampling_probability nc")
+    if workspace is None:       # the rank pass needs only the bias / threshold / count regions, not the gradient slabs
+        workspace = torch.empty(retrieval_rank_workspace_bytes(nq, nc, d), dtype=torch.uint8, device=q.device)
     if out is None:
         out = torch.empty(nq, dtype=torch.int32, device=q.device)
     lib = _lib.load()

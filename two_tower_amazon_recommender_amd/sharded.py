@@ -42,13 +42,13 @@ class HipRowBackend:
         from . import ops
         self.ops = ops
         self.device = device
-        self._plans = {}
+        self._plans = {}          # (owner key, n ids) -> SparsePlan; the key is the ShardedTables instance using the backend
         # High-priority streams: ROCm keeps a separate hardware-queue pool per priority, so these never land on the
         # main stream's queue (with the default priority the sort plan ended up serialised behind the compute kernels
         # whenever the stream -> queue round-robin happened to collide, e.g. after RCCL had created its streams)
         self._side = torch.cuda.Stream(device=device, priority=-1)
         self._pre = torch.cuda.Stream(device=device, priority=-1)
-        self._pending = None
+        self._pending = {}        # owner key -> the plan its next apply() consumes
 
     @contextlib.contextmanager
     def prefetch_stream(self):
@@ -69,24 +69,33 @@ class HipRowBackend:
     def scatter_rows(self, src, idx, dst):
         self.ops.scatter_rows(src, idx, dst)
 
-    def plan(self, ids, num_rows):
-        """Sort the owner-side ids on a side stream (they are known right after C1)."""
+    def plan(self, ids, num_rows, key=None):
+        """Sort the owner-side ids on a side stream (they are known right after C1).  ``key`` names the caller
+        (one ShardedTables): several sharded tables may share a backend without sharing plans."""
         n = ids.numel()
-        plan = self._plans.get((n, ids.data_ptr()))
+        plan = self._plans.get((key, n, ids.data_ptr()))
         if plan is None:
-            plan = self._plans[(n, ids.data_ptr())] = self.ops.SparsePlan(n, ids.device)
+            plan = self._plans[(key, n, ids.data_ptr())] = self.ops.SparsePlan(n, ids.device)
         self._side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self._side):
             plan.run(ids, num_rows)
-        self._pending = plan
+        self._pending[key] = plan
 
-    def apply(self, opt, table, accum, ids, grads, lr, eps):
-        plan = self._pending
+    def apply(self, opt, table, accum, ids, grads, lr, eps, key=None):
+        plan = self._pending.pop(key)
         torch.cuda.current_stream().wait_stream(self._side)
         if opt == "sgd":
             self.ops.sparse_sgd_(table, grads, plan, lr)
         else:
             self.ops.sparse_adagrad_(table, accum, grads, plan, lr, eps)
+
+
+class _Ready:
+    """Stand-in for a CUDA event on the CPU/gloo test path: the copy is synchronous, so it is always complete."""
+
+    @staticmethod
+    def query():
+        return True
 
 
 def shard_rows(num_rows: int, world: int, rank: int) -> int:
@@ -133,6 +142,9 @@ class ShardedTables:
         self._cur = 0
         self._prefetched = None
         self.flags = torch.zeros(2, dtype=torch.int32, device=device)   # [oob, overflow]
+        self._flag_host = None          # pinned copy of the flags taken by poll(); checked one poll later, without a sync
+        self._flag_event = None
+        self._flag_step = -1
 
     def _make_idbufs(self):
         n = self.world * self.n_tables * self.cap
@@ -213,7 +225,7 @@ class ShardedTables:
         """owner side: sort plan (side stream), K1 gather, C2 (rows back to the requesters)."""
         self._wait(self._w)
         be = self.backend
-        be.plan(self.recv_ids, self.table.shape[0])
+        be.plan(self.recv_ids, self.table.shape[0], key=id(self))
         be.gather(self.table, self.recv_ids, self.rows_out, self.flags[0:1])       # K1
         self._w = self._a2a(self.rows_in, self.rows_out, overlap=False)            # C2
 
@@ -237,17 +249,48 @@ class ShardedTables:
     def grads_finish(self, opt: str, lr: float, eps: float = 1e-7):
         """K2: fused sparse update on the owner (duplicates summed first, in (source rank, position) order)."""
         self._wait(self._w)
-        self.backend.apply(opt, self.table, self.accum, self.recv_ids, self.rows_out, lr, eps)
+        self.backend.apply(opt, self.table, self.accum, self.recv_ids, self.rows_out, lr, eps, key=id(self))
 
     def apply_gradients(self, grads: torch.Tensor, opt: str, lr: float, eps: float = 1e-7):
         """grads[t*batch + p, :] = dLoss/d(out[t*batch + p, :]) of the last lookup (K2', C3, K2)."""
         self.grads_start(grads)
         self.grads_finish(opt, lr, eps)
 
+    def _raise_flags(self, f, when: str):
+        if int(f[0]):
+            raise IndexError(f"embedding id out of range {when}")
+        if int(f[1]):
+            raise RuntimeError(f"sharded exchange overflow {when}: more than {self.cap} positions for one owner; "
+                               "raise capacity_factor")
+
+    def poll(self, step_index: int):
+        """Asynchronous check of [out-of-range, overflow]: looks at the flag copy taken by the PREVIOUS poll (if its
+        8-byte device-to-pinned-host copy has landed — never waits for the GPU) and starts a new one.  A bad id or an
+        overflowed bucket is therefore reported one polling interval late at most, with the step range it happened in,
+        instead of at the end of the epoch."""
+        if self._flag_event is not None and self._flag_event.query():
+            f = self._flag_host.tolist()
+            self._flag_event = None
+            if int(f[0]) or int(f[1]):
+                self.flags.zero_()
+                self._raise_flags(f, f"at or before step {self._flag_step}")
+        if self._flag_event is None:
+            if self._flag_host is None:
+                self._flag_host = torch.zeros(2, dtype=torch.int32).pin_memory() if self.flags.is_cuda \
+                    else torch.zeros(2, dtype=torch.int32)
+            self._flag_host.copy_(self.flags, non_blocking=True)
+            if self.flags.is_cuda:
+                self._flag_event = torch.cuda.Event()
+                self._flag_event.record()
+            else:
+                self._flag_event = _Ready()
+            self._flag_step = step_index
+
     def check(self):
         """Host check (synchronises): out-of-range ids (TF's gather raises) and exchange-buffer overflow."""
         f = self.flags.tolist()          # (a copy: .cpu() would alias a CPU tensor)
         self.flags.zero_()
+        self._flag_event = None
         if int(f[0]):
             raise IndexError("embedding id out of range in a previous step")
         if int(f[1]):
@@ -353,6 +396,7 @@ class ShardedTwoTowerTrainer:
             self.c_all = torch.empty(nc, sd, device=dev)
             self.dc_all = torch.empty(nc, sd, device=dev)
         self.step_index = 0
+        self.flag_poll_every = 50     # steps between asynchronous [out-of-range, overflow] flag polls (0 = never)
         self.dropout_seed = 0 if seed is None else seed
         if seed is not None:
             self.init_synthetic(seed)
@@ -404,9 +448,23 @@ class ShardedTwoTowerTrainer:
         dist.all_gather_into_tensor(self.p_all, p.contiguous(), group=self.group)
         return self.p_all
 
+    def _cand_ids(self, ids):
+        """candidate_ids (accidental-hit removal) of the candidates this rank scores against: its own batch's for local
+        negatives, every rank's (all-gathered, rank-major like the candidate embeddings) for global negatives."""
+        if ids is None or self.negatives == "local" or not self.collectives:
+            return ids
+        if not hasattr(self, "id_all"):
+            self.id_all = torch.empty(self.cfg.batch_size * self.world, dtype=torch.int64, device=self.dev)
+        dist.all_gather_into_tensor(self.id_all, ids.contiguous(), group=self.group)
+        return self.id_all
+
     def step(self, user_ids: torch.Tensor, item_ids: torch.Tensor, next_ids=None, category_ids=None,
-             candidate_sampling_probability=None, prefetch_exchange: bool = False) -> torch.Tensor:
+             candidate_sampling_probability=None, prefetch_exchange: bool = False, sample_weight=None,
+             candidate_ids=None) -> torch.Tensor:
         """One train step on this rank's batch; returns this rank's (device, unsynchronised) loss.
+        sample_weight [batch] weighs this rank's pairs; candidate_sampling_probability / candidate_ids [batch] describe
+        this rank's candidates (logQ correction / accidental-hit removal, tfrs.tasks.Retrieval) and are all-gathered
+        with the candidates when negatives are global.
         next_ids = (user_ids, item_ids) of the following step, if the input pipeline already has them: they are
         routed beside this step's scorer (and, with prefetch_exchange, their id all-to-all is issued there too); pass
         the same tensors to the next call."""
@@ -415,6 +473,14 @@ class ShardedTwoTowerTrainer:
         b, w = cfg.batch_size, self.world
         if (category_ids is None) != (self.cat_table is None):
             raise ValueError("category_ids must be given exactly when cfg.n_category_buckets > 0")
+        if user_ids.numel() != b or item_ids.numel() != b:
+            raise ValueError(f"batch must have {b} pairs per rank")
+        for name, v in (("sample_weight", sample_weight), ("candidate_sampling_probability", candidate_sampling_probability),
+                        ("candidate_ids", candidate_ids)):
+            if v is not None and v.numel() != b:
+                raise ValueError(f"{name} must have {b} entries (this rank's batch)")
+        if self.flag_poll_every and self.step_index % self.flag_poll_every == 0:
+            em.poll(self.step_index)              # bad ids / overflowed buckets surface within one interval, no sync
         em.lookup_start((user_ids, item_ids))
         em.lookup_rows()
         if category_ids is not None:          # the replicated table's sort plan joins the owner plan on the side stream
@@ -435,13 +501,15 @@ class ShardedTwoTowerTrainer:
             c = it.forward((cfg.dropout_rate, self.dropout_seed, 1, row0))
         inv_t = 1.0 / cfg.temperature
         cp = self._cand_prob(candidate_sampling_probability)
+        ci = self._cand_ids(candidate_ids)
         if self.negatives == "local" or not self.collectives:
-            ops.retrieval_fwd_bwd(q, c, inv_t, self.ws, self.lse, self.per_row, self.loss, ut.dz[-1], it.dz[-1], cand_prob=cp)
+            ops.retrieval_fwd_bwd(q, c, inv_t, self.ws, self.lse, self.per_row, self.loss, ut.dz[-1], it.dz[-1], cand_prob=cp,
+                                  sample_weight=sample_weight, cand_ids=ci)
         else:
             dist.all_gather_into_tensor(self.c_all, c, group=self.group)                       # C4
             off = self.rank * b
             ops.retrieval_fwd_bwd(q, self.c_all, inv_t, self.ws, self.lse, self.per_row, self.loss, ut.dz[-1], self.dc_all,
-                                  diag_offset=off, cand_prob=cp)
+                                  diag_offset=off, cand_prob=cp, sample_weight=sample_weight, cand_ids=ci)
             dist.reduce_scatter_tensor(it.dz[-1], self.dc_all, op=dist.ReduceOp.SUM, group=self.group)   # C5
 
         # every dx first: the embedding gradient rows travel to their owners beside the dw GEMMs and the dense reduce
@@ -497,13 +565,15 @@ class ShardedTwoTowerTrainer:
     def _inputs(self, user_ids, item_ids, category_ids):
         if (category_ids is None) != (self.cat_table is None):
             raise ValueError("category_ids must be given exactly when cfg.n_category_buckets > 0")
+        if user_ids.numel() != self.cfg.batch_size or item_ids.numel() != self.cfg.batch_size:
+            raise ValueError(f"batch must have {self.cfg.batch_size} pairs per rank (the buffers are sized for it)")
         self.emb.lookup((user_ids, item_ids), self.emb_in)
         if category_ids is not None:
             self.ops.embedding_gather_add_(self.item_tower.acts[0], self.cat_table, category_ids, self.emb.flags[0:1])
 
     @torch.no_grad()
     def evaluate(self, user_ids: torch.Tensor, item_ids: torch.Tensor, category_ids=None,
-                 candidate_sampling_probability=None) -> torch.Tensor:
+                 candidate_sampling_probability=None, sample_weight=None, candidate_ids=None) -> torch.Tensor:
         """Forward only: this rank's validation loss (SUM over its batch; device tensor, unsynchronised).  Collective:
         every rank must call it the same number of times."""
         from .trainer import towers_forward
@@ -511,11 +581,13 @@ class ShardedTwoTowerTrainer:
         self._inputs(user_ids, item_ids, category_ids)
         q, c = towers_forward(ut, it) if cfg.symmetric else (ut.forward(), it.forward())
         cp = self._cand_prob(candidate_sampling_probability)
+        ci = self._cand_ids(candidate_ids)
         if self.negatives == "local" or not self.collectives:
-            return ops.retrieval_fwd(q, c, 1.0 / cfg.temperature, self.ws, self.lse, self.per_row, self.loss, cand_prob=cp)
+            return ops.retrieval_fwd(q, c, 1.0 / cfg.temperature, self.ws, self.lse, self.per_row, self.loss, cand_prob=cp,
+                                     sample_weight=sample_weight, cand_ids=ci)
         dist.all_gather_into_tensor(self.c_all, c, group=self.group)
         return ops.retrieval_fwd(q, self.c_all, 1.0 / cfg.temperature, self.ws, self.lse, self.per_row, self.loss,
-                                 diag_offset=self.rank * cfg.batch_size, cand_prob=cp)
+                                 diag_offset=self.rank * cfg.batch_size, cand_prob=cp, sample_weight=sample_weight, cand_ids=ci)
 
     @torch.no_grad()
     def item_corpus_embeddings(self, item_category_ids: torch.Tensor | None = None) -> torch.Tensor:
@@ -555,11 +627,15 @@ class ShardedTwoTowerTrainer:
         """THIS RANK's part of the checkpoint: its rows of both tables (global rows rank, rank+world, ...), their
         Adagrad accumulators, and the replicated dense parameters (+ category table).  One file per rank; plain
         tensors, so ``torch.load(..., weights_only=True)`` reads it back."""
+        # the shards are slices of the combined allocation: torch.save would serialise the WHOLE storage behind a view,
+        # so the checkpoint holds compact copies
+        own = lambda t: t.detach().contiguous().clone()
         sd = {"config": dict(self.cfg.__dict__), "world": self.world, "rank": self.rank, "negatives": self.negatives,
-              "step_index": self.step_index, "user_shard": self.emb.shard(0), "item_shard": self.emb.shard(1),
-              "dense": self.dense_flat}
+              "step_index": self.step_index, "dropout_seed": self.dropout_seed,
+              "user_shard": own(self.emb.shard(0)), "item_shard": own(self.emb.shard(1)), "dense": own(self.dense_flat)}
         if self.cfg.optimizer == "adagrad":
-            sd.update(user_accum=self.emb.accum_shard(0), item_accum=self.emb.accum_shard(1), dense_accum=self.dense_accum)
+            sd.update(user_accum=own(self.emb.accum_shard(0)), item_accum=own(self.emb.accum_shard(1)),
+                      dense_accum=own(self.dense_accum))
         return sd
 
     def load_state_dict(self, sd: dict):
@@ -575,6 +651,7 @@ class ShardedTwoTowerTrainer:
             self.emb.accum_shard(0).copy_(sd["user_accum"]); self.emb.accum_shard(1).copy_(sd["item_accum"])
             self.dense_accum.copy_(sd["dense_accum"])
         self.step_index = int(sd.get("step_index", 0))
+        self.dropout_seed = int(sd.get("dropout_seed", self.dropout_seed))
 
     def check_ids(self):
         self.emb.check()

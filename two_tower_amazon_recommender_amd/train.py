@@ -26,6 +26,29 @@ from .trainer import TwoTowerTrainer
 log = logging.getLogger("train")
 
 
+class EarlyStopping:
+    """`model.training.patience` of the reference's schema (configs/data_config.yaml:65): stop after `patience`
+    consecutive evaluations without an improvement of the validation loss by more than `min_delta`."""
+
+    def __init__(self, patience: int, min_delta: float = 1e-6):
+        self.patience, self.min_delta = int(patience), float(min_delta)
+        self.best, self.bad = float("inf"), 0
+
+    def update(self, value: float) -> bool:
+        """Record one evaluation; returns True when training should stop."""
+        if value < self.best - self.min_delta:
+            self.best, self.bad = value, 0
+        else:
+            self.bad += 1
+        return self.bad >= self.patience
+
+    def state_dict(self) -> dict:
+        return {"best": self.best, "bad": self.bad}
+
+    def load_state_dict(self, sd: dict):
+        self.best, self.bad = float(sd["best"]), int(sd["bad"])
+
+
 def parse(argv=None):
     ap = argparse.ArgumentParser(description="Train the two-tower retrieval model on MI355X (HIP kernels).")
     ap.add_argument("--config", required=True, help="YAML with a `model:` block (configs/data_config.yaml schema)")
@@ -47,6 +70,8 @@ def parse(argv=None):
     ap.add_argument("--device", default="cuda:0")
     ap.add_argument("--save", default=None, help="write a checkpoint (torch.save of tensors) here at the end "
                                                  "(distributed: one file per rank, <path>.rank<r>of<N>)")
+    ap.add_argument("--resume", default=None, help="continue from a checkpoint written by --save (distributed: the "
+                                                   "<path>.rank<r>of<N> files of the same world size)")
     ap.add_argument("--distributed", action="store_true",
                     help="use the row-sharded multi-GPU trainer (implied when WORLD_SIZE > 1); batch_size is per rank")
     ap.add_argument("--negatives", default="local", choices=["local", "global"],
@@ -143,8 +168,16 @@ def main(argv=None) -> int:
         if item_prob is not None:
             k["candidate_sampling_probability"] = item_prob[batch[1]]
         return k
-    best, bad, history = float("inf"), 0, []
-    for epoch in range(epochs):
+    stopper, history, first_epoch = EarlyStopping(loop["patience"]), [], 0
+    if args.resume:
+        path = f"{args.resume}.rank{rank}of{world}" if distributed else args.resume
+        ck = torch.load(path, map_location=trainer.dev, weights_only=True)       # plain tensors / numbers only
+        trainer.load_state_dict(ck)
+        first_epoch = int(ck.get("epoch", 0))
+        if "early_stopping" in ck:
+            stopper.load_state_dict(ck["early_stopping"])
+        log.info("resumed from %s (epoch %d, step %d)", path, first_epoch, trainer.step_index)
+    for epoch in range(first_epoch, epochs):
         t0 = time.perf_counter()
         tot = torch.zeros((), device=trainer.dev, dtype=torch.float64)
         for batch in train_it:
@@ -159,14 +192,14 @@ def main(argv=None) -> int:
             for batch in val_it:
                 vt += trainer.evaluate(batch[0], batch[1], **kw(batch)).double().squeeze()
             rec["val_loss_per_pair"] = total(vt) / (len(val_it) * cfg.batch_size * world)
-            if rec["val_loss_per_pair"] < best - 1e-6:
-                best, bad = rec["val_loss_per_pair"], 0
-            else:
-                bad += 1
+            stop = stopper.update(rec["val_loss_per_pair"])
+        else:
+            stop = False
         history.append(rec)
         log.info(json.dumps(rec))
-        if bad >= loop["patience"]:                      # early stopping (configs/data_config.yaml:65)
-            log.info("early stop: no validation improvement for %d evaluations", bad)
+        last_epoch = epoch + 1
+        if stop:                                         # early stopping (configs/data_config.yaml:65)
+            log.info("early stop: no validation improvement for %d evaluations", stopper.bad)
             break
     final = {"history": history}
     if loop["top_k_eval"] and len(val_it):
@@ -189,7 +222,9 @@ def main(argv=None) -> int:
         log.info(json.dumps(final["val_metrics"]))
     if args.save:
         path = f"{args.save}.rank{rank}of{world}" if distributed else args.save
-        torch.save(trainer.state_dict(), path)
+        ck = trainer.state_dict()
+        ck.update(epoch=last_epoch if history else first_epoch, early_stopping=stopper.state_dict())
+        torch.save(ck, path)
         log.info("saved checkpoint to %s", path)
     if rank == 0:
         print(json.dumps(final))

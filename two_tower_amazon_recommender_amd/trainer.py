@@ -226,6 +226,9 @@ class TwoTowerTrainer:
         # the main stream's kernels, whatever other streams the process has created
         self._side = torch.cuda.Stream(device=dev, priority=-1)
         self.step_index = 0                      # counter of the dropout stream (global batch row = step*batch + r)
+        self.flag_poll_every = 50                # steps between asynchronous polls of the out-of-range flag (0 = never)
+        self._oob_host = self._oob_event = None
+        self._oob_step = -1
         self.dropout_seed = 0 if seed is None else seed
         self._segs = self.user_tower.segments(cfg.l2_regularization) + self.item_tower.segments(cfg.l2_regularization)
         if seed is not None:
@@ -273,8 +276,18 @@ class TwoTowerTrainer:
         if category_ids is not None and category_ids.numel() != self.cfg.batch_size:
             raise ValueError(f"category_ids must have {self.cfg.batch_size} entries")
 
+    def _check_batch(self, *id_tensors):
+        """The tower buffers hold exactly cfg.batch_size rows: more ids would write past them, fewer would leave stale
+        rows that the scorer still reads."""
+        b = self.cfg.batch_size
+        for t in id_tensors:
+            if t is not None and t.numel() != b:
+                raise ValueError(f"batch must have exactly {b} entries (got {t.numel()}): the kernels' buffers are sized "
+                                 "for cfg.batch_size; pad or drop a ragged last batch")
+
     def _item_inputs(self, user_ids, item_ids, category_ids):
         """K1: both towers' input rows; the hashed category's row is summed into the item tower's input."""
+        self._check_batch(user_ids, item_ids, category_ids)
         ut, it = self.user_tower, self.item_tower
         ops.embedding_gather2(self.user_table, user_ids, ut.acts[0], self.item_table, item_ids, it.acts[0], self.oob)
         if category_ids is not None:
@@ -319,8 +332,10 @@ class TwoTowerTrainer:
 
     def step(self, user_ids: torch.Tensor, item_ids: torch.Tensor, **loss_kw) -> torch.Tensor:
         """One train step; returns the (device, unsynchronised) retrieval loss (SUM over the batch)."""
-        if user_ids.numel() != self.cfg.batch_size or item_ids.numel() != self.cfg.batch_size:
-            raise ValueError(f"batch must have {self.cfg.batch_size} pairs")
+        self._check_batch(user_ids, item_ids, loss_kw.get("category_ids"), loss_kw.get("sample_weight"),
+                          loss_kw.get("candidate_sampling_probability"), loss_kw.get("candidate_ids"))
+        if self.flag_poll_every and self.step_index % self.flag_poll_every == 0:
+            self.poll_ids()
         # the sort plans depend on the ids only: they run on a side stream beside the forward/backward pass
         main = torch.cuda.current_stream()
         self._side.wait_stream(main)
@@ -338,6 +353,8 @@ class TwoTowerTrainer:
         """Forward only (validation loss, SUM over the batch); device tensor, unsynchronised."""
         cfg, ut, it = self.cfg, self.user_tower, self.item_tower
         self._check_categories(loss_kw.get("category_ids"))
+        self._check_batch(loss_kw.get("sample_weight"), loss_kw.get("candidate_sampling_probability"),
+                          loss_kw.get("candidate_ids"))
         self._item_inputs(user_ids, item_ids, loss_kw.get("category_ids"))
         q, c = towers_forward(ut, it) if cfg.symmetric else (ut.forward(), it.forward())
         kw = dict(sample_weight=loss_kw.get("sample_weight"), cand_prob=loss_kw.get("candidate_sampling_probability"),
@@ -367,6 +384,7 @@ class TwoTowerTrainer:
     def evaluate_topk(self, user_ids: torch.Tensor, item_ids: torch.Tensor, metric, corpus: torch.Tensor | None = None):
         """Updates ``metric`` (metrics.FactorizedTopK) with one batch of (user, true item) pairs scored against the
         whole item corpus; returns the ranks."""
+        self._check_batch(user_ids, item_ids)
         if corpus is None:
             corpus = self.item_corpus_embeddings()
         ut = self.user_tower
@@ -377,7 +395,7 @@ class TwoTowerTrainer:
     # ------------------------------------------------------------------ checkpoint
     def state_dict(self) -> dict:
         sd = {"config": dict(self.cfg.__dict__), "user_table": self.user_table, "item_table": self.item_table,
-              "dense": self.dense_flat}
+              "dense": self.dense_flat, "step_index": self.step_index, "dropout_seed": self.dropout_seed}
         if self.cat_table is not None:
             sd["cat_table"] = self.cat_table
         if self.cfg.optimizer == "adagrad":
@@ -389,8 +407,11 @@ class TwoTowerTrainer:
     def load_state_dict(self, sd: dict):
         for k in ("n_users", "n_items", "embedding_dim", "tower_dims", "item_tower_dims", "optimizer", "n_category_buckets"):
             if sd["config"].get(k, 0 if k == "n_category_buckets" else None) != getattr(self.cfg, k):
-                raise ValueError(f"checkpoint {k}={sd['config'][k]!r} does not match the trainer's {getattr(self.cfg, k)!r}")
+                raise ValueError(f"checkpoint {k}={sd['config'].get(k)!r} does not match the trainer's {getattr(self.cfg, k)!r}")
         self.user_table.copy_(sd["user_table"]); self.item_table.copy_(sd["item_table"]); self.dense_flat.copy_(sd["dense"])
+        # the counter-based dropout stream continues where the checkpoint stopped (no replayed masks)
+        self.step_index = int(sd.get("step_index", 0))
+        self.dropout_seed = int(sd.get("dropout_seed", self.dropout_seed))
         if self.cat_table is not None:
             self.cat_table.copy_(sd["cat_table"])
             if self.cfg.optimizer == "adagrad":
@@ -446,8 +467,26 @@ class TwoTowerTrainer:
         self._graph.replay()
         return self.loss
 
+    def poll_ids(self):
+        """Asynchronous check of the out-of-range flag: looks at the copy the PREVIOUS poll started (if it has landed —
+        never waits for the GPU) and starts a new 4-byte device-to-pinned-host copy.  step() calls it every
+        ``flag_poll_every`` steps, so a bad id is reported within one interval, with the step it was seen at."""
+        if self._oob_event is not None and self._oob_event.query():
+            bad, self._oob_event = int(self._oob_host.item()), None
+            if bad:
+                self.oob.zero_()
+                raise IndexError(f"embedding id out of range at or before step {self._oob_step}")
+        if self._oob_event is None:
+            if self._oob_host is None:
+                self._oob_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._oob_host.copy_(self.oob, non_blocking=True)
+            self._oob_event = torch.cuda.Event()
+            self._oob_event.record()
+            self._oob_step = self.step_index
+
     def check_ids(self):
         """Host check of the out-of-range flag (TF's CPU gather raises InvalidArgumentError); synchronises."""
+        self._oob_event = None
         if int(self.oob.item()) != 0:
             self.oob.zero_()
             raise IndexError("embedding id out of range in a previous step")
