@@ -236,13 +236,26 @@ int tt_dense_bwd_scaled_f32(const float* x, const float* w, const float* dz,
  * fwd: 1 launch, bwd: 1 launch (the dx tiles and the dw+db tiles of the layer side by side; 2 launches when
  * only dx or only dw is asked for) — instead of twice as many half-size launches.
  * `probs` is a HOST array of n_probs (1 or 2) entries.                                                     */
+/* Embedding lookup FUSED into the layer (a1 + a2, the tower's first Dense): with a non-NULL `ids` the layer's input
+ * x is never materialised — row r of x is row ids[r] of `table` [table_rows, k] (+ row ids2[r] of `table2`, the
+ * hashed-category feature summed into the item tower's input; one f32 add per element), read straight into the
+ * GEMM's LDS tiles by the forward pass (x @ w) and by the backward pass's dW = x^T @ dz.  Ids outside
+ * [0, table_rows) give a zero row; -1 is a silent padding id, any other sets *oob_flag.  All-zero = no lookup.
+ * Needs m <= 32768 (the ids of one dW split are staged in LDS).                                                  */
+typedef struct tt_dense_lookup {
+  const float* table;  const int64_t* ids;  int64_t table_rows;
+  const float* table2; const int64_t* ids2; int64_t table2_rows;     /* optional */
+  int32_t* oob_flag;                                                 /* optional */
+} tt_dense_lookup;
 typedef struct tt_dense_fwd_args {
   const float* x; const float* w; const float* b; float* y;
   uint64_t dropout_tensor_id;       /* counter stream of this problem's dropout mask (ignored at rate 0) */
+  tt_dense_lookup lookup;           /* x may be NULL when lookup.ids is given */
 } tt_dense_fwd_args;
 typedef struct tt_dense_bwd_args {
   const float* x; const float* w; const float* dz; float* dx; const float* dx_relu_src;
   float* dw_slabs; float* db_slabs;
+  tt_dense_lookup lookup;           /* x may be NULL when lookup.ids is given (dW reads the table rows) */
 } tt_dense_bwd_args;
 int tt_dense_fwd_batched_f32(const tt_dense_fwd_args* probs, int32_t n_probs, int64_t m, int32_t k, int32_t n,
                              int32_t relu, float drop_rate, uint64_t seed, uint64_t counter_offset,

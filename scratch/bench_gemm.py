@@ -1,16 +1,63 @@
-import sys, time, torch
-sys.path.insert(0, "/root/repo")
-from two_tower_amazon_recommender_amd import ops
+"""Tower GEMM launches exactly as the cfg3 train step issues them (both towers per launch): fwd L0, fwd L1, bwd L1
+(dx + dw/db), bwd L0 — hipEvent time over back-to-back launches, per launch and summed, with the f32-MFMA fraction."""
+import json
+import sys
+
+import torch
+
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+from two_tower_amazon_recommender_amd import ops  # noqa: E402
+from two_tower_amazon_recommender_amd.trainer import TwoTowerConfig, TwoTowerTrainer, towers_forward, towers_backward  # noqa: E402
+
 dev = torch.device("cuda:0")
-def t(fn, n=200):
-    for _ in range(10): fn()
-    torch.cuda.synchronize(); s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+
+
+def t(fn, n=100):
+    for _ in range(10):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
-    for _ in range(n): fn()
-    e.record(); torch.cuda.synchronize()
+    for _ in range(n):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
     return s.elapsed_time(e) / n * 1e3
-for (m, k, n) in [(8192, 128, 256), (8192, 256, 128)]:
-    x = torch.randn(m, k, device=dev); w = torch.randn(k, n, device=dev); b = torch.randn(n, device=dev)
-    y = torch.empty(m, n, device=dev); dz = torch.randn(m, n, device=dev); dx = torch.empty(m, k, device=dev)
-    ns = ops.dense_bwd_num_slabs(m); dw = torch.empty(ns, k, n, device=dev); db = torch.empty(ns, n, device=dev)
-    print(f"m{m} k{k} n{n}: fwd {t(lambda: ops.dense_fwd(x, w, b, True, out=y)):.1f} us  bwd(dx+dw) {t(lambda: ops.dense_bwd(x, w, dz, dx, x, dw, db)):.1f} us  torch.mm {t(lambda: torch.mm(x, w, out=y)):.1f} us")
+
+
+def main():
+    b, d, dims = 8192, 128, [256, 128]
+    cfg = TwoTowerConfig(n_users=100_000, n_items=100_000, embedding_dim=d, tower_dims=dims, batch_size=b)
+    tr = TwoTowerTrainer(cfg, dev, seed=3)
+    u, i = tr.synthetic_batch(3, 0)
+    tr.step(u, i)
+    ut, it = tr.user_tower, tr.item_tower
+    for tw in (ut, it):
+        for z in tw.dz:
+            z.normal_()
+    none2 = (None, None)
+    res = {}
+    for l in range(2):
+        hidden = l < 1
+        res[f"fwd_L{l}"] = t(lambda: ops.dense_fwd2((ut.acts[l], it.acts[l]), (ut.w[l], it.w[l]), (ut.b[l], it.b[l]),
+                                                    (ut.acts[l + 1], it.acts[l + 1]), relu=hidden))
+    for l in (1, 0):
+        dxs = (ut.dz[l - 1], it.dz[l - 1]) if l > 0 else (ut.demb, it.demb)
+        masks = (ut.acts[l], it.acts[l]) if l > 0 else none2
+        res[f"bwd_L{l}"] = t(lambda: ops.dense_bwd2((ut.acts[l], it.acts[l]), (ut.w[l], it.w[l]), (ut.dz[l], it.dz[l]), dxs, masks,
+                                                    (ut.dw_slabs[l], it.dw_slabs[l]), (ut.db_slabs[l], it.db_slabs[l])))
+        res[f"bwd_L{l}_dx_only"] = t(lambda: ops.dense_bwd2((ut.acts[l], it.acts[l]), (ut.w[l], it.w[l]), (ut.dz[l], it.dz[l]), dxs,
+                                                            masks, none2, none2))
+        res[f"bwd_L{l}_dw_only"] = t(lambda: ops.dense_bwd2((ut.acts[l], it.acts[l]), (ut.w[l], it.w[l]), (ut.dz[l], it.dz[l]), none2,
+                                                            none2, (ut.dw_slabs[l], it.dw_slabs[l]), (ut.db_slabs[l], it.db_slabs[l])))
+    res["towers_fwd_all"] = t(lambda: towers_forward(ut, it))
+    res["towers_bwd_all"] = t(lambda: towers_backward(ut, it))
+    step_sum = res["fwd_L0"] + res["fwd_L1"] + res["bwd_L1"] + res["bwd_L0"]
+    flops = 12 * 2.0 * b * 128 * 256
+    res["sum_4_launches_us"] = step_sum
+    res["frac_f32_mfma_peak"] = flops / (step_sum * 1e-6) / 157.3e12
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -365,6 +365,53 @@ def test_dense_bwd_dx_only_then_dw_only_equals_one_call(dev):
         ops.dense_bwd(x, w, dz, None, None, None, None)
 
 
+@pytest.mark.parametrize("m,k,n,with_cat", [(8192, 128, 256, False), (4096, 64, 64, True), (1000, 256, 512, True), (77, 36, 20, False)])
+def test_lookup_fused_into_the_first_layer_is_bit_identical_to_gather_then_dense(dev, m, k, n, with_cat):
+    """K1 inside the GEMM loaders (tt_dense_lookup): forward y = act(table[ids] (+ cat[ids2]) @ w + b) and backward
+    dW = x^T dz read the table rows themselves.  Same tiles, same k order => bit-identical to the two-launch form,
+    including zero rows for padding (-1) and out-of-range ids (flagged) and ragged tile edges."""
+    rows, rows2 = 50_000, 30
+    table = T(synth.embedding_table(61, 1, rows, k), dev)
+    cat = T(synth.embedding_table(61, 5, rows2, k), dev)
+    ids = synth.batch_ids(61, 3, 0, m, rows, "Z")
+    ids2 = synth.batch_ids(61, 6, 0, m, rows2, "Z")
+    ids[3] = -1                                   # padding: zero row, silent
+    if m > 100:
+        ids[100] = rows + 7                       # out of range: zero row, flagged
+        ids2[5] = rows2                           # out of range category: adds nothing, flagged
+    d_ids, d_ids2 = T(ids, dev), T(ids2, dev)
+    w = T(synth.uniform_f32(61, 20, k * n, -0.2, 0.4).reshape(k, n), dev)
+    b = T(synth.uniform_f32(61, 21, n, -0.1, 0.2), dev)
+    dz = T(synth.uniform_f32(61, 22, m * n, -1.0, 2.0).reshape(m, n), dev)
+    # two launches: gather (+ gather_add), then the plain layer
+    flag_a = torch.zeros(1, dtype=torch.int32, device=dev)
+    x = ops.embedding_gather(table, d_ids, oob_flag=flag_a)
+    if with_cat:
+        ops.embedding_gather_add_(x, cat, d_ids2, flag_a)
+    y_ref = ops.dense_fwd(x, w, b, relu=True)
+    ns = ops.dense_bwd_num_slabs(m)
+    dw_ref, db_ref = torch.empty(ns, k, n, device=dev), torch.empty(ns, n, device=dev)
+    dx_ref = torch.empty(m, k, device=dev)
+    ops.dense_bwd(x, w, dz, dx_ref, None, dw_ref, db_ref)
+    # fused
+    flag_b = torch.zeros(1, dtype=torch.int32, device=dev)
+    lk = ops.make_lookup(table, d_ids, cat if with_cat else None, d_ids2 if with_cat else None, flag_b)
+    y = ops.dense_fwd(None, w, b, relu=True, lookup=lk)
+    dw, db, dx = torch.full_like(dw_ref, 7.0), torch.full_like(db_ref, 7.0), torch.empty(m, k, device=dev)
+    ops.dense_bwd(None, w, dz, dx, None, dw, db, lookup=lk)
+    assert torch.equal(y, y_ref) and torch.equal(dw, dw_ref) and torch.equal(db, db_ref) and torch.equal(dx, dx_ref)
+    assert flag_a.item() == flag_b.item() == (1 if m > 100 else 0)
+    # dw only / dx only with the lookup, and both towers in one launch
+    dw2, db2 = torch.empty_like(dw), torch.empty_like(db)
+    ops.dense_bwd(None, w, dz, None, None, dw2, db2, lookup=lk)
+    assert torch.equal(dw2, dw_ref) and torch.equal(db2, db_ref)
+    y2 = (torch.empty_like(y), torch.empty_like(y))
+    lk2 = ops.make_lookup(table, d_ids)
+    ops.dense_fwd2((None, None), (w, w), (b, b), y2, relu=True, lookups=(lk, lk2))
+    assert torch.equal(y2[0], y_ref)
+    assert torch.equal(y2[1], ops.dense_fwd(ops.embedding_gather(table, d_ids), w, b, relu=True))
+
+
 @pytest.mark.parametrize("opt", ["sgd", "adagrad"])
 def test_dense_update_segments(dev, opt):
     rng = np.random.default_rng(5)

@@ -22,15 +22,22 @@ TT_IDS_UNIFORM, TT_IDS_POWERLAW = 0, 1
 TT_MAX_DENSE_SEGS = 16
 
 
+class DenseLookup(C.Structure):
+    """Mirror of ``tt_dense_lookup``: the embedding lookup fused into a tower's first Dense layer."""
+    _fields_ = [("table", C.c_void_p), ("ids", C.c_void_p), ("table_rows", C.c_int64),
+                ("table2", C.c_void_p), ("ids2", C.c_void_p), ("table2_rows", C.c_int64), ("oob_flag", C.c_void_p)]
+
+
 class DenseFwdArgs(C.Structure):
     """Mirror of ``tt_dense_fwd_args``."""
-    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("b", C.c_void_p), ("y", C.c_void_p), ("dropout_tensor_id", C.c_uint64)]
+    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("b", C.c_void_p), ("y", C.c_void_p), ("dropout_tensor_id", C.c_uint64),
+                ("lookup", DenseLookup)]
 
 
 class DenseBwdArgs(C.Structure):
     """Mirror of ``tt_dense_bwd_args``."""
     _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("dz", C.c_void_p), ("dx", C.c_void_p), ("dx_relu_src", C.c_void_p),
-                ("dw_slabs", C.c_void_p), ("db_slabs", C.c_void_p)]
+                ("dw_slabs", C.c_void_p), ("db_slabs", C.c_void_p), ("lookup", DenseLookup)]
 
 
 class RouteTable(C.Structure):

@@ -13,6 +13,7 @@
 // per k-tile).  MFMA k order inside a step is permuted
 // (k = 8g + 4*lanehalf + s) so a k-contiguous operand is read with one ds_read_b128 per 4 MFMAs
 // from rows padded to BK+4 floats (conflict-free); an m-contiguous operand is read with ds_read_b32.
+// The embedding lookup of a tower's first layer is fused into the A loader (fwd and dW): see GemmArgs::a_ids.
 #include "common.h"
 
 namespace {
@@ -22,10 +23,12 @@ using tt::f32x16;
 
 constexpr int BM = 64, BN = 64, BK = 32;
 constexpr int PF = 4;                    // k-tiles of global loads kept in flight per thread (register ring)
-constexpr int NST = BM * BK / 4 / 256;   // staged float4 per thread and operand
-constexpr int LS_KC = BK + 4;    // [row][k] stride
-constexpr int LS_MC = BM + 4;    // [k][row] stride
+constexpr int NST = BM * BK / 4 / 256;   // staged float4 per thread and operand (= 2)
+constexpr int LS_KC = BK + 4;            // [row][k] stride
+constexpr int LS_MC = BM + 4;            // [k][row] stride
 constexpr int TILE_F = (BM * LS_KC > BK * LS_MC) ? BM * LS_KC : BK * LS_MC;   // floats per operand tile
+constexpr int kMaxGatherK = 1024;        // fused-gather dW tiles: ids of one split's batch rows staged in LDS (2 KB up to 256 rows
+                                         // per split = batch <= 8192: 4 workgroups per CU still fit; 8 KB up to 1024)
 
 struct GemmArgs {
   const float* A;
@@ -46,9 +49,25 @@ struct GemmArgs {
   int64_t k_per_split;     // multiple of BK
   int64_t slab_stride;     // C offset per blockIdx.z
   float* db_slabs;         // TN only: [splits][N] column sums of B
+  // K1 fused into the loader (north_star: "LDS-staged embedding rows"): logical A row r is row a_ids[r] of the TABLE
+  // A points to (+ row a_ids2[r] of table A2, the hashed-category feature) — the [batch, dim] tower input is never
+  // written to or re-read from HBM.  Ids outside [0, a_rows) give a zero row (-1 = padding: silent; else *oob_flag = 1).
+  const int64_t* a_ids;
+  int64_t a_rows;
+  const float* A2;
+  const int64_t* a_ids2;
+  int64_t a_rows2;
+  int32_t* oob_flag;
 };
 
-// stage one operand tile into registers.  KC: rows x 32 k, float4 along k.  MC: 32 k x rows, float4 along rows.
+__device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// ---- operand staging: global -> registers (ring) -> LDS ----
+//   KC  operand is k-contiguous   [row][k]: thread f = tid + 256 j moves float4 (row = f / 8, k = 4 (f % 8)); LDS [row][k]
+//   MC  operand is row-contiguous [k][row]: thread f moves float4 (k = f / 16, rows 4 (f % 16) ..);           LDS [k][row]
+// (A transposing store that gives MC operands the [row][k] layout too — ds_read_b128 fragments everywhere — was built
+// and measured in r02: 118 vs 114 us for the four tower launches.  The kernel is not LDS-read-bound; the 16-row global
+// load pattern the transpose needs costs more than the wider reads save.)
 template <bool KC>
 __device__ __forceinline__ void load_operand(f32x4 (&st)[NST], const float* __restrict__ base, int64_t ld, int64_t row0,
                                              int64_t nrows, int64_t k0, int64_t kend, int tid) {
@@ -58,12 +77,51 @@ __device__ __forceinline__ void load_operand(f32x4 (&st)[NST], const float* __re
     if constexpr (KC) {
       const int row = f / (BK / 4), k4 = f % (BK / 4);
       const int64_t r = row0 + row, k = k0 + 4 * k4;
-      st[j] = (r < nrows && k < kend) ? *reinterpret_cast<const f32x4*>(base + r * ld + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+      st[j] = (r < nrows && k < kend) ? ldg4(base + r * ld + k) : f32x4{0.f, 0.f, 0.f, 0.f};
     } else {
       const int kk = f >> 4, m4 = f & 15;
       const int64_t k = k0 + kk, r = row0 + 4 * m4;
-      st[j] = (k < kend && r < nrows) ? *reinterpret_cast<const f32x4*>(base + k * ld + r) : f32x4{0.f, 0.f, 0.f, 0.f};
+      st[j] = (k < kend && r < nrows) ? ldg4(base + k * ld + r) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+  }
+}
+
+// KC gather (forward layer 0): the thread's two tile rows are table rows; off[j] = element offset of the row or -1
+__device__ __forceinline__ void load_rows_kc(f32x4 (&st)[NST], const float* __restrict__ t1, const int64_t (&off1)[NST],
+                                             const float* __restrict__ t2, const int64_t (&off2)[NST], int64_t k0, int64_t kend,
+                                             int tid) {
+#pragma unroll
+  for (int j = 0; j < NST; ++j) {
+    const int64_t k = k0 + 4 * ((tid + 256 * j) % (BK / 4));
+    f32x4 v = (off1[j] >= 0 && k < kend) ? ldg4(t1 + off1[j] + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (t2 != nullptr) {
+      const f32x4 c = (off2[j] >= 0 && k < kend) ? ldg4(t2 + off2[j] + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+      v = v + c;                                            // one f32 add per element (the oracle's row + category row)
+    }
+    st[j] = v;
+  }
+}
+
+// MC gather (dW of layer 0: A = x^T, x[b][:] = table row ids[b]): the tile's k rows are batch rows; their table rows
+// come from the ids staged in LDS (ids1 / ids2: int32 row index, -1 = none)
+__device__ __forceinline__ void load_rows_mc(f32x4 (&st)[NST], const float* __restrict__ t1, const int32_t* ids1,
+                                             const float* __restrict__ t2, const int32_t* ids2, int64_t ld, int64_t row0,
+                                             int64_t nrows, int kloc0 /* k0 - kbeg */, int klen, int tid) {
+#pragma unroll
+  for (int j = 0; j < NST; ++j) {
+    const int f = tid + 256 * j;
+    const int kl = kloc0 + (f >> 4);
+    const int64_t r = row0 + 4 * (f & 15);
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (kl < klen && r < nrows) {
+      const int i1 = ids1[kl];
+      if (i1 >= 0) v = ldg4(t1 + (int64_t)i1 * ld + r);
+      if (t2 != nullptr) {
+        const int i2 = ids2[kl];
+        if (i2 >= 0) v = v + ldg4(t2 + (int64_t)i2 * ld + r);
+      }
+    }
+    st[j] = v;
   }
 }
 
@@ -93,6 +151,16 @@ __device__ __forceinline__ f32x4 read_operand(const float* T, int row, int g, in
   }
 }
 
+// table row of logical row r for the fused gather: element offset id * ld, or -1 (zero row); flags ids out of range
+__device__ __forceinline__ int64_t gather_row(const int64_t* __restrict__ ids, int64_t r, int64_t n, int64_t rows, int64_t ld,
+                                              int32_t* oob_flag, bool flag_it) {
+  if (r >= n) return -1;
+  const int64_t id = ids[r];
+  if (id >= 0 && id < rows) return id * ld;
+  if (flag_it && oob_flag != nullptr && id != -1) atomicOr(oob_flag, 1);
+  return -1;
+}
+
 // up to two independent problems of identical shape per launch (the user and the item tower's layer l):
 // blockIdx.z = problem * splits + split
 struct GemmBatch {
@@ -100,9 +168,19 @@ struct GemmBatch {
   int splits;
 };
 
-// one 64x64 output tile (bx, by) of problem p, k-range of split zsplit
-template <bool A_KC, bool B_KC, bool COLSUM>
-__device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int zsplit, const int bx, const int by, float* smem) {
+// one 64x64 output tile (bx, by) of problem p, k-range of split zsplit.  GATHER: A is an embedding table read through
+// p.a_ids (KC: the forward GEMM of layer 0; MC: its dW GEMM, ids staged in `gids`).
+//
+// r02 experiments on this structure, both measured on the four cfg3 tower launches and dropped:
+//  * every operand staged [row][k] (transposing ds_write_b64 for the row-contiguous ones, all fragments ds_read_b128):
+//    118 vs 114 us — the kernel is not LDS-read-bound, and the 16-rows-per-instruction global load pattern costs more;
+//  * a persistent workgroup walking several tiles as one flat k-tile sequence (register ring across tile boundaries,
+//    epilogue stores under the next tile's MFMAs), 1-4 workgroups per CU: 125-196 us vs 114 — the cursor state costs
+//    ~50 VGPRs (149-176 -> 3 waves/SIMD instead of 4) and these 4-8 k-tile GEMMs want occupancy (memory-level
+//    parallelism across many small workgroups) more than an in-workgroup pipeline.
+template <bool A_KC, bool B_KC, bool COLSUM, int GK>
+__device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int zsplit, const int bx, const int by, float* smem,
+                                          int32_t* gids) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, ln = lane & 31;
@@ -113,6 +191,37 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int zsplit, c
   int64_t kend = kbeg + p.k_per_split;
   if (kend > p.K) kend = p.K;
   const int nk = kend > kbeg ? (int)((kend - kbeg + BK - 1) / BK) : 0;
+  constexpr bool GATHER = GK != 0;    // GK: capacity of the LDS id stage (MC form); any non-zero value selects the KC form
+
+  // ---- fused gather: resolve the table rows once per tile ----
+  int64_t off1[NST] = {}, off2[NST] = {};
+  const int klen = (int)(kend - kbeg);
+  if constexpr (GATHER && A_KC) {
+#pragma unroll
+    for (int j = 0; j < NST; ++j) {
+      const int64_t r = m0 + (tid + 256 * j) / (BK / 4);
+      const bool first = by == 0 && ((tid + 256 * j) % (BK / 4)) == 0;     // one flagging thread per row
+      off1[j] = gather_row(p.a_ids, r, p.M, p.a_rows, p.lda, p.oob_flag, first);
+      off2[j] = p.A2 != nullptr ? gather_row(p.a_ids2, r, p.M, p.a_rows2, p.lda, p.oob_flag, first) : -1;
+    }
+  }
+  if constexpr (GATHER && !A_KC) {
+    for (int i = tid; i < klen; i += 256) {
+      const int64_t i1 = p.a_ids[kbeg + i];
+      gids[i] = (i1 >= 0 && i1 < p.a_rows) ? (int32_t)i1 : -1;
+      if (p.A2 != nullptr) {
+        const int64_t i2 = p.a_ids2[kbeg + i];
+        gids[GK + i] = (i2 >= 0 && i2 < p.a_rows2) ? (int32_t)i2 : -1;
+      }
+    }
+    __syncthreads();
+  }
+  auto load_a = [&](f32x4 (&st)[NST], int t) {
+    const int64_t k0 = kbeg + (int64_t)t * BK;
+    if constexpr (GATHER && A_KC) load_rows_kc(st, p.A, off1, p.A2, off2, k0, kend, tid);
+    else if constexpr (GATHER) load_rows_mc(st, p.A, gids, p.A2, gids + GK, p.lda, m0, p.M, t * BK, klen, tid);
+    else load_operand<A_KC>(st, p.A, p.lda, m0, p.M, k0, kend, tid);
+  };
 
   // Register ring: the loads of PF k-tiles are in flight at any time (a dependent round trip through L2/HBM costs
   // ~1 us under load, one k-tile is only 16 MFMAs per wave), so the wait at step t is for a load issued PF steps ago.
@@ -125,7 +234,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int zsplit, c
 #pragma unroll
   for (int u = 0; u < PF; ++u) {
     if (u < nk) {
-      load_operand<A_KC>(sa[u], p.A, p.lda, m0, p.M, kbeg + (int64_t)u * BK, kend, tid);
+      load_a(sa[u], u);
       load_operand<B_KC>(sb[u], p.B, p.ldb, n0, p.N, kbeg + (int64_t)u * BK, kend, tid);
     }
   }
@@ -140,7 +249,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int zsplit, c
         store_operand<A_KC>(sa[u], TA, tid);          // waits only for ring slot u
         store_operand<B_KC>(sb[u], TB, tid);
         if (t + PF < nk) {
-          load_operand<A_KC>(sa[u], p.A, p.lda, m0, p.M, kbeg + (int64_t)(t + PF) * BK, kend, tid);
+          load_a(sa[u], t + PF);
           load_operand<B_KC>(sb[u], p.B, p.ldb, n0, p.N, kbeg + (int64_t)(t + PF) * BK, kend, tid);
         }
         __syncthreads();                              // tile t visible; everyone is done with the other buffer
@@ -186,10 +295,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int zsplit, c
   }
 }
 
-template <bool A_KC, bool B_KC, bool COLSUM>
+constexpr int kGidsInts(int gk, bool mc) { return (gk != 0 && mc) ? 2 * gk : 1; }
+
+template <bool A_KC, bool B_KC, bool COLSUM, int GK>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmBatch pb) {
   __shared__ __attribute__((aligned(16))) float smem[2 * 2 * TILE_F];
-  gemm_tile<A_KC, B_KC, COLSUM>(pb.a[blockIdx.z / pb.splits], blockIdx.z % pb.splits, blockIdx.x, blockIdx.y, smem);
+  __shared__ int32_t gids[kGidsInts(GK, !A_KC)];
+  gemm_tile<A_KC, B_KC, COLSUM, GK>(pb.a[blockIdx.z / pb.splits], blockIdx.z % pb.splits, blockIdx.x, blockIdx.y, smem, gids);
 }
 
 // dx AND dw+db of one layer (of both towers) in ONE launch: the two kinds of tiles are independent given dz, so
@@ -203,8 +315,10 @@ struct BwdBatch {
   int dw_first;          // 1: the dw tiles take the first workgroup indices (when their k-range is the longer one)
 };
 
+template <int GK>
 __global__ __launch_bounds__(256) void gemm_bwd_kernel(BwdBatch pb) {
   __shared__ __attribute__((aligned(16))) float smem[2 * 2 * TILE_F];
+  __shared__ int32_t gids[kGidsInts(GK, true)];
   const int per_split = pb.dw_gm * pb.dw_gn;
   const int per_w = per_split * pb.splits;
   const int per_x = pb.dx_gm * pb.dx_gn;
@@ -218,16 +332,16 @@ __global__ __launch_bounds__(256) void gemm_bwd_kernel(BwdBatch pb) {
     b -= prob * per_w;
     const int split = b / per_split;
     b -= split * per_split;
-    gemm_tile<false, false, true>(pb.aw[prob], split, b % pb.dw_gm, b / pb.dw_gm, smem);
+    gemm_tile<false, false, true, GK>(pb.aw[prob], split, b % pb.dw_gm, b / pb.dw_gm, smem, gids);
   } else {
     if (pb.dw_first) b -= n_dw;
     const int prob = b / per_x;
     b -= prob * per_x;
-    gemm_tile<true, true, false>(pb.ax[prob], 0, b % pb.dx_gm, b / pb.dx_gm, smem);
+    gemm_tile<true, true, false, 0>(pb.ax[prob], 0, b % pb.dx_gm, b / pb.dx_gm, smem, gids);
   }
 }
 
-template <bool A_KC, bool B_KC, bool COLSUM>
+template <bool A_KC, bool B_KC, bool COLSUM, int GK = 0>
 int launch(const GemmArgs* probs, int nprob, int splits, hipStream_t stream, const char* what, const char* tag) {
   const GemmArgs& a0 = probs[0];
   const int64_t gm = (a0.M + BM - 1) / BM, gn = (a0.N + BN - 1) / BN;
@@ -237,12 +351,29 @@ int launch(const GemmArgs* probs, int nprob, int splits, hipStream_t stream, con
   for (int i = 0; i < nprob; ++i) pb.a[i] = probs[i];
   pb.splits = splits;
   tt::ProfScope prof(tag, stream);
-  hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, COLSUM>), dim3((unsigned)gm, (unsigned)gn, (unsigned)(splits * nprob)), dim3(256), 0,
+  hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, COLSUM, GK>), dim3((unsigned)gm, (unsigned)gn, (unsigned)(splits * nprob)), dim3(256), 0,
                      stream, pb);
   return tt::check_launch(what);
 }
 
 }  // namespace
+
+// the fused embedding lookup of a layer-0 problem: A becomes the table, rows come through the ids
+static int set_lookup(GemmArgs& g, const tt_dense_lookup& lk, const float* x, int64_t m, const char* fn) {
+  if (lk.ids == nullptr) {
+    TT_REQUIRE(x != nullptr, "%s: null input x (and no lookup)", fn);
+    return TT_OK;
+  }
+  TT_REQUIRE(lk.table != nullptr && lk.table_rows > 0 && lk.table_rows <= 0x7fffffff, "%s: lookup needs a table of 1..2^31-1 rows", fn);
+  TT_REQUIRE(tt::aligned16(lk.table) && tt::aligned16(lk.table2), "%s: lookup tables must be 16-byte aligned", fn);
+  TT_REQUIRE((lk.table2 == nullptr) == (lk.ids2 == nullptr), "%s: lookup.table2 and lookup.ids2 go together", fn);
+  TT_REQUIRE(lk.table2 == nullptr || (lk.table2_rows > 0 && lk.table2_rows <= 0x7fffffff), "%s: bad lookup.table2_rows", fn);
+  TT_REQUIRE(m <= 32 * (int64_t)kMaxGatherK, "%s: the fused lookup supports m <= %d", fn, 32 * kMaxGatherK);
+  g.A = lk.table; g.a_ids = lk.ids; g.a_rows = lk.table_rows;
+  g.A2 = lk.table2; g.a_ids2 = lk.ids2; g.a_rows2 = lk.table2_rows;
+  g.oob_flag = lk.oob_flag;
+  return TT_OK;
+}
 
 static uint64_t dropout_stream_key(uint64_t seed, uint64_t tensor_id) {
   return tt::splitmix_host(tt::splitmix_host(seed) ^ (tensor_id * 0xD6E8FEB86659FD93ull));
@@ -266,12 +397,16 @@ extern "C" int tt_dense_fwd_batched_f32(const tt_dense_fwd_args* probs, int32_t 
   TT_REQUIRE(m > 0 && k > 0 && n > 0 && k % 4 == 0 && n % 4 == 0, "tt_dense_fwd_f32: need m>0, k%%4==0, n%%4==0 (m=%lld k=%d n=%d)",
              (long long)m, k, n);
   GemmArgs a[2] = {};
+  const bool gather = probs[0].lookup.ids != nullptr;
   for (int i = 0; i < n_probs; ++i) {
     const tt_dense_fwd_args& q = probs[i];
-    TT_REQUIRE(q.x && q.w && q.y, "tt_dense_fwd_f32: null pointer");
+    TT_REQUIRE((q.lookup.ids != nullptr) == gather, "tt_dense_fwd_batched_f32: the lookup must be given for all problems or for none");
+    TT_REQUIRE(q.w && q.y, "tt_dense_fwd_f32: null pointer");
     TT_REQUIRE(tt::aligned16(q.x) && tt::aligned16(q.w) && tt::aligned16(q.y), "tt_dense_fwd_f32: pointers must be 16-byte aligned");
     a[i].A = q.x; a[i].B = q.w; a[i].C = q.y; a[i].M = m; a[i].N = n; a[i].K = k; a[i].lda = k; a[i].ldb = n; a[i].ldc = n;
     a[i].bias = q.b; a[i].relu = relu; a[i].mask_scale = 1.f; a[i].k_per_split = (k + BK - 1) / BK * BK;
+    int rc = set_lookup(a[i], q.lookup, q.x, m, "tt_dense_fwd_f32");
+    if (rc != TT_OK) return rc;
     if (drop_rate > 0.f) {
       a[i].drop_p24 = (uint32_t)((double)drop_rate * 16777216.0 + 0.5);
       a[i].drop_scale = 1.0f / (1.0f - drop_rate);
@@ -279,19 +414,20 @@ extern "C" int tt_dense_fwd_batched_f32(const tt_dense_fwd_args* probs, int32_t 
       a[i].drop_offset = counter_offset;
     }
   }
+  if (gather) return launch<true, false, false, 1>(a, n_probs, 1, tt::as_stream(stream), "tt_dense_fwd_f32(lookup)", "dense_fwd");
   return launch<true, false, false>(a, n_probs, 1, tt::as_stream(stream), "tt_dense_fwd_f32", "dense_fwd");
 }
 
 extern "C" int tt_dense_fwd_f32(const float* x, const float* w, const float* b, float* y, int64_t m, int32_t k,
                                 int32_t n, int32_t relu, tt_stream_t stream) {
-  const tt_dense_fwd_args q{x, w, b, y, 0};
+  const tt_dense_fwd_args q{x, w, b, y, 0, {}};
   return tt_dense_fwd_batched_f32(&q, 1, m, k, n, relu, 0.f, 0, 0, stream);
 }
 
 extern "C" int tt_dense_fwd_dropout_f32(const float* x, const float* w, const float* b, float* y, int64_t m, int32_t k,
                                         int32_t n, int32_t relu, float drop_rate, uint64_t seed, uint64_t tensor_id,
                                         uint64_t counter_offset, tt_stream_t stream) {
-  const tt_dense_fwd_args q{x, w, b, y, tensor_id};
+  const tt_dense_fwd_args q{x, w, b, y, tensor_id, {}};
   return tt_dense_fwd_batched_f32(&q, 1, m, k, n, relu, drop_rate, seed, counter_offset, stream);
 }
 
@@ -312,9 +448,11 @@ extern "C" int tt_dense_bwd_batched_f32(const tt_dense_bwd_args* probs, int32_t 
   const int splits = tt_dense_bwd_num_slabs(m);
   const bool want_dx = probs[0].dx != nullptr;
   const bool want_dw = probs[0].dw_slabs != nullptr;
+  const bool gather = probs[0].lookup.ids != nullptr;
   for (int i = 0; i < n_probs; ++i) {
     const tt_dense_bwd_args& q = probs[i];
-    TT_REQUIRE(q.x && q.w && q.dz, "tt_dense_bwd_f32: null pointer");
+    TT_REQUIRE((q.lookup.ids != nullptr) == gather, "tt_dense_bwd_batched_f32: the lookup must be given for all problems or for none");
+    TT_REQUIRE(q.w && q.dz, "tt_dense_bwd_f32: null pointer");
     TT_REQUIRE((q.dx != nullptr) == want_dx, "tt_dense_bwd_batched_f32: dx must be given for all problems or for none");
     TT_REQUIRE((q.dw_slabs != nullptr) == want_dw && (q.db_slabs != nullptr) == want_dw,
                "tt_dense_bwd_batched_f32: dw_slabs and db_slabs must be given together, for all problems or for none");
@@ -331,6 +469,10 @@ extern "C" int tt_dense_bwd_batched_f32(const tt_dense_bwd_args* probs, int32_t 
     aw[i].slab_stride = (int64_t)k * n;
     aw[i].db_slabs = q.db_slabs;
     aw[i].mask_scale = 1.f;
+    int rcl = set_lookup(aw[i], q.lookup, q.x, m, "tt_dense_bwd_f32");
+    if (rcl != TT_OK) return rcl;
+    aw[i].oob_flag = nullptr;            // the forward pass has flagged bad ids already
+    TT_REQUIRE(!gather || aw[i].k_per_split <= kMaxGatherK, "tt_dense_bwd_f32: fused lookup: batch split too long");
   }
   int rc;
   if (want_dx && want_dw) {
@@ -343,11 +485,16 @@ extern "C" int tt_dense_bwd_batched_f32(const tt_dense_bwd_args* probs, int32_t 
     const int64_t blocks = (int64_t)n_probs * ((int64_t)pb.dx_gm * pb.dx_gn + (int64_t)pb.dw_gm * pb.dw_gn * splits);
     TT_REQUIRE(blocks <= 0x7fffffff && (ax[0].M + BM - 1) / BM <= 0x3fffffff, "tt_dense_bwd_f32: grid too large");
     tt::ProfScope prof("dense_bwd", stream);
-    hipLaunchKernelGGL(gemm_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, pb);
+    if (gather && aw[0].k_per_split <= 256) hipLaunchKernelGGL(gemm_bwd_kernel<256>, dim3((unsigned)blocks), dim3(256), 0, stream, pb);
+    else if (gather) hipLaunchKernelGGL(gemm_bwd_kernel<kMaxGatherK>, dim3((unsigned)blocks), dim3(256), 0, stream, pb);
+    else hipLaunchKernelGGL(gemm_bwd_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, stream, pb);
     return tt::check_launch("tt_dense_bwd_f32(dx+dw)");
   }
   if (want_dx && (rc = launch<true, true, false>(ax, n_probs, 1, stream, "tt_dense_bwd_f32(dx)", "dense_bwd_dx")) != TT_OK) return rc;
   if (!want_dw) return TT_OK;
+  if (gather && aw[0].k_per_split <= 256)
+    return launch<false, false, true, 256>(aw, n_probs, splits, stream, "tt_dense_bwd_f32(dw, lookup)", "dense_bwd_dw");
+  if (gather) return launch<false, false, true, kMaxGatherK>(aw, n_probs, splits, stream, "tt_dense_bwd_f32(dw, lookup)", "dense_bwd_dw");
   return launch<false, false, true>(aw, n_probs, splits, stream, "tt_dense_bwd_f32(dw)", "dense_bwd_dw");
 }
 
@@ -359,6 +506,6 @@ extern "C" int tt_dense_bwd_f32(const float* x, const float* w, const float* dz,
 extern "C" int tt_dense_bwd_scaled_f32(const float* x, const float* w, const float* dz, float* dx, const float* dx_relu_src,
                                        float dx_scale, float* dw_slabs, float* db_slabs, int64_t m, int32_t k, int32_t n,
                                        tt_stream_t stream_) {
-  const tt_dense_bwd_args q{x, w, dz, dx, dx_relu_src, dw_slabs, db_slabs};
+  const tt_dense_bwd_args q{x, w, dz, dx, dx_relu_src, dw_slabs, db_slabs, {}};
   return tt_dense_bwd_batched_f32(&q, 1, dx_scale, m, k, n, stream_);
 }

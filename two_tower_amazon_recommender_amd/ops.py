@@ -281,26 +281,63 @@ def sparse_update2_(opt: str, table_a, accum_a, grads_a, plan_a: SparsePlan,
 
 
 # ----------------------------------------------------------------------------- a2 dense layers
-def dense_fwd(x, w, b, relu: bool, out=None, dropout=None):
-    """y = act(x@w+b); ``dropout`` = (rate, seed, tensor_id, counter_offset) applies inverted dropout to y."""
+MAX_FUSED_LOOKUP_ROWS = 32768       # tt_dense_lookup: the ids of one dW split are staged in LDS
+
+
+def make_lookup(table, ids, table2=None, ids2=None, oob_flag=None) -> "_lib.DenseLookup":
+    """The embedding lookup fused into a tower's FIRST Dense layer (``tt_dense_lookup``): the layer's input row r is
+    ``table[ids[r]]`` (+ ``table2[ids2[r]]``), read straight into the GEMM tiles — never written to HBM."""
+    _chk(table, torch.float32, "lookup table", 2)
+    _chk(ids, torch.int64, "lookup ids", 1)
+    if (table2 is None) != (ids2 is None):
+        raise RuntimeError("make_lookup: table2 and ids2 go together")
+    if table2 is not None:
+        _chk(table2, torch.float32, "lookup table2", 2)
+        _chk(ids2, torch.int64, "lookup ids2", 1)
+        if table2.shape[1] != table.shape[1] or ids2.numel() != ids.numel():
+            raise RuntimeError("make_lookup: table2 / ids2 must match table's width and the number of ids")
+    if oob_flag is not None:
+        _chk(oob_flag, torch.int32, "oob_flag")
+    if ids.numel() > MAX_FUSED_LOOKUP_ROWS:
+        raise RuntimeError(f"make_lookup: at most {MAX_FUSED_LOOKUP_ROWS} rows per fused lookup")
+    lk = _lib.DenseLookup(_p(table), _p(ids), table.shape[0], _p(table2), _p(ids2), 0 if table2 is None else table2.shape[0],
+                          _p(oob_flag))
+    lk._keep = (table, ids, table2, ids2, oob_flag)      # the struct holds raw pointers: keep the tensors alive with it
+    lk._mk = (ids.numel(), table.shape[1])
+    return lk
+
+
+def _no_lookup():
+    return _lib.DenseLookup()
+
+
+def _in_shape(x, lookup):
+    if lookup is not None:
+        return lookup._mk
     _chk(x, torch.float32, "x", 2)
+    return x.shape[0], x.shape[1]
+
+
+def dense_fwd(x, w, b, relu: bool, out=None, dropout=None, lookup=None):
+    """y = act(x@w+b); ``dropout`` = (rate, seed, tensor_id, counter_offset) applies inverted dropout to y.
+    With ``lookup`` (make_lookup) x is ignored: the input rows come from the embedding table."""
     _chk(w, torch.float32, "w", 2)
     if b is not None:
         _chk(b, torch.float32, "b", 1)
-    m, k = x.shape
+    m, k = _in_shape(x, lookup)
     n = w.shape[1]
     if w.shape[0] != k:
-        raise RuntimeError(f"dense_fwd: x is [{m},{k}] but w is {tuple(w.shape)}")
+        raise RuntimeError(f"dense_fwd: input is [{m},{k}] but w is {tuple(w.shape)}")
     if out is None:
-        out = torch.empty((m, n), dtype=torch.float32, device=x.device)
+        out = torch.empty((m, n), dtype=torch.float32, device=w.device)
     _chk(out, torch.float32, "out", 2)
-    lib = _lib.load()
-    if dropout is None:
-        _lib.check(lib.tt_dense_fwd_f32(_p(x), _p(w), _p(b), _p(out), m, k, n, int(relu), _stream()), "tt_dense_fwd_f32")
-    else:
-        rate, seed, tid, off = dropout
-        _lib.check(lib.tt_dense_fwd_dropout_f32(_p(x), _p(w), _p(b), _p(out), m, k, n, int(relu), rate, seed, tid, off,
-                                                _stream()), "tt_dense_fwd_dropout_f32")
+    if tuple(out.shape) != (m, n):
+        raise RuntimeError(f"dense_fwd: out must be [{m},{n}], got {tuple(out.shape)}")
+    rate, seed, tid, off = dropout if dropout is not None else (0.0, 0, 0, 0)
+    arr = (_lib.DenseFwdArgs * 1)(_lib.DenseFwdArgs(None if lookup is not None else _p(x), _p(w), _p(b), _p(out), tid,
+                                                    lookup if lookup is not None else _no_lookup()))
+    _lib.check(_lib.load().tt_dense_fwd_batched_f32(arr, 1, m, k, n, int(relu), rate, seed, off, _stream()),
+               "tt_dense_fwd_batched_f32")
     return out
 
 
@@ -308,12 +345,12 @@ def dense_bwd_num_slabs(m: int) -> int:
     return int(_lib.load().tt_dense_bwd_num_slabs(m))
 
 
-def dense_bwd(x, w, dz, dx, dx_relu_src, dw_slabs, db_slabs, dx_scale: float = 1.0):
-    """dx = dz@w^T (* (dx_relu_src>0)); dw_slabs/db_slabs get the split-K partials."""
-    _chk(x, torch.float32, "x", 2)
+def dense_bwd(x, w, dz, dx, dx_relu_src, dw_slabs, db_slabs, dx_scale: float = 1.0, lookup=None):
+    """dx = dz@w^T (* (dx_relu_src>0)); dw_slabs/db_slabs get the split-K partials.  With ``lookup`` the layer's input
+    (needed by dw = x^T dz) is read from the embedding table."""
     _chk(w, torch.float32, "w", 2)
     _chk(dz, torch.float32, "dz", 2)
-    m, k = x.shape
+    m, k = _in_shape(x, lookup)
     n = w.shape[1]
     if dx is not None:
         _chk(dx, torch.float32, "dx", 2)
@@ -325,28 +362,31 @@ def dense_bwd(x, w, dz, dx, dx_relu_src, dw_slabs, db_slabs, dx_scale: float = 1
         _chk(db_slabs, torch.float32, "db_slabs")
         if dw_slabs.numel() < ns * k * n or db_slabs.numel() < ns * n:
             raise RuntimeError("dense_bwd: slab buffers too small")
-    lib = _lib.load()
-    _lib.check(lib.tt_dense_bwd_scaled_f32(_p(x), _p(w), _p(dz), _p(dx), _p(dx_relu_src), dx_scale, _p(dw_slabs),
-                                           _p(db_slabs), m, k, n, _stream()), "tt_dense_bwd_scaled_f32")
+    arr = (_lib.DenseBwdArgs * 1)(_lib.DenseBwdArgs(None if lookup is not None else _p(x), _p(w), _p(dz), _p(dx), _p(dx_relu_src),
+                                                    _p(dw_slabs), _p(db_slabs), lookup if lookup is not None else _no_lookup()))
+    _lib.check(_lib.load().tt_dense_bwd_batched_f32(arr, 1, dx_scale, m, k, n, _stream()), "tt_dense_bwd_batched_f32")
     return ns
 
 
-def dense_fwd2(xs, ws, bs, ys, relu: bool, dropout=None):
-    """Layer l of both towers in one launch: ys[i] = act(xs[i] @ ws[i] + bs[i]).  dropout = (rate, seed, (tid_a, tid_b), offset)."""
-    m, k = xs[0].shape
+def dense_fwd2(xs, ws, bs, ys, relu: bool, dropout=None, lookups=None):
+    """Layer l of both towers in one launch: ys[i] = act(xs[i] @ ws[i] + bs[i]).  dropout = (rate, seed, (tid_a, tid_b), offset).
+    lookups = (lookup_a, lookup_b): the towers' first layer reads its input rows from the embedding tables."""
+    m, k = _in_shape(xs[0], None if lookups is None else lookups[0])
     n = ws[0].shape[1]
     rate, seed, tids, off = dropout if dropout is not None else (0.0, 0, (0, 0), 0)
-    arr = (_lib.DenseFwdArgs * 2)(*[_lib.DenseFwdArgs(_p(xs[i]), _p(ws[i]), _p(bs[i]), _p(ys[i]), tids[i]) for i in range(2)])
+    arr = (_lib.DenseFwdArgs * 2)(*[_lib.DenseFwdArgs(None if lookups is not None else _p(xs[i]), _p(ws[i]), _p(bs[i]), _p(ys[i]),
+                                                      tids[i], lookups[i] if lookups is not None else _no_lookup()) for i in range(2)])
     _lib.check(_lib.load().tt_dense_fwd_batched_f32(arr, 2, m, k, n, int(relu), rate, seed, off, _stream()),
                "tt_dense_fwd_batched_f32")
 
 
-def dense_bwd2(xs, ws, dzs, dxs, dx_relu_srcs, dw_slabs, db_slabs, dx_scale: float = 1.0):
-    """Backward of layer l of both towers: two launches (dx for both, dw+db for both)."""
-    m, k = xs[0].shape
+def dense_bwd2(xs, ws, dzs, dxs, dx_relu_srcs, dw_slabs, db_slabs, dx_scale: float = 1.0, lookups=None):
+    """Backward of layer l of both towers: one launch (dx and dw+db tiles side by side; dx only / dw only: one each)."""
+    m, k = _in_shape(xs[0], None if lookups is None else lookups[0])
     n = ws[0].shape[1]
-    arr = (_lib.DenseBwdArgs * 2)(*[_lib.DenseBwdArgs(_p(xs[i]), _p(ws[i]), _p(dzs[i]), _p(dxs[i]), _p(dx_relu_srcs[i]),
-                                                     _p(dw_slabs[i]), _p(db_slabs[i])) for i in range(2)])
+    arr = (_lib.DenseBwdArgs * 2)(*[_lib.DenseBwdArgs(None if lookups is not None else _p(xs[i]), _p(ws[i]), _p(dzs[i]), _p(dxs[i]),
+                                                     _p(dx_relu_srcs[i]), _p(dw_slabs[i]), _p(db_slabs[i]),
+                                                     lookups[i] if lookups is not None else _no_lookup()) for i in range(2)])
     _lib.check(_lib.load().tt_dense_bwd_batched_f32(arr, 2, dx_scale, m, k, n, _stream()), "tt_dense_bwd_batched_f32")
 
 

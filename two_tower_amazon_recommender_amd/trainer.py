@@ -111,19 +111,21 @@ class Tower:
         dims = [cfg.embedding_dim] + list(tower_dims)
         return sum(dims[l] * dims[l + 1] + dims[l + 1] for l in range(len(tower_dims)))
 
-    def forward(self, dropout=None):
+    def forward(self, dropout=None, lookup=None):
         """dropout = (rate, seed, tower_index, first_global_row) in training; None = inference (no dropout).
-        Inverted dropout follows every hidden (ReLU) layer, fused in the GEMM epilogue."""
+        Inverted dropout follows every hidden (ReLU) layer, fused in the GEMM epilogue.
+        lookup (ops.make_lookup): layer 0 reads its input rows from the embedding table (acts[0] is not used)."""
         for l in range(self.n_layers):
             hidden = l < self.n_layers - 1
             d = None
             if dropout is not None and hidden and dropout[0] > 0.0:
                 rate, seed, tower, row0 = dropout
                 d = (rate, seed, TID_DROPOUT_BASE + 2 * l + tower, row0 * self.dims[l + 1])
-            ops.dense_fwd(self.acts[l], self.w[l], self.b[l], relu=hidden, out=self.acts[l + 1], dropout=d)
+            ops.dense_fwd(self.acts[l], self.w[l], self.b[l], relu=hidden, out=self.acts[l + 1], dropout=d,
+                          lookup=lookup if l == 0 else None)
         return self.acts[-1]
 
-    def backward(self, dropout_rate: float = 0.0, dx: bool = True, dw: bool = True):
+    def backward(self, dropout_rate: float = 0.0, dx: bool = True, dw: bool = True, lookup=None):
         """Consumes dz[-1]; leaves demb (dx) and the dw/db slabs (dw).  backward(dx=True, dw=False) followed by
         backward(dx=False, dw=True) is the same computation with every dx first."""
         scale = 1.0
@@ -134,7 +136,8 @@ class Tower:
             dxo = (self.dz[l - 1] if l > 0 else self.demb) if dx else None
             mask_src = self.acts[l] if (l > 0 and dx) else None       # acts[l] = (dropped-out) ReLU output of layer l-1
             ops.dense_bwd(self.acts[l], self.w[l], self.dz[l], dxo, mask_src, self.dw_slabs[l] if dw else None,
-                          self.db_slabs[l] if dw else None, dx_scale=scale if l > 0 else 1.0)
+                          self.db_slabs[l] if dw else None, dx_scale=scale if l > 0 else 1.0,
+                          lookup=lookup if l == 0 else None)
 
     def segments(self, l2: float, grad_flat=None, grad_offset: int = 0):
         segs = []
@@ -148,9 +151,10 @@ class Tower:
         return segs
 
 
-def towers_forward(ut: "Tower", it: "Tower", dropout=None):
+def towers_forward(ut: "Tower", it: "Tower", dropout=None, lookups=None):
     """Both towers layer by layer, one launch per layer (the towers have identical shapes).
-    dropout = (rate, seed, first_global_row) in training, None at inference."""
+    dropout = (rate, seed, first_global_row) in training, None at inference.
+    lookups = (user lookup, item lookup): layer 0 gathers its input rows from the embedding tables itself."""
     for l in range(ut.n_layers):
         hidden = l < ut.n_layers - 1
         d = None
@@ -158,11 +162,11 @@ def towers_forward(ut: "Tower", it: "Tower", dropout=None):
             rate, seed, row0 = dropout
             d = (rate, seed, (TID_DROPOUT_BASE + 2 * l, TID_DROPOUT_BASE + 2 * l + 1), row0 * ut.dims[l + 1])
         ops.dense_fwd2((ut.acts[l], it.acts[l]), (ut.w[l], it.w[l]), (ut.b[l], it.b[l]), (ut.acts[l + 1], it.acts[l + 1]),
-                       relu=hidden, dropout=d)
+                       relu=hidden, dropout=d, lookups=lookups if l == 0 else None)
     return ut.acts[-1], it.acts[-1]
 
 
-def towers_backward(ut: "Tower", it: "Tower", dropout_rate: float = 0.0, on_embedding_grads=None):
+def towers_backward(ut: "Tower", it: "Tower", dropout_rate: float = 0.0, on_embedding_grads=None, lookups=None):
     """Backward of both towers, two launches per layer (dx of both, dw+db of both).
     With ``on_embedding_grads`` every dx is computed first, the callback runs as soon as demb is complete (the
     sharded trainer starts the gradient exchange there) and the dw+db launches follow, beside the transfer."""
@@ -177,7 +181,7 @@ def towers_backward(ut: "Tower", it: "Tower", dropout_rate: float = 0.0, on_embe
         masks = (ut.acts[l], it.acts[l]) if (l > 0 and dx) else none2
         ops.dense_bwd2((ut.acts[l], it.acts[l]), (ut.w[l], it.w[l]), (ut.dz[l], it.dz[l]), dxs, masks,
                        (ut.dw_slabs[l], it.dw_slabs[l]) if dw else none2, (ut.db_slabs[l], it.db_slabs[l]) if dw else none2,
-                       dx_scale=scale if l > 0 else 1.0)
+                       dx_scale=scale if l > 0 else 1.0, lookups=lookups if l == 0 else None)
 
     if on_embedding_grads is None:
         for l in range(ut.n_layers - 1, -1, -1):
@@ -226,6 +230,7 @@ class TwoTowerTrainer:
         # the main stream's kernels, whatever other streams the process has created
         self._side = torch.cuda.Stream(device=dev, priority=-1)
         self.step_index = 0                      # counter of the dropout stream (global batch row = step*batch + r)
+        self.fuse_lookup = True                  # K1 inside the first tower layer's GEMMs (False: gather2 launch + acts[0])
         self.flag_poll_every = 50                # steps between asynchronous polls of the out-of-range flag (0 = never)
         self._oob_host = self._oob_event = None
         self._oob_step = -1
@@ -285,8 +290,18 @@ class TwoTowerTrainer:
                 raise ValueError(f"batch must have exactly {b} entries (got {t.numel()}): the kernels' buffers are sized "
                                  "for cfg.batch_size; pad or drop a ragged last batch")
 
+    def _lookups(self, user_ids, item_ids, category_ids):
+        """K1 fused into the towers' first layer (fwd GEMM and dW GEMM read the table rows themselves): the
+        [batch, dim] tower inputs are never written to HBM.  None when the batch is too long for the fused form."""
+        self._check_batch(user_ids, item_ids, category_ids)
+        if not self.fuse_lookup or self.cfg.batch_size > ops.MAX_FUSED_LOOKUP_ROWS:
+            return None
+        return (ops.make_lookup(self.user_table, user_ids, oob_flag=self.oob),
+                ops.make_lookup(self.item_table, item_ids, self.cat_table, category_ids, self.oob))
+
     def _item_inputs(self, user_ids, item_ids, category_ids):
-        """K1: both towers' input rows; the hashed category's row is summed into the item tower's input."""
+        """K1 as its own launch (fuse_lookup = False): both towers' input rows; the hashed category's row is summed
+        into the item tower's input."""
         self._check_batch(user_ids, item_ids, category_ids)
         ut, it = self.user_tower, self.item_tower
         ops.embedding_gather2(self.user_table, user_ids, ut.acts[0], self.item_table, item_ids, it.acts[0], self.oob)
@@ -298,22 +313,25 @@ class TwoTowerTrainer:
                          candidate_sampling_probability=None, candidate_ids=None, category_ids=None):
         cfg, ut, it = self.cfg, self.user_tower, self.item_tower
         self._check_categories(category_ids)
-        self._item_inputs(user_ids, item_ids, category_ids)
+        lks = self._lookups(user_ids, item_ids, category_ids)
+        if lks is None:
+            self._item_inputs(user_ids, item_ids, category_ids)
+            lks = (None, None)
         row0 = self.step_index * cfg.batch_size
         if cfg.symmetric:        # same shapes: every layer of both towers in one launch
-            q, c = towers_forward(ut, it, (cfg.dropout_rate, self.dropout_seed, row0))
+            q, c = towers_forward(ut, it, (cfg.dropout_rate, self.dropout_seed, row0), lookups=lks if lks[0] else None)
         else:
-            q = ut.forward((cfg.dropout_rate, self.dropout_seed, 0, row0))
-            c = it.forward((cfg.dropout_rate, self.dropout_seed, 1, row0))
+            q = ut.forward((cfg.dropout_rate, self.dropout_seed, 0, row0), lookup=lks[0])
+            c = it.forward((cfg.dropout_rate, self.dropout_seed, 1, row0), lookup=lks[1])
         kw = dict(sample_weight=sample_weight, cand_prob=candidate_sampling_probability, cand_ids=candidate_ids)
         # loss + dq + dc in two fused passes over the logits (never materialised)
         ops.retrieval_fwd_bwd(q, c, 1.0 / cfg.temperature, self.ws, self.lse, self.per_row, self.loss,
                               ut.dz[-1], it.dz[-1], **kw)
         if cfg.symmetric:
-            towers_backward(ut, it, cfg.dropout_rate)
+            towers_backward(ut, it, cfg.dropout_rate, lookups=lks if lks[0] else None)
         else:
-            ut.backward(cfg.dropout_rate)
-            it.backward(cfg.dropout_rate)
+            ut.backward(cfg.dropout_rate, lookup=lks[0])
+            it.backward(cfg.dropout_rate, lookup=lks[1])
         self.step_index += 1
         return self.loss
 
@@ -355,8 +373,12 @@ class TwoTowerTrainer:
         self._check_categories(loss_kw.get("category_ids"))
         self._check_batch(loss_kw.get("sample_weight"), loss_kw.get("candidate_sampling_probability"),
                           loss_kw.get("candidate_ids"))
-        self._item_inputs(user_ids, item_ids, loss_kw.get("category_ids"))
-        q, c = towers_forward(ut, it) if cfg.symmetric else (ut.forward(), it.forward())
+        lks = self._lookups(user_ids, item_ids, loss_kw.get("category_ids"))
+        if lks is None:
+            self._item_inputs(user_ids, item_ids, loss_kw.get("category_ids"))
+            q, c = towers_forward(ut, it) if cfg.symmetric else (ut.forward(), it.forward())
+        else:
+            q, c = towers_forward(ut, it, lookups=lks) if cfg.symmetric else (ut.forward(lookup=lks[0]), it.forward(lookup=lks[1]))
         kw = dict(sample_weight=loss_kw.get("sample_weight"), cand_prob=loss_kw.get("candidate_sampling_probability"),
                   cand_ids=loss_kw.get("candidate_ids"))
         return ops.retrieval_fwd(q, c, 1.0 / cfg.temperature, self.ws, self.lse, self.per_row, self.loss, **kw)
@@ -387,9 +409,7 @@ class TwoTowerTrainer:
         self._check_batch(user_ids, item_ids)
         if corpus is None:
             corpus = self.item_corpus_embeddings()
-        ut = self.user_tower
-        ops.embedding_gather(self.user_table, user_ids, out=ut.acts[0], oob_flag=self.oob)
-        q = ut.forward()
+        q = self.user_tower.forward(lookup=ops.make_lookup(self.user_table, user_ids, oob_flag=self.oob))
         return metric.update_state(q, corpus, item_ids)
 
     # ------------------------------------------------------------------ checkpoint
