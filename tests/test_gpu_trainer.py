@@ -599,3 +599,79 @@ def test_asymmetric_towers_match_oracle(dev):
         assert np.abs(tr.item_tower.demb.cpu().numpy() - r["die"]).max() <= 1e-4 * np.abs(r["die"]).max()
     assert np.abs(tr.item_tower.w[1].cpu().numpy() - ref.item_tower.weights[1]).max() <= 1e-5
     assert np.abs(tr.user_table.cpu().numpy() - ref.user_table).max() <= 2e-6
+
+
+def test_custom_ops_pass_opcheck_and_match_the_oracle(dev):
+    """torch.library.opcheck on every registered op (schema, fake implementation, autograd registration, AOT dispatch),
+    then numbers: the autograd path through torch.ops.twotower.retrieval_loss / dense_fwd against the f64 oracle."""
+    from two_tower_amazon_recommender_amd import torch_ops  # noqa: F401
+    g = torch.Generator(device="cpu").manual_seed(3)
+    b, d, n = 192, 64, 128
+    q = (torch.rand(b, d, generator=g) * 0.6 - 0.3).to(dev).requires_grad_()
+    c = (torch.rand(b + 40, d, generator=g) * 0.6 - 0.3).to(dev).requires_grad_()
+    w = (torch.rand(b, generator=g) + 0.5).to(dev)
+    p = (torch.rand(b + 40, generator=g) * 0.5 + 0.001).to(dev)
+    ids = torch.randint(0, 50, (b + 40,), generator=g).to(dev)
+    opc = torch.library.opcheck
+    opc(torch.ops.twotower.retrieval_loss, (q, c, w, p, ids, 10.0, 7, 0))
+    opc(torch.ops.twotower.retrieval_loss, (q.detach(), c.detach(), None, None, None, 1.0, 0, 5))
+    opc(torch.ops.twotower.retrieval_loss_value, (q.detach(), c.detach(), w, None, None, 10.0, 0, 0))
+    opc(torch.ops.twotower.retrieval_rank, (q.detach(), c.detach(), torch.arange(b, device=dev), p, 10.0))
+    table = torch.rand(500, d, generator=g).to(dev)
+    opc(torch.ops.twotower.embedding_gather, (table, torch.randint(0, 500, (77,), generator=g).to(dev)))
+    x = (torch.rand(b, d, generator=g) - 0.5).to(dev).requires_grad_()
+    wt = (torch.rand(d, n, generator=g) - 0.5).to(dev).requires_grad_()
+    bias = (torch.rand(n, generator=g) - 0.5).to(dev).requires_grad_()
+    opc(torch.ops.twotower.dense_fwd, (x, wt, bias, True))
+    opc(torch.ops.twotower.dense_bwd, (x.detach(), wt.detach(), torch.rand(b, n, generator=g).to(dev), None))
+    acc = torch.full_like(table, 0.1)
+    grads = torch.rand(77, d, generator=g).to(dev)
+    opc(torch.ops.twotower.sparse_update_, (table.clone(), acc, grads, torch.randint(0, 500, (77,), generator=g).to(dev), "adagrad", 0.01, 1e-7))
+    # numbers: loss(dense(x)) differentiated by autograd through the two custom ops
+    y = torch.ops.twotower.dense_fwd(x, wt, bias, True)
+    c2 = (torch.rand(b + 40, n, generator=g) * 0.6 - 0.3).to(dev).requires_grad_()
+    loss, _, _, _ = torch.ops.twotower.retrieval_loss(y, c2, w, p, ids, 10.0, 7, 0)
+    (loss * 0.5).backward()
+    xn, wn, bn, cn = (t.detach().cpu().double().numpy() for t in (x, wt, bias, c2))
+    yn = np.maximum(xn @ wn + bn, 0)
+    kw = dict(temperature=0.1, sample_weight=w.cpu().numpy(), candidate_sampling_probability=p.cpu().numpy(),
+              candidate_ids=ids.cpu().numpy(), remove_accidental_hits=True, diag_offset=7)
+    rl, _, _ = tt.retrieval_loss(yn, cn, **kw)
+    dyn, dcn = tt.retrieval_grad(yn, cn, **kw)
+    dyn, dcn = 0.5 * dyn * (yn > 0), 0.5 * dcn
+    assert abs(loss.item() - rl) <= 1e-4 * abs(rl)
+    for got, ref in ((x.grad, dyn @ wn.T), (wt.grad, xn.T @ dyn), (bias.grad, dyn.sum(0)), (c2.grad, dcn)):
+        assert np.abs(got.cpu().numpy() - ref).max() <= 2e-4 * np.abs(ref).max()
+
+
+def test_retrieval_task_with_factorized_topk_and_loss_metrics(dev):
+    """tfrs.tasks.Retrieval(metrics=FactorizedTopK(candidates=...)): the task updates the metric when compute_metrics
+    is true, given every candidate's index in the corpus."""
+    from two_tower_amazon_recommender_amd.metrics import FactorizedTopK
+    from two_tower_amazon_recommender_amd.tasks import Retrieval
+    g = torch.Generator(device="cpu").manual_seed(5)
+    corpus = (torch.rand(1000, 32, generator=g) - 0.5).to(dev)
+    idx = torch.randperm(1000, generator=g)[:128].to(dev)
+    q = (corpus[idx] + 0.01 * torch.rand(128, 32, generator=g).to(dev)).requires_grad_()      # queries near their true items
+
+    class Mean:
+        def __init__(self):
+            self.v = []
+
+        def update_state(self, x):
+            self.v.append(float(x))
+    lm = Mean()
+    metric = FactorizedTopK(ks=(1, 10), temperature=0.1, candidates=corpus)
+    task = Retrieval(metrics=metric, loss_metrics=[lm], temperature=0.1)
+    loss = task(q, corpus[idx], candidate_ids=idx)
+    loss.backward()
+    assert q.grad is not None and torch.isfinite(q.grad).all() and len(lm.v) == 1 and abs(lm.v[0] - loss.item()) < 1e-3
+    res = task.factorized_metrics.result()
+    s = (q.detach().double() @ corpus.double().T) * 10.0
+    rank = (s > s[torch.arange(128), idx][:, None]).sum(1)
+    assert abs(res["recall@1"] - (rank < 1).double().mean().item()) < 1e-9
+    assert abs(res["recall@10"] - (rank < 10).double().mean().item()) < 1e-9
+    task(q.detach(), corpus[idx], candidate_ids=idx, compute_metrics=False)       # no update
+    assert metric._n == 128
+    with pytest.raises(ValueError):
+        task(q.detach(), corpus[idx])                                              # metrics need the candidates' corpus index

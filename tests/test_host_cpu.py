@@ -82,8 +82,12 @@ def test_category_column_reader_and_batch_triples(tmp_path):
 def test_retrieval_task_argument_errors_mirror_tfrs():
     with pytest.raises(ValueError):
         Retrieval(num_hard_negatives=0)
+    with pytest.raises(TypeError):
+        Retrieval(metrics=object())                # only metrics.FactorizedTopK(candidates=...) is a metric the task can run
     with pytest.raises(NotImplementedError):
-        Retrieval(metrics=object())
+        Retrieval(batch_metrics=[object()])        # would need the materialised in-batch score matrix
+    with pytest.raises(TypeError):
+        Retrieval(loss_metrics=[object()])
     with pytest.raises(ValueError):
         Retrieval(temperature=0.0)
     task = Retrieval(temperature=0.1, remove_accidental_hits=True)
@@ -145,3 +149,24 @@ def test_bench_self_launches_ranks_and_relays_one_json_line(tmp_path):
         out = json.loads(lines[0])
         assert out["n_gpus"] == 2 and out["argv"] == ["--gpus", "2", "--steps", "3"]
         assert (res.returncode == 0) == (rc == 0), (rc, res.returncode, res.stderr[-2000:])
+
+
+def test_custom_ops_are_registered_with_schemas_and_fake_implementations():
+    """north_star: "exposed to Python through PyTorch-ROCm custom ops".  Every hot-path op is a torch.library custom op
+    (torch.ops.twotower.*) with a fake (meta) implementation, so shapes/dtypes propagate without a GPU; the real
+    implementations are CUDA-only (no CPU fallback: a CPU tensor is refused)."""
+    import torch
+    from two_tower_amazon_recommender_amd import torch_ops
+    for name in torch_ops.OPS:
+        assert hasattr(torch.ops.twotower, name), name
+    q, c = torch.empty(8, 32, device="meta"), torch.empty(16, 32, device="meta")
+    loss, per, dq, dc = torch.ops.twotower.retrieval_loss(q, c, None, None, None, 10.0, 0, 0)
+    assert loss.shape == () and per.shape == (8,) and dq.shape == (8, 32) and dc.shape == (16, 32)
+    assert torch.ops.twotower.retrieval_rank(q, c, torch.empty(8, dtype=torch.int64, device="meta"), None, 1.0).dtype == torch.int32
+    assert torch.ops.twotower.embedding_gather(torch.empty(100, 32, device="meta"), torch.empty(7, dtype=torch.int64, device="meta")).shape == (7, 32)
+    y = torch.ops.twotower.dense_fwd(q, torch.empty(32, 64, device="meta"), None, True)
+    assert y.shape == (8, 64)
+    schema = str(torch.ops.twotower.sparse_update_.default._schema)
+    assert "Tensor(a0!) table" in schema and "Tensor(a1!)? accum" in schema          # declared as mutating its table / accumulator
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        torch.ops.twotower.retrieval_loss(torch.zeros(4, 32), torch.zeros(4, 32), None, None, None, 1.0, 0, 0)   # CPU: no kernel

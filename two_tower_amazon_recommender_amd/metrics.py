@@ -12,9 +12,12 @@ from . import ops
 
 
 class FactorizedTopK:
-    def __init__(self, ks=(1, 5, 10, 20, 50, 100), temperature: float | None = None):
+    def __init__(self, ks=(1, 5, 10, 20, 50, 100), temperature: float | None = None, candidates: torch.Tensor | None = None):
+        """candidates: optional [n_candidates, D] corpus embeddings (tfrs.metrics.FactorizedTopK(candidates=...)); then
+        ``update_state(q, None, true_index)`` and ``tasks.Retrieval(metrics=...)`` rank against it."""
         self.ks = tuple(int(k) for k in ks)
         self.inv_t = 1.0 if temperature is None else 1.0 / temperature
+        self.candidates = None if candidates is None else candidates.contiguous()
         self.reset_state()
 
     def reset_state(self):
@@ -26,6 +29,10 @@ class FactorizedTopK:
     def update_state(self, query_embeddings: torch.Tensor, candidate_embeddings: torch.Tensor,
                      true_candidate_index: torch.Tensor, candidate_sampling_probability=None) -> torch.Tensor:
         """Accumulates the metrics of one query batch against the candidate corpus; returns the int32 ranks."""
+        if candidate_embeddings is None:
+            candidate_embeddings = self.candidates
+        if candidate_embeddings is None:
+            raise ValueError("FactorizedTopK.update_state: no candidate corpus (pass it here or to the constructor)")
         q, c = query_embeddings.contiguous(), candidate_embeddings.contiguous()
         key = (q.shape[0], c.shape[0], q.shape[1], str(q.device))
         if self._ws is None or self._ws[0] != key:         # one small buffer per shape, not one allocation per batch

@@ -4,10 +4,17 @@
 calls it).  The scorer, the in-batch sampled-softmax loss and its gradient run in ONE family of fused
 HIP kernels (csrc/score.hip): the [num_queries, num_candidates] logits never reach HBM.
 
+The task dispatches through the registered custom ops ``torch.ops.twotower.retrieval_loss`` (training: loss and
+both gradients in the fused two-pass form, 8*Bq*Bc*D executed FLOPs, gradients saved for autograd) and
+``torch.ops.twotower.retrieval_loss_value`` (no gradient needed: one statistics pass) — ``torch_ops.py``.
+
 Differences from TFRS, all loud:
   * ``loss`` must be None (the TFRS default: CategoricalCrossentropy(from_logits=True, reduction=SUM));
-  * ``metrics`` / ``batch_metrics`` / ``loss_metrics`` objects are not accepted by the task (use
-    ``metrics.FactorizedTopK`` directly: it runs the fused rank pass) and raise NotImplementedError;
+  * ``metrics`` takes a ``metrics.FactorizedTopK`` built WITH its candidate corpus (``FactorizedTopK(candidates=...)``);
+    it is updated when ``compute_metrics`` is true, and ``candidate_ids`` must then be the int64 index of every
+    candidate in that corpus (the reference's ``item_idx``); ``loss_metrics`` takes objects with
+    ``update_state(loss)``; ``batch_metrics`` (metrics over the in-batch score matrix, which the fused kernels never
+    materialise) raises NotImplementedError;
   * ``num_hard_negatives=k`` keeps the positive and the k highest-scoring negatives per query
     (tfrs.layers.loss.HardNegativeMining); negatives tied with the k-th are all kept;
   * ``candidate_ids`` must be an int64 tensor (the reference's ids are int64:
@@ -17,41 +24,7 @@ from __future__ import annotations
 
 import torch
 
-from . import ops
-
-
-class _RetrievalLoss(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, q, c, sample_weight, cand_prob, cand_ids, inv_t, diag_offset, task):
-        k = task._num_hard_negatives
-        q = q.contiguous()
-        c = c.contiguous()
-        nq, nc, d = q.shape[0], c.shape[0], q.shape[1]
-        ws = task._workspace(nq, nc, d, q.device)
-        lse = torch.empty(nq, dtype=torch.float32, device=q.device)
-        per_row = torch.empty(nq, dtype=torch.float32, device=q.device)
-        loss = torch.empty(1, dtype=torch.float32, device=q.device)
-        thr = None
-        if k is not None:       # non-differentiable selection of the k hardest negatives per query (as in TFRS)
-            thr = ops.retrieval_hard_negative_thresholds(q, c, inv_t, k, ws, cand_prob=cand_prob, cand_ids=cand_ids,
-                                                         diag_offset=diag_offset)
-        ops.retrieval_fwd(q, c, inv_t, ws, lse, per_row, loss, sample_weight=sample_weight, cand_prob=cand_prob,
-                          cand_ids=cand_ids, diag_offset=diag_offset, hard_thr=thr)
-        ctx.save_for_backward(q, c, lse, sample_weight, cand_prob, cand_ids, thr)
-        ctx.inv_t, ctx.diag_offset, ctx.task = inv_t, diag_offset, task
-        task.last_per_example_loss = per_row
-        return loss.reshape(())
-
-    @staticmethod
-    def backward(ctx, grad_out):
-        q, c, lse, sample_weight, cand_prob, cand_ids, thr = ctx.saved_tensors
-        ws = ctx.task._workspace(q.shape[0], c.shape[0], q.shape[1], q.device)
-        dq = torch.empty_like(q)
-        dc = torch.empty_like(c)
-        ops.retrieval_bwd(q, c, ctx.inv_t, ws, lse, dq, dc, sample_weight=sample_weight, cand_prob=cand_prob,
-                          cand_ids=cand_ids, diag_offset=ctx.diag_offset, hard_thr=thr)
-        # upstream gradient of the scalar loss stays on the device (no host sync)
-        return dq * grad_out, dc * grad_out, None, None, None, None, None, None
+from . import torch_ops  # noqa: F401  (registers torch.ops.twotower.*)
 
 
 class Retrieval:
@@ -62,8 +35,19 @@ class Retrieval:
         if loss is not None:
             raise NotImplementedError("Retrieval(loss=...): only the TFRS default loss (categorical cross-entropy "
                                       "from logits, SUM reduction) is implemented in the HIP path")
-        if metrics is not None or batch_metrics is not None or loss_metrics is not None:
-            raise NotImplementedError("Retrieval metrics (FactorizedTopK etc.) are not implemented yet (SURVEY.md §8f)")
+        if batch_metrics is not None:
+            raise NotImplementedError("Retrieval(batch_metrics=...): metrics over the in-batch score matrix need the "
+                                      "[queries x candidates] logits, which the fused kernels never materialise")
+        if metrics is not None:
+            from .metrics import FactorizedTopK
+            if not isinstance(metrics, FactorizedTopK) or metrics.candidates is None:
+                raise TypeError("Retrieval(metrics=...) takes a metrics.FactorizedTopK built with its candidate corpus "
+                                "(FactorizedTopK(candidates=item_corpus_embeddings))")
+        self._factorized_metrics = metrics
+        self._loss_metrics = list(loss_metrics) if loss_metrics is not None else []
+        for m in self._loss_metrics:
+            if not hasattr(m, "update_state"):
+                raise TypeError("Retrieval(loss_metrics=...): every entry needs update_state(loss)")
         if num_hard_negatives is not None and num_hard_negatives < 1:
             raise ValueError("num_hard_negatives must be a positive integer")
         if temperature is not None and temperature <= 0:
@@ -72,17 +56,11 @@ class Retrieval:
         self._num_hard_negatives = num_hard_negatives
         self._remove_accidental_hits = remove_accidental_hits
         self.name = name
-        self._ws = {}
         self.last_per_example_loss = None
 
-    def _workspace(self, nq, nc, d, device):
-        key = (nq, nc, d, str(device))
-        ws = self._ws.get(key)
-        if ws is None:
-            self._ws.clear()                      # one live shape at a time: the slabs are tens of MB
-            ws = torch.empty(ops.retrieval_workspace_bytes(nq, nc, d), dtype=torch.uint8, device=device)
-            self._ws[key] = ws
-        return ws
+    @property
+    def factorized_metrics(self):
+        return self._factorized_metrics
 
     def __call__(self, query_embeddings, candidate_embeddings, sample_weight=None, candidate_sampling_probability=None,
                  candidate_ids=None, compute_metrics=True, compute_batch_metrics=True, diag_offset: int = 0):
@@ -97,6 +75,21 @@ class Retrieval:
         ids = candidate_ids if self._remove_accidental_hits else None
         sw = None if sample_weight is None else sample_weight.to(torch.float32).contiguous()
         cp = None if candidate_sampling_probability is None else candidate_sampling_probability.to(torch.float32).contiguous()
-        return _RetrievalLoss.apply(q, c, sw, cp, ids, inv_t, diag_offset, self)
+        k = 0 if self._num_hard_negatives is None else int(self._num_hard_negatives)
+        if torch.is_grad_enabled() and (q.requires_grad or c.requires_grad):
+            loss, per_example, _, _ = torch.ops.twotower.retrieval_loss(q, c, sw, cp, ids, inv_t, diag_offset, k)
+        else:
+            loss, per_example = torch.ops.twotower.retrieval_loss_value(q, c, sw, cp, ids, inv_t, diag_offset, k)
+        self.last_per_example_loss = per_example
+        if compute_metrics and self._factorized_metrics is not None:
+            if candidate_ids is None:
+                raise ValueError("Retrieval(metrics=FactorizedTopK): pass candidate_ids = the index of every candidate "
+                                 "in the metric's corpus")
+            with torch.no_grad():
+                true_index = candidate_ids[diag_offset:diag_offset + q.shape[0]]
+                self._factorized_metrics.update_state(q.detach(), None, true_index)
+        for m in self._loss_metrics:
+            m.update_state(loss.detach())
+        return loss
 
     call = __call__
