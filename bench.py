@@ -92,12 +92,14 @@ def cpu_share() -> int:
     return max(1, min(n, 16))
 
 
+PMC_FILE = "profiles/pmc_cfg3_sgd.json"     # rocprofv3 --pmc passes of round r01d (scratch/prof_pmc.sh + pmc_summary.py)
+
+
 def pmc_traffic(tag):
-    """HBM bytes per launch of kernel `tag` from the committed rocprofv3 --pmc summary (collected in separate passes,
-    MI355X_MICROARCH.md §HBM corrections applied; scratch/prof_pmc.sh + scratch/pmc_summary.py), or None."""
-    path = os.path.join(ROOT, "profiles", "pmc_cfg3_sgd.json")
+    """HBM bytes per launch of kernel `tag` from the COMMITTED rocprofv3 --pmc summary (separate passes,
+    MI355X_MICROARCH.md §HBM corrections applied) — not measured in this run: the line says so in `traffic_source`."""
     try:
-        return json.load(open(path))["kernels"][tag].get("hbm_bytes_per_launch")
+        return json.load(open(os.path.join(ROOT, PMC_FILE)))["kernels"][tag].get("hbm_bytes_per_launch")
     except (OSError, KeyError, ValueError):
         return None
 
@@ -183,7 +185,7 @@ def main():
     # Timed region: only the DOMINANT kernel carries hipEvent brackets (each event record is a barrier packet that
     # costs the stream ~4-7 us: bracketing all five kernel families inflated the step by 33 us = 4 %).  The other
     # kernels' durations come from an untimed detail pass of the same steps right after it.
-    all_tags = "score_fused,score_bwd,gather,sparse_plan,sparse_apply".split(",")
+    all_tags = "score_fused,score_bwd,gather,sparse_plan,sparse_apply,dense_fwd,dense_bwd".split(",")
     timed_tags = os.environ.get("TT_BENCH_TAGS", "score_fused")
     stride = 4 if args.steps >= 40 else 1            # the dominant kernel is sampled every 4th step (>= 10 samples)
     _lib.profile_set_stride(stride)
@@ -204,6 +206,21 @@ def main():
     torch.cuda.synchronize()
     for t in rest:
         prof[t] = _lib.profile_read(t, 2 * detail_steps + 8)[0]
+    # K1's cost inside the first layer's GEMMs = (layer-0 fwd + bwd launch with the lookup fused) - (the same launches on a
+    # materialised input), measured by a second untimed detail pass with the lookup un-fused (gather2 launch + acts[0])
+    n_layers = len(tower_dims)
+    lookup_us, unfused = None, {}
+    if trainer.fuse_lookup and cfg.symmetric and not args.graph:
+        trainer.fuse_lookup = False
+        _lib.profile_enable("dense_fwd,dense_bwd,gather", capacity=2 * n_layers * detail_steps + 8)
+        for s in range(total - detail_steps, total):
+            step(s)
+        torch.cuda.synchronize()
+        unfused = {t: _lib.profile_read(t, 2 * n_layers * detail_steps + 8)[0] for t in ("dense_fwd", "dense_bwd", "gather")}
+        trainer.fuse_lookup = True
+        f_l0 = mean(prof["dense_fwd"][0::n_layers]) - mean(unfused["dense_fwd"][0::n_layers])
+        b_l0 = mean(prof["dense_bwd"][n_layers - 1::n_layers]) - mean(unfused["dense_bwd"][n_layers - 1::n_layers])
+        lookup_us = (f_l0 + b_l0) * 1e3
     _lib.profile_enable("")
     steps_of = {t: (args.steps if t in timed_tags.split(",") else detail_steps) for t in all_tags}
     loss = float(trainer.loss.item())
@@ -223,7 +240,9 @@ def main():
             return {"bound": "mfma", "kernel": name, "achieved": None, "note": "no hipEvent samples (graph replay)"}
         a = alg_flops / t / 1e12
         return {"bound": "mfma", "kernel": name, "achieved": a, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": a / MFMA_F32_PEAK_TFLOPS, "traffic": None, "avg_launch_us": t * 1e6, "dtype": "f32-input MFMA",
+                "frac": a / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                "traffic_source": f"{PMC_FILE} (committed rocprofv3 --pmc passes of round r01d; not re-measured in this run)",
+                "avg_launch_us": t * 1e6, "dtype": "f32-input MFMA",
                 "executed_tflops": 4.0 * b2d / t / 1e12, "executed_frac": 4.0 * b2d / t / 1e12 / MFMA_F32_PEAK_TFLOPS}
 
     r_fused = roof(f"score_kernel<{sd},FUSED> (loss + dq pass; 1 launch/step; algorithmic 4*B^2*D)", 4.0 * b2d, t_fused)
@@ -242,7 +261,7 @@ def main():
 
     def per_step(tag):                 # ms per STEP (a step may launch a tagged kernel more than once)
         return sum(prof[tag]) / steps_of[tag]
-    t_gs = max((per_step("gather") + per_step("sparse_apply")) * 1e-3, 1e-12)
+    t_gs = max((per_step("gather") + per_step("sparse_apply")) * 1e-3 + max(lookup_us or 0.0, 0.0) * 1e-6, 1e-12)
     out = {
         "metric": "user-item pairs/sec (train step) + embedding-gather HBM GB/s, 1/2/4/8 MI355X",
         "value": batch / (dt / args.steps), "unit": "pairs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -258,14 +277,24 @@ def main():
                        f"({len(prof['score_fused'])} samples); score_bwd / gather / sparse_* durations "
                        f"from an untimed detail pass of {detail_steps} further steps",
         "roofline": dominant,
-        "roofline_hbm": {"bound": "hbm", "kernel": "gather2 + sparse_update2 (K1 + K2 apply; both tables; hipEvent brackets add "
-                                                   "~3 us to kernels this short, see profiles/ for rocprof durations)",
+        "roofline_hbm": {"bound": "hbm",
+                         "kernel": "K1 + K2 on the critical path: the embedding lookup fused into the first tower layer's GEMM "
+                                   "loaders (time = what the layer-0 fwd and bwd launches cost MORE than on a materialised "
+                                   "input, from an un-fused detail pass) + sparse_apply_kernel (ONE launch: "
+                                   "segmented sums, fused SGD/Adagrad, arrival-ticket finish; both tables). EXCLUDED and "
+                                   "reported beside it: lds_sort_kernel (the plan: one launch for all tables on a side stream, "
+                                   "concurrent with the forward pass). hipEvent brackets add ~3 us to kernels this short; "
+                                   "rocprof durations: profiles/",
                          "achieved": gs_bytes / t_gs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": gs_bytes / t_gs / 1e9 / HBM_PEAK_GBS,
-                         "traffic": ((pmc_traffic("gather") or 0) + (pmc_traffic("sparse_apply") or 0)) or None
-                         if (args.config == "cfg3" and args.optimizer == "sgd") else None,
-                         "gather_us": per_step("gather") * 1e3, "sparse_apply_us": per_step("sparse_apply") * 1e3,
-                         "sparse_plan_us_each_side_stream": mean(prof["sparse_plan"]) * 1e3, "algorithmic_bytes": gs_bytes},
+                         "traffic": None,
+                         "lookup_in_gemm_us": lookup_us,
+                         "unfused_gather2_us": (mean(unfused["gather"]) * 1e3) if unfused.get("gather") else None,
+                         "gather_us": per_step("gather") * 1e3,
+                         "sparse_apply_us": per_step("sparse_apply") * 1e3,
+                         "sparse_plan_us_side_stream": per_step("sparse_plan") * 1e3,
+                         "frac_with_plan_counted": gs_bytes / (t_gs + per_step("sparse_plan") * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "algorithmic_bytes": gs_bytes},
         "loss_per_pair": loss / batch,
     }
     if not args.no_cpu_baseline and not cfg.n_category_buckets:     # the torch-CPU port covers the cfg1-cfg4 model

@@ -13,7 +13,8 @@ import subprocess
 import threading
 
 _PKG = pathlib.Path(__file__).resolve().parent
-LIB_PATH = _PKG / "libtwotower_hip.so"
+# TT_LIB_PATH: load another build of the same C ABI (kernel A/B experiments); the product default is the in-tree library
+LIB_PATH = pathlib.Path(os.environ["TT_LIB_PATH"]) if os.environ.get("TT_LIB_PATH") else _PKG / "libtwotower_hip.so"
 ABI_VERSION = 5
 
 TT_OK, TT_ERR_INVALID_ARG, TT_ERR_LAUNCH, TT_ERR_UNSUPPORTED, TT_ERR_WORKSPACE = range(5)

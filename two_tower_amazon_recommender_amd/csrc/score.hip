@@ -36,6 +36,12 @@ constexpr float kLn2 = 0.69314718055994530942f;
 constexpr float kNegBig = -1.0e30f;   // log2-domain stand-in for -inf (tfrs uses finfo.min/100)
 
 enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2, MODE_RANK = 3 };
+#ifndef TT_PK_EPILOGUE
+// 1: v_pk_fma_f32 / v_pk_add_f32 pairs in the softmax epilogue; 0: scalar f32 ops.  A/B on one box, alternating runs
+// (profiles/r02_ab_epilogue_pk_vs_scalar.txt): FUSED 273.1 vs 272.4 us, BWD 271.3 vs 271.7 us, step 0.7024 vs 0.7019 ms —
+// a tie; the scalar form is the default (MI355X_MICROARCH.md: packed f32 VALU beside MFMAs is at best neutral).
+#define TT_PK_EPILOGUE 0
+#endif
 constexpr float kRescaleThr = 8.0f;   // FUSED: rescale the accumulators only when a row max grows by > 2^8 (p stays <= 256)
 
 struct ScoreArgs {
@@ -280,12 +286,17 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? 2 : 1))) 
         // the fma and the add as packed f32 pairs (v_pk_fma_f32 / v_pk_add_f32: same roundings, half the VALU
         // issue slots — VALU cycles are not hidden behind f32 MFMAs)
         float tvs[16];
+        if constexpr (TT_PK_EPILOGUE) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const f32x2 x2 = f32x2{X[2 * q], X[2 * q + 1]}, a2 = f32x2{ac[2 * q], ac[2 * q + 1]};
-          const f32x2 t2 = __builtin_elementwise_fma(x2, f32x2{p.c1, p.c1}, a2) + f32x2{ar, ar};
-          tvs[2 * q] = t2[0];
-          tvs[2 * q + 1] = t2[1];
+          for (int q = 0; q < 8; ++q) {
+            const f32x2 x2 = f32x2{X[2 * q], X[2 * q + 1]}, a2 = f32x2{ac[2 * q], ac[2 * q + 1]};
+            const f32x2 t2 = __builtin_elementwise_fma(x2, f32x2{p.c1, p.c1}, a2) + f32x2{ar, ar};
+            tvs[2 * q] = t2[0];
+            tvs[2 * q + 1] = t2[1];
+          }
+        } else {
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) tvs[reg] = __builtin_fmaf(X[reg], p.c1, ac[reg]) + ar;
         }
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
@@ -307,12 +318,17 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? 2 : 1))) 
         // over both halves' c).  Lazy rescale (threshold kRescaleThr): wave-uniform branch.
         float mx = kNegBig;
         float vs[16];
+        if constexpr (TT_PK_EPILOGUE) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {      // packed f32 pairs: v_pk_fma_f32
-          const f32x2 x2 = f32x2{X[2 * q], X[2 * q + 1]}, a2 = f32x2{ac[2 * q], ac[2 * q + 1]};
-          const f32x2 t2 = __builtin_elementwise_fma(x2, f32x2{p.c1, p.c1}, a2);
-          vs[2 * q] = t2[0];
-          vs[2 * q + 1] = t2[1];
+          for (int q = 0; q < 8; ++q) {      // packed f32 pairs: v_pk_fma_f32
+            const f32x2 x2 = f32x2{X[2 * q], X[2 * q + 1]}, a2 = f32x2{ac[2 * q], ac[2 * q + 1]};
+            const f32x2 t2 = __builtin_elementwise_fma(x2, f32x2{p.c1, p.c1}, a2);
+            vs[2 * q] = t2[0];
+            vs[2 * q + 1] = t2[1];
+          }
+        } else {
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) vs[reg] = __builtin_fmaf(X[reg], p.c1, ac[reg]);
         }
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
@@ -339,16 +355,28 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? 2 : 1))) 
           run_m = m_new;
         }
         float sum = 0.f;
+        if constexpr (TT_PK_EPILOGUE) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {      // the subtraction as packed pairs (v_pk_add_f32 with negated operand)
-          const f32x2 d2 = f32x2{coef[2 * q], coef[2 * q + 1]} - f32x2{run_m, run_m};
-          coef[2 * q] = __builtin_amdgcn_exp2f(d2[0]);
-          coef[2 * q + 1] = __builtin_amdgcn_exp2f(d2[1]);
+          for (int q = 0; q < 8; ++q) {      // the subtraction as packed pairs (v_pk_add_f32 with negated operand)
+            const f32x2 d2 = f32x2{coef[2 * q], coef[2 * q + 1]} - f32x2{run_m, run_m};
+            coef[2 * q] = __builtin_amdgcn_exp2f(d2[0]);
+            coef[2 * q + 1] = __builtin_amdgcn_exp2f(d2[1]);
+          }
+          f32x2 s2 = f32x2{coef[0], coef[1]};           // 8 packed adds + 1 instead of 16 sequential ones
+#pragma unroll
+          for (int q = 1; q < 8; ++q) s2 += f32x2{coef[2 * q], coef[2 * q + 1]};
+          sum = s2[0] + s2[1];
+        } else {                                        // the same additions (pairs, then the two lanes), scalar ops
+          float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            coef[2 * q] = __builtin_amdgcn_exp2f(coef[2 * q] - run_m);
+            coef[2 * q + 1] = __builtin_amdgcn_exp2f(coef[2 * q + 1] - run_m);
+            s0 = q == 0 ? coef[0] : s0 + coef[2 * q];
+            s1 = q == 0 ? coef[1] : s1 + coef[2 * q + 1];
+          }
+          sum = s0 + s1;
         }
-        f32x2 s2 = f32x2{coef[0], coef[1]};           // 8 packed adds + 1 instead of 16 sequential ones
-#pragma unroll
-        for (int q = 1; q < 8; ++q) s2 += f32x2{coef[2 * q], coef[2 * q + 1]};
-        sum = s2[0] + s2[1];
         run_l += sum;
       }
     }
