@@ -340,6 +340,18 @@ int tt_retrieval_fwd_bwd_f32(const float* q, const float* c, int64_t nq, int64_t
                              float* lse, float* per_row, float* loss, float* dq, float* dc,
                              tt_stream_t stream);
 
+/* The same fused training form with every matrix product on the bf16 matrix cores through a three-way split of the
+ * f32 operands (x = hi + mid + lo, each bf16, residuals exact): "bf16x3", an f32-EMULATED precision — 6 bf16 products
+ * per logit term (error ~2^-24 relative), 3 per gradient term (~2^-16), f32 accumulation, f32 softmax; inputs and
+ * outputs stay f32 and the results meet the same 1e-4 bars as the exact-f32 form (tests/test_gpu_parity.py).  2.7x
+ * fewer matrix-pipe cycles than v_mfma_f32_32x32x2_f32.  dim must be 128 or 256 (else TT_ERR_UNSUPPORTED: use the f32 form). */
+int tt_retrieval_fwd_bwd_bf16x3_f32(const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
+                                    int64_t diag_offset, float inv_temperature,
+                                    const float* sample_weight, const float* cand_prob, const int64_t* cand_ids,
+                                    const float* hard_thr, float grad_scale, void* workspace, int64_t workspace_bytes,
+                                    float* lse, float* per_row, float* loss, float* dq, float* dc,
+                                    tt_stream_t stream);
+
 /* Retrieval metrics (configs/data_config.yaml:71 top_k_eval; tfrs.metrics.FactorizedTopK's role):
  * rank[i] = number of candidates j != pos_index[i] with s_ij > s_{i,pos_index[i]} over ALL nc candidates
  * (nc may be the whole item corpus; nq <= or > nc both allowed).  Recall@K = mean(rank < K),

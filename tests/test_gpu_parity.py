@@ -450,8 +450,9 @@ def run_retrieval(dev, q, c, temperature, w=None, p=None, ids=None, off=0, grad_
     kw = dict(sample_weight=None if w is None else T(w.astype(np.float32), dev),
               cand_prob=None if p is None else T(p.astype(np.float32), dev),
               cand_ids=None if ids is None else T(ids.astype(np.int64), dev), diag_offset=off)
-    if fused:
-        ops.retrieval_fwd_bwd(dq_, dc_, 1.0 / temperature, ws, lse, per_row, loss, dq, dc, grad_scale=grad_scale, **kw)
+    if fused:       # True: exact-f32 fused form; "bf16x3": the f32-emulated split-bf16 form of the same two passes
+        ops.retrieval_fwd_bwd(dq_, dc_, 1.0 / temperature, ws, lse, per_row, loss, dq, dc, grad_scale=grad_scale,
+                              precision="bf16x3" if fused == "bf16x3" else "f32", **kw)
     else:
         ops.retrieval_fwd(dq_, dc_, 1.0 / temperature, ws, lse, per_row, loss, **kw)
         ops.retrieval_bwd(dq_, dc_, 1.0 / temperature, ws, lse, dq, dc, grad_scale=grad_scale, **kw)
@@ -459,8 +460,9 @@ def run_retrieval(dev, q, c, temperature, w=None, p=None, ids=None, off=0, grad_
 
 
 def check_retrieval(dev, nq, nc, d, temperature=0.1, scale=0.3, use_w=False, use_p=False, use_ids=False, off=0, seed=41):
-    """Checks BOTH forms: separate fwd + bwd entry points, and the fused two-pass training entry."""
-    for fused in (False, True):
+    """Checks ALL forms against the f64 oracle at the SAME bars: separate fwd + bwd entry points, the fused two-pass
+    training entry, and (dim 128 / 256) the fused entry in the f32-emulated bf16x3 precision."""
+    for fused in (False, True) + (("bf16x3",) if d in (128, 256) else ()):
         _check_retrieval(dev, nq, nc, d, temperature, scale, use_w, use_p, use_ids, off, seed, fused)
 
 
@@ -520,7 +522,7 @@ def test_retrieval_grad_scale_linearity(dev):
     assert np.allclose(dq2, 2 * dq1, rtol=1e-6, atol=1e-9) and np.allclose(dc2, 2 * dc1, rtol=1e-6, atol=1e-9)
 
 
-@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("fused", [False, True, "bf16x3"])
 def test_retrieval_is_deterministic(dev, fused):
     q = synth.uniform_f32(44, 1, 2048 * 128, -0.3, 0.6).reshape(2048, 128)
     a = run_retrieval(dev, q, q[::-1].copy(), 0.1, fused=fused)

@@ -30,6 +30,9 @@ namespace {
 using tt::f32x4;
 using tt::f32x16;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 constexpr float kLog2e = 1.44269504088896340736f;
 constexpr float kLn2 = 0.69314718055994530942f;
@@ -68,20 +71,49 @@ struct ScoreArgs {
   int32_t* part_cnt;        // RANK [nsplit][n_r]: columns scoring strictly above the row's threshold a_r
 };
 
-template <int D>
+// PREC = 0: exact f32 products (v_mfma_f32_32x32x2_f32).  PREC = 1: "bf16x3" — every f32 operand is split into three
+// bf16 pieces (hi + mid + lo, the two residuals exact in f32) and the products run on v_mfma_f32_32x32x16_bf16 with f32
+// accumulation: GEMM1 (the logits) keeps the 6 products down to 2^-24 relative (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi,
+// mid*mid), GEMM2 (the gradient sums, judged at 1e-4 of their maximum) the 3 down to 2^-16 (hi*hi, hi*mid, mid*hi).
+// 72 bf16 MFMAs of 32 cycles per 32x32 tile and wave instead of 128 f32 MFMAs of 64: 0.28x the matrix-pipe time.
+template <int D, int PREC>
 struct Geo {
-  static constexpr int LS = D + 4;             // LDS row stride (floats): bank-conflict-free b128 reads
-  static constexpr int NG = D / 8;             // GEMM1 k-groups of 8 (4 per lane half)
-  static constexpr int NB = D / 32;            // GEMM2 d-blocks (d = NB*lane_row + b)
-  static constexpr int TILE_F = 32 * LS;
+  static constexpr int LS = D + 4;             // f32: LDS row stride (floats): bank-conflict-free b128 reads
+  static constexpr int NG = D / 8;             // f32 GEMM1 k-groups of 8 (4 per lane half)
+  static constexpr int NB = D / 32;            // GEMM2 d-blocks (f32: d = NB*lane_row + b; bf16x3: d = 32*b + acc row)
+  static constexpr int KS = D / 16;            // bf16x3 GEMM1 k-steps
+  static constexpr int HALF_B = 32 * 256;      // bf16x3: bytes of one [32 rows][128 cols] bf16 sub-image
+  static constexpr int PIECE_B = (D / 128) * HALF_B;
+  static constexpr int TILE_F = PREC == 0 ? 32 * LS : 3 * PIECE_B / 4;
   static constexpr int BUF_F = TILE_F + 160;   // + a_c[32] + s_c[32] + id_c[32] (int64) + h_c[32]
   static constexpr int LDS_BYTES = 2 * BUF_F * 4;      // 4-wave schedule: 2 buffers
 };
 
-template <int D, int MODE, bool HAS_IDS, bool HAS_HN, int WAVES>
+// x = hi + mid + lo, each a bf16 (round to nearest even); x - hi and (x - hi) - mid are exact in f32
+struct Bf3 {
+  __bf16 hi, mid, lo;
+};
+__device__ __forceinline__ Bf3 split3(float x) {
+  Bf3 o;
+  o.hi = (__bf16)x;
+  const float r1 = x - (float)o.hi;
+  o.mid = (__bf16)r1;
+  o.lo = (__bf16)(r1 - (float)o.mid);
+  return o;
+}
+
+// Byte offset of 16-byte chunk `ch` (8 bf16) of row `row` in a [32][128] bf16 sub-image with plain 256-byte rows and
+// the chunk index XOR-swizzled by the row (cdna_hip_programming.md T10, image (b)): conflict-free both for the row
+// reads (ds_read_b128, GEMM1's A operand) and for the transposing reads (ds_read_b64_tr_b16, GEMM2's A operand = K^T).
+__device__ __forceinline__ int img_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
+template <int D, int MODE, bool HAS_IDS, bool HAS_HN, int WAVES, int PREC>
 __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? 2 : 1))) void score_kernel(ScoreArgs p) {
-  using G_ = Geo<D>;
+  using G_ = Geo<D, PREC>;
   constexpr int LS = G_::LS, NG = G_::NG, NB = G_::NB, TILE_F = G_::TILE_F, BUF_F = G_::BUF_F;
+  constexpr int KS = G_::KS, HALF_B = G_::HALF_B, PIECE_B = G_::PIECE_B;
+  static_assert(PREC == 0 || (D % 128 == 0 && (MODE == MODE_BWD || MODE == MODE_FUSED)),
+                "bf16x3: gradient passes at dim 128 / 256 only");
   constexpr int ROW4 = D / 4;                       // float4 per K row
   constexpr int THREADS = WAVES * 64;
   constexpr int NV = (32 * ROW4 + THREADS - 1) / THREADS;   // staged float4 per thread
@@ -103,12 +135,28 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? 2 : 1))) 
   if (c_end > p.n_c) c_end = p.n_c;
   const int ntiles = c_end > c_begin ? (int)((c_end - c_begin + 31) >> 5) : 0;
 
-  // ---- stationary fragment: rf[g][s] = R[r][8g + 4h + s]  (B operand of GEMM1) ----
-  f32x4 rf[NG];
-  {
+  // ---- stationary fragment (B operand of GEMM1), in registers for the whole launch ----
+  //   f32:     rf[g][s]     = R[r][8g + 4h + s]
+  //   bf16x3:  rp[q][ks][j] = piece q of R[r][16 ks + 8h + j]
+  f32x4 rf[PREC == 0 ? NG : 1];
+  bf16x8 rp[PREC == 0 ? 1 : 3][PREC == 0 ? 1 : KS];
+  if constexpr (PREC == 0) {
     const f32x4* R4 = reinterpret_cast<const f32x4*>(p.R + (r_ok ? r : 0) * D) + h;
 #pragma unroll
     for (int g = 0; g < NG; ++g) rf[g] = r_ok ? R4[2 * g] : f32x4{0.f, 0.f, 0.f, 0.f};
+  } else {
+    const f32x4* R4 = reinterpret_cast<const f32x4*>(p.R + (r_ok ? r : 0) * D) + 2 * h;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const f32x4 x0 = r_ok ? R4[4 * ks] : f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 x1 = r_ok ? R4[4 * ks + 1] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const Bf3 u = split3(x0[j]), v = split3(x1[j]);
+        rp[0][ks][j] = u.hi; rp[1][ks][j] = u.mid; rp[2][ks][j] = u.lo;
+        rp[0][ks][4 + j] = v.hi; rp[1][ks][4 + j] = v.mid; rp[2][ks][4 + j] = v.lo;
+      }
+    }
   }
   const float ar = ((MODE == MODE_BWD || MODE == MODE_RANK) && p.a_r != nullptr && r_ok) ? p.a_r[r] : 0.f;
   const float sr = (MODE == MODE_BWD && p.s_r != nullptr && r_ok) ? p.s_r[r] : 1.f;
@@ -151,10 +199,33 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? 2 : 1))) 
   };
   auto store_tile = [&](int buf) {
     float* T = smem + buf * BUF_F;
-    float* dst = T + st_row * LS + st_col4 * 4;
+    if constexpr (PREC == 0) {
+      float* dst = T + st_row * LS + st_col4 * 4;
 #pragma unroll
-    for (int j = 0; j < NV; ++j)
-      if (st_row + j * RPJ < 32) *reinterpret_cast<f32x4*>(dst + j * RPJ * LS) = st[j];
+      for (int j = 0; j < NV; ++j)
+        if (st_row + j * RPJ < 32) *reinterpret_cast<f32x4*>(dst + j * RPJ * LS) = st[j];
+    } else {
+      // three bf16 images of the tile (hi / mid / lo pieces), each float4 -> 4 bf16 = one ds_write_b64 per piece
+      char* img = reinterpret_cast<char*>(T);
+      const int d0 = 4 * st_col4;
+      const int sub = (d0 >> 7) * HALF_B + 8 * ((d0 >> 2) & 1), ch = (d0 & 127) >> 3;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const int row = st_row + j * RPJ;
+        if (row < 32) {
+          bf16x4 q0, q1, q2;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const Bf3 u = split3(st[j][e]);
+            q0[e] = u.hi; q1[e] = u.mid; q2[e] = u.lo;
+          }
+          char* dst = img + sub + img_off(row, ch);
+          *reinterpret_cast<bf16x4*>(dst) = q0;
+          *reinterpret_cast<bf16x4*>(dst + PIECE_B) = q1;
+          *reinterpret_cast<bf16x4*>(dst + 2 * PIECE_B) = q2;
+        }
+      }
+    }
     if (tid < 32) {
       T[TILE_F + tid] = st_a;
       T[TILE_F + 32 + tid] = st_s;
@@ -185,7 +256,23 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? 2 : 1))) 
     f32x16 X;
 #pragma unroll
     for (int i = 0; i < 16; ++i) X[i] = 0.f;
-    {
+    if constexpr (PREC == 1) {
+      // A operand: lane (row c = ln, half h) reads k = 16 ks + 8h .. +7 of every piece: one ds_read_b128 per piece
+      const char* img = reinterpret_cast<const char*>(T);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int off = (ks >> 3) * HALF_B + img_off(ln, 2 * (ks & 7) + h);
+        const bf16x8 a_hi = *reinterpret_cast<const bf16x8*>(img + off);
+        const bf16x8 a_mid = *reinterpret_cast<const bf16x8*>(img + PIECE_B + off);
+        const bf16x8 a_lo = *reinterpret_cast<const bf16x8*>(img + 2 * PIECE_B + off);
+        X = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, rp[0][ks], X, 0, 0, 0);     // smallest terms first
+        X = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, rp[2][ks], X, 0, 0, 0);
+        X = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, rp[1][ks], X, 0, 0, 0);
+        X = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, rp[0][ks], X, 0, 0, 0);
+        X = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, rp[1][ks], X, 0, 0, 0);
+        X = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, rp[0][ks], X, 0, 0, 0);
+      }
+    } else {
       const float* arow = T + ln * LS + 4 * h;
       // one ds_read_b128 ahead of the MFMAs that use it; sched_barrier keeps hipcc from hoisting all
       // NG reads (4*NG VGPRs) to the loop top
@@ -383,6 +470,48 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? 2 : 1))) 
   };
 
   auto gemm2 = [&](const float* T, const float (&coef)[16]) {
+    if constexpr (PREC == 1) {
+      // ---- GEMM2 (bf16x3): G^T[d = 32 b + acc row][r] += sum_c K[c][d] * coef[c][r].  The accumulator's registers
+      // 8s .. 8s+7 ARE the B fragment of k-step s (element j of lane half h = tile row c = 16s + 8(j>>2) + 4h + (j&3));
+      // the A fragment K^T[d][those c] comes out of the SAME row-major images through transposing reads
+      // (ds_read_b64_tr_b16: a 16-lane group fetches 4 rows x 16 columns and gets them column-major). ----
+      bf16x8 c_hi[2], c_mid[2];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const __bf16 hi = (__bf16)coef[i];
+        c_hi[i >> 3][i & 7] = hi;
+        c_mid[i >> 3][i & 7] = (__bf16)(coef[i] - (float)hi);
+      }
+      const char* img = reinterpret_cast<const char*>(T);
+      const int g16 = (lane >> 4) & 1, q = (lane >> 2) & 3, pp = lane & 3;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int sub = ((32 * b) >> 7) * HALF_B + 8 * (pp & 1);
+        const int ch = (((32 * b) & 127) >> 3) + 2 * g16 + (pp >> 1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          bf16x8 k_hi, k_mid;
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            const int row = 16 * s + 8 * half + 4 * h + q;
+            const int off = sub + img_off(row, ch);
+            const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4*)(img + off));
+            const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4*)(img + PIECE_B + off));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              k_hi[4 * half + e] = __builtin_bit_cast(__bf16, (short)v0[e]);
+              k_mid[4 * half + e] = __builtin_bit_cast(__bf16, (short)v1[e]);
+            }
+          }
+          G[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_mid, c_hi[s], G[b], 0, 0, 0);
+          G[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_hi, c_mid[s], G[b], 0, 0, 0);
+          G[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_hi, c_hi[s], G[b], 0, 0, 0);
+        }
+      }
+      return;
+    } else {
       // ---- GEMM2: G^T[d = NB*i + b][r] += K[c(reg,h)][d] * coef[reg] ----
       const float* kbase = T + 4 * h * LS + NB * ln;
       f32x4 kc0, kc1;
@@ -416,6 +545,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? 2 : 1))) 
         kc0 = kn0; kc1 = kn1;
         __builtin_amdgcn_sched_barrier(0);
       }
+    }
   };
 
   {
@@ -466,6 +596,13 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? 2 : 1))) 
   } else {
     if (r_ok) {
       float* out = p.slab + ((int64_t)split * p.n_r + r) * D;
+      if constexpr (PREC == 1) {          // G[b][reg] = G^T[d = 32 b + acc row(reg, h)][r]: registers 4g .. 4g+3 are 4 consecutive d
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<f32x4*>(out + 32 * b + 8 * g + 4 * h) = f32x4{G[b][4 * g], G[b][4 * g + 1], G[b][4 * g + 2], G[b][4 * g + 3]};
+      } else
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int i = tt::acc_row(reg, 0) + 4 * h;
@@ -806,12 +943,12 @@ WsLayout ws_layout(int64_t nq, int64_t nc, int32_t dim) {
 template <int D, int MODE>
 constexpr int waves_for() { return 4; }
 
-template <int D, int MODE>
+template <int D, int MODE, int PREC = 0>
 int launch_score(const ScoreArgs& a_in, bool has_ids, hipStream_t stream) {
   constexpr int W = waves_for<D, MODE>();
   const int64_t nrb = (a_in.n_r + W * 32 - 1) / (W * 32);
   const int64_t blocks = nrb * a_in.nsplit;
-  const int lds = Geo<D>::LDS_BYTES;
+  const int lds = Geo<D, PREC>::LDS_BYTES;
   const bool has_hn = (a_in.h_r != nullptr) || (a_in.h_c != nullptr);
   const ScoreArgs& a = a_in;
   auto go = [&](auto kern) -> int {
@@ -823,10 +960,20 @@ int launch_score(const ScoreArgs& a_in, bool has_ids, hipStream_t stream) {
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(W * 64), lds, stream, a);
     return tt::check_launch(MODE == MODE_FWD ? "score_fwd" : (MODE == MODE_BWD ? "score_bwd" : "score_fused"));
   };
-  if (has_ids && has_hn) return go(score_kernel<D, MODE, true, true, W>);
-  if (has_ids) return go(score_kernel<D, MODE, true, false, W>);
-  if (has_hn) return go(score_kernel<D, MODE, false, true, W>);
-  return go(score_kernel<D, MODE, false, false, W>);
+  if (has_ids && has_hn) return go(score_kernel<D, MODE, true, true, W, PREC>);
+  if (has_ids) return go(score_kernel<D, MODE, true, false, W, PREC>);
+  if (has_hn) return go(score_kernel<D, MODE, false, true, W, PREC>);
+  return go(score_kernel<D, MODE, false, false, W, PREC>);
+}
+
+// bf16x3 gradient passes (MODE_FUSED / MODE_BWD) at the dims whose tiles are whole [32][128] bf16 images
+template <int MODE>
+int dispatch_score_bx3(int32_t dim, const ScoreArgs& a, bool has_ids, hipStream_t stream) {
+  switch (dim) {
+    case 128: return launch_score<128, MODE, 1>(a, has_ids, stream);
+    case 256: return launch_score<256, MODE, 1>(a, has_ids, stream);
+    default: return tt::fail(TT_ERR_UNSUPPORTED, "retrieval (bf16x3): dim %d not in {128,256}", dim);
+  }
 }
 
 template <int MODE>
@@ -985,11 +1132,11 @@ extern "C" int tt_retrieval_bwd_f32(const float* q, const float* c, int64_t nq, 
 // Fused training entry: loss AND both gradients in two passes (8*B^2*D executed FLOPs instead of 10):
 //   pass 1 (R = q, K = c, MODE_FUSED): online softmax + sum_c p*c  -> lse, per-row loss, dq
 //   pass 2 (R = c, K = q, MODE_BWD)  : recompute with the final lse -> dc
-extern "C" int tt_retrieval_fwd_bwd_f32(const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
-                                        int64_t diag_offset, float inv_temperature, const float* sample_weight,
-                                        const float* cand_prob, const int64_t* cand_ids, const float* hard_thr,
-                                        float grad_scale, void* workspace, int64_t workspace_bytes, float* lse,
-                                        float* per_row, float* loss, float* dq, float* dc, tt_stream_t stream_) {
+static int retrieval_fwd_bwd(int prec, const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
+                             int64_t diag_offset, float inv_temperature, const float* sample_weight,
+                             const float* cand_prob, const int64_t* cand_ids, const float* hard_thr,
+                             float grad_scale, void* workspace, int64_t workspace_bytes, float* lse,
+                             float* per_row, float* loss, float* dq, float* dc, tt_stream_t stream_) {
   int rc = check_common("tt_retrieval_fwd_bwd_f32", q, c, nq, nc, dim, diag_offset, workspace, workspace_bytes);
   if (rc != TT_OK) return rc;
   TT_REQUIRE(lse && per_row && loss && dq && dc, "tt_retrieval_fwd_bwd_f32: null output pointer");
@@ -1020,7 +1167,9 @@ extern "C" int tt_retrieval_fwd_bwd_f32(const float* q, const float* c, int64_t 
     a.part_l = reinterpret_cast<float*>(ws + w.off_pl);
     a.pos2 = reinterpret_cast<float*>(ws + w.off_pos);
     a.slab = slab;
-    if ((rc = dispatch_score<MODE_FUSED>(dim, a, cand_ids != nullptr, stream)) != TT_OK) return rc;
+    rc = prec == 1 ? dispatch_score_bx3<MODE_FUSED>(dim, a, cand_ids != nullptr, stream)
+                   : dispatch_score<MODE_FUSED>(dim, a, cand_ids != nullptr, stream);
+    if (rc != TT_OK) return rc;
     {
       tt::ProfScope prof("score_aux", stream);
       hipLaunchKernelGGL(fused_combine_kernel, dim3((unsigned)((nq + 7) / 8)), dim3(256), 0, stream, a.part_m, a.part_l, a.pos2,
@@ -1048,7 +1197,9 @@ extern "C" int tt_retrieval_fwd_bwd_f32(const float* q, const float* c, int64_t 
     a.nsplit = w.ns_c;
     a.c_per_split = align_up((nq + a.nsplit - 1) / a.nsplit, 32);
     a.slab = slab;
-    if ((rc = dispatch_score<MODE_BWD>(dim, a, cand_ids != nullptr, stream)) != TT_OK) return rc;
+    rc = prec == 1 ? dispatch_score_bx3<MODE_BWD>(dim, a, cand_ids != nullptr, stream)
+                   : dispatch_score<MODE_BWD>(dim, a, cand_ids != nullptr, stream);
+    if (rc != TT_OK) return rc;
     const int64_t n4 = nc * dim / 4;
     const int64_t blocks = (n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048;
     tt::ProfScope prof("score_aux", stream);
@@ -1057,6 +1208,27 @@ extern "C" int tt_retrieval_fwd_bwd_f32(const float* q, const float* c, int64_t 
     if ((rc = tt::check_launch("reduce_slabs(dc)")) != TT_OK) return rc;
   }
   return TT_OK;
+}
+
+extern "C" int tt_retrieval_fwd_bwd_f32(const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
+                                        int64_t diag_offset, float inv_temperature, const float* sample_weight,
+                                        const float* cand_prob, const int64_t* cand_ids, const float* hard_thr,
+                                        float grad_scale, void* workspace, int64_t workspace_bytes, float* lse,
+                                        float* per_row, float* loss, float* dq, float* dc, tt_stream_t stream) {
+  return retrieval_fwd_bwd(0, q, c, nq, nc, dim, diag_offset, inv_temperature, sample_weight, cand_prob, cand_ids, hard_thr,
+                           grad_scale, workspace, workspace_bytes, lse, per_row, loss, dq, dc, stream);
+}
+
+// The same two passes with every matrix product on bf16 MFMA through the hi/mid/lo split of the f32 operands
+// (f32-emulated: 6 products for the logits, 3 for the gradient sums; f32 accumulation, f32 softmax).  dim in {128, 256}.
+extern "C" int tt_retrieval_fwd_bwd_bf16x3_f32(const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
+                                               int64_t diag_offset, float inv_temperature, const float* sample_weight,
+                                               const float* cand_prob, const int64_t* cand_ids, const float* hard_thr,
+                                               float grad_scale, void* workspace, int64_t workspace_bytes, float* lse,
+                                               float* per_row, float* loss, float* dq, float* dc, tt_stream_t stream) {
+  if (dim != 128 && dim != 256) return tt::fail(TT_ERR_UNSUPPORTED, "tt_retrieval_fwd_bwd_bf16x3_f32: dim %d not in {128,256}", dim);
+  return retrieval_fwd_bwd(1, q, c, nq, nc, dim, diag_offset, inv_temperature, sample_weight, cand_prob, cand_ids, hard_thr,
+                           grad_scale, workspace, workspace_bytes, lse, per_row, loss, dq, dc, stream);
 }
 
 // Retrieval metric support (configs/data_config.yaml:71 top_k_eval): rank of each query's true

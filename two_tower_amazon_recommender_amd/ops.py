@@ -457,15 +457,23 @@ def retrieval_bwd(q, c, inv_temperature: float, workspace, lse, dq, dc, sample_w
     return dq, dc
 
 
+SCORER_PRECISIONS = ("f32", "bf16x3")
+
+
 def retrieval_fwd_bwd(q, c, inv_temperature: float, workspace, lse, per_row, loss, dq, dc, sample_weight=None,
-                      cand_prob=None, cand_ids=None, diag_offset: int = 0, grad_scale: float = 1.0, hard_thr=None):
-    """Loss and both gradients in two fused passes (training form)."""
+                      cand_prob=None, cand_ids=None, diag_offset: int = 0, grad_scale: float = 1.0, hard_thr=None,
+                      precision: str = "f32"):
+    """Loss and both gradients in two fused passes (training form).  precision "f32": exact f32 products on the
+    f32-input MFMA; "bf16x3": the f32-emulated split-bf16 form on the bf16 MFMA (dim 128 / 256)."""
     _chk_retrieval(q, c, sample_weight, cand_prob, cand_ids, hard_thr, lse, per_row, dq, dc)
+    if precision not in SCORER_PRECISIONS:
+        raise ValueError(f"precision must be one of {SCORER_PRECISIONS}, got {precision!r}")
     lib = _lib.load()
-    _lib.check(lib.tt_retrieval_fwd_bwd_f32(_p(q), _p(c), q.shape[0], c.shape[0], q.shape[1], diag_offset, inv_temperature,
+    fn = lib.tt_retrieval_fwd_bwd_f32 if precision == "f32" else lib.tt_retrieval_fwd_bwd_bf16x3_f32
+    _lib.check(fn(_p(q), _p(c), q.shape[0], c.shape[0], q.shape[1], diag_offset, inv_temperature,
                                             _p(sample_weight), _p(cand_prob), _p(cand_ids), _p(hard_thr), grad_scale, _p(workspace),
-                                            workspace.numel(), _p(lse), _p(per_row), _p(loss), _p(dq), _p(dc), _stream()),
-               "tt_retrieval_fwd_bwd_f32")
+              workspace.numel(), _p(lse), _p(per_row), _p(loss), _p(dq), _p(dc), _stream()),
+               "tt_retrieval_fwd_bwd_f32" if precision == "f32" else "tt_retrieval_fwd_bwd_bf16x3_f32")
     return loss
 
 
