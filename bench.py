@@ -221,6 +221,29 @@ def main():
         f_l0 = mean(prof["dense_fwd"][0::n_layers]) - mean(unfused["dense_fwd"][0::n_layers])
         b_l0 = mean(prof["dense_bwd"][n_layers - 1::n_layers]) - mean(unfused["dense_bwd"][n_layers - 1::n_layers])
         lookup_us = (f_l0 + b_l0) * 1e3
+    # ---- second, separately labelled measurement: the same train step with the scorer's matrix products in the
+    # f32-EMULATED bf16x3 precision (three-way bf16 split on the bf16 MFMA; same 1e-4 parity bars).  Never the headline:
+    # `value` / `roofline` above are the exact-f32 run.
+    alt = None
+    sd = tower_dims[-1]
+    if sd in (128, 256) and not args.graph:
+        cfg.scorer_precision = "bf16x3"
+        alt_steps = min(args.steps, 100)
+        for s in range(min(args.warmup, 10)):
+            step(s)
+        torch.cuda.synchronize()
+        _lib.profile_set_stride(4 if alt_steps >= 40 else 1)
+        _lib.profile_enable("score_fused,score_bwd", capacity=2 * alt_steps + 8)
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        for s in range(total - alt_steps, total):
+            step(s)
+        torch.cuda.synchronize()
+        dta = time.perf_counter() - ta
+        af, ab = _lib.profile_read("score_fused", 2 * alt_steps + 8)[0], _lib.profile_read("score_bwd", 2 * alt_steps + 8)[0]
+        _lib.profile_set_stride(1)
+        cfg.scorer_precision = "f32"
+        alt = (alt_steps, dta, mean(af) * 1e-3, mean(ab) * 1e-3, float(trainer.loss.item()))
     _lib.profile_enable("")
     steps_of = {t: (args.steps if t in timed_tags.split(",") else detail_steps) for t in all_tags}
     loss = float(trainer.loss.item())
@@ -297,6 +320,22 @@ def main():
                          "algorithmic_bytes": gs_bytes},
         "loss_per_pair": loss / batch,
     }
+    if alt is not None:
+        alt_steps, dta, tf_, tb_, aloss = alt
+        # per launch of the FUSED pass: GEMM1 = 2*B^2*D algorithmic FLOPs at 6 bf16 products each, GEMM2 = 2*B^2*D at 3
+        peak_equiv = 2500.0 * 4.0 / 18.0
+        a_alg = 4.0 * b2d / tf_ / 1e12
+        out["roofline_alt"] = {
+            "bound": "mfma", "dtype": "bf16x3 (f32-emulated: x = hi + mid + lo bf16 pieces, f32 accumulate, f32 softmax)",
+            "kernel": f"score_kernel<{sd},FUSED,bf16x3> (loss + dq pass on v_mfma_f32_32x32x16_bf16; algorithmic 4*B^2*D, "
+                      "executed 18*B^2*D bf16 FLOPs: 6 products per logit term, 3 per gradient term)",
+            "achieved": a_alg, "peak": peak_equiv, "unit": "TFLOP/s (f32-equivalent)", "frac": a_alg / peak_equiv,
+            "peak_note": "2500 TFLOP/s dense bf16 MFMA x 4/18 (algorithmic / executed products)",
+            "executed_bf16_tflops": 18.0 * b2d / tf_ / 1e12, "executed_frac_of_bf16_peak": 18.0 * b2d / tf_ / 1e12 / 2500.0,
+            "avg_launch_us": tf_ * 1e6, "other_pass_avg_launch_us": tb_ * 1e6, "traffic": None,
+            "value_alt": batch / (dta / alt_steps), "unit_alt": "pairs/s", "ms_per_step_alt": dta / alt_steps * 1e3,
+            "steps_alt": alt_steps, "loss_per_pair_alt": aloss / batch,
+            "note": "whole train step with scorer_precision='bf16x3'; NOT the headline (value / roofline are exact f32)"}
     if not args.no_cpu_baseline and not cfg.n_category_buckets:     # the torch-CPU port covers the cfg1-cfg4 model
         out["cpu_baseline"] = cpu_baseline(trainer, cfg, seed, args, batch)
     print(json.dumps(out))

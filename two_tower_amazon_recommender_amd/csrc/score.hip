@@ -39,6 +39,18 @@ constexpr float kLn2 = 0.69314718055994530942f;
 constexpr float kNegBig = -1.0e30f;   // log2-domain stand-in for -inf (tfrs uses finfo.min/100)
 
 enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2, MODE_RANK = 3 };
+#ifndef TT_BX3_ABL
+#define TT_BX3_ABL 0          // timing-only ablation hooks of the bf16x3 kernel (wrong results when non-zero; scratch/abl_bx3.sh)
+#endif
+#ifndef TT_BX3_STAGGER
+// bf16x3, 8 waves: 1 = barrier between GEMM1 and the epilogue + 3-buffer LDS ring (see the tile loop), so that the two waves
+// of a SIMD may drift apart.  r02 measurements at B = 8192, D = 128 (FUSED / BWD pass, us): lock-step (0) 147 / 151;
+// this form 163 / 160; a first form (waves 4-7 run GEMM2 one tile late, coefficients kept across the barrier) 164 / 175 with
+// 24 spilled VGPRs.  The ablation says why lock-step still wins: GEMM1 (69 us) and GEMM2 (39 us) already run at the
+// bf16 matrix pipe's pace at the clock it holds (~1.6 GHz), and what is left (~60 us) is the epilogue + staging VALU,
+// which neither form managed to slide under the partner wave's MFMAs at a 256-VGPR budget.
+#define TT_BX3_STAGGER 0
+#endif
 #ifndef TT_PK_EPILOGUE
 // 1: v_pk_fma_f32 / v_pk_add_f32 pairs in the softmax epilogue; 0: scalar f32 ops.  A/B on one box, alternating runs
 // (profiles/r02_ab_epilogue_pk_vs_scalar.txt): FUSED 273.1 vs 272.4 us, BWD 271.3 vs 271.7 us, step 0.7024 vs 0.7019 ms —
@@ -138,24 +150,34 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? 2 : 1))) 
   // ---- stationary fragment (B operand of GEMM1), in registers for the whole launch ----
   //   f32:     rf[g][s]     = R[r][8g + 4h + s]
   //   bf16x3:  rp[q][ks][j] = piece q of R[r][16 ks + 8h + j]
+  // (bf16x3 with 8-wave workgroups: the lo piece — one product per k-step — lives in LDS, [ks][lane] x 16 B per wave,
+  // written once: 32 VGPRs less, which is what keeps the gradient kernels free of scratch spills)
+  constexpr bool RLO_LDS = PREC == 1 && WAVES == 8;
+  constexpr bool STAG = PREC == 1 && WAVES == 8 && TT_BX3_STAGGER;     // staggered wave halves + 3-buffer LDS ring (see the tile loop)
+  constexpr int NBUF = STAG ? 3 : 2;
   f32x4 rf[PREC == 0 ? NG : 1];
-  bf16x8 rp[PREC == 0 ? 1 : 3][PREC == 0 ? 1 : KS];
+  bf16x8 rp[PREC == 0 ? 1 : (RLO_LDS ? 2 : 3)][PREC == 0 ? 1 : KS];
+  bf16x8* rlo = reinterpret_cast<bf16x8*>(smem + NBUF * BUF_F) + (wave * KS) * 64 + lane;
   if constexpr (PREC == 0) {
     const f32x4* R4 = reinterpret_cast<const f32x4*>(p.R + (r_ok ? r : 0) * D) + h;
 #pragma unroll
     for (int g = 0; g < NG; ++g) rf[g] = r_ok ? R4[2 * g] : f32x4{0.f, 0.f, 0.f, 0.f};
   } else {
     const f32x4* R4 = reinterpret_cast<const f32x4*>(p.R + (r_ok ? r : 0) * D) + 2 * h;
+    const float live = r_ok ? 1.f : 0.f;            // rows past n_r read row 0 and are zeroed (all loads unconditional)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const f32x4 x0 = r_ok ? R4[4 * ks] : f32x4{0.f, 0.f, 0.f, 0.f};
-      const f32x4 x1 = r_ok ? R4[4 * ks + 1] : f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 x0 = R4[4 * ks] * live;
+      const f32x4 x1 = R4[4 * ks + 1] * live;
+      bf16x8 lo8;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const Bf3 u = split3(x0[j]), v = split3(x1[j]);
-        rp[0][ks][j] = u.hi; rp[1][ks][j] = u.mid; rp[2][ks][j] = u.lo;
-        rp[0][ks][4 + j] = v.hi; rp[1][ks][4 + j] = v.mid; rp[2][ks][4 + j] = v.lo;
+        rp[0][ks][j] = u.hi; rp[1][ks][j] = u.mid; lo8[j] = u.lo;
+        rp[0][ks][4 + j] = v.hi; rp[1][ks][4 + j] = v.mid; lo8[4 + j] = v.lo;
       }
+      if constexpr (RLO_LDS) rlo[ks * 64] = lo8;        // read back by this lane only: no barrier needed
+      else rp[2][ks] = lo8;
     }
   }
   const float ar = ((MODE == MODE_BWD || MODE == MODE_RANK) && p.a_r != nullptr && r_ok) ? p.a_r[r] : 0.f;
@@ -216,6 +238,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? 2 : 1))) 
           bf16x4 q0, q1, q2;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
+            if constexpr (TT_BX3_ABL & 1) { q0[e] = (__bf16)st[j][e]; q1[e] = q0[e]; q2[e] = q0[e]; continue; }
             const Bf3 u = split3(st[j][e]);
             q0[e] = u.hi; q1[e] = u.mid; q2[e] = u.lo;
           }
@@ -257,20 +280,33 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? 2 : 1))) 
 #pragma unroll
     for (int i = 0; i < 16; ++i) X[i] = 0.f;
     if constexpr (PREC == 1) {
-      // A operand: lane (row c = ln, half h) reads k = 16 ks + 8h .. +7 of every piece: one ds_read_b128 per piece
+      // A operand: lane (row c = ln, half h) reads k = 16 ks + 8h .. +7 of every piece: one ds_read_b128 per piece.
+      // Software-pipelined by hand: the three fragments of k-step ks+1 are in flight under the six MFMAs of k-step ks
+      // (left to the compiler the MFMAs sat behind each read's LDS latency: 2.3x the pure MFMA time, r02 ablation).
       const char* img = reinterpret_cast<const char*>(T);
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
+      constexpr int KSN = (TT_BX3_ABL & 2) ? 1 : KS;
+      auto frag = [&](int ks, bf16x8& f_hi, bf16x8& f_mid, bf16x8& f_lo, bf16x8& r_lo) {
         const int off = (ks >> 3) * HALF_B + img_off(ln, 2 * (ks & 7) + h);
-        const bf16x8 a_hi = *reinterpret_cast<const bf16x8*>(img + off);
-        const bf16x8 a_mid = *reinterpret_cast<const bf16x8*>(img + PIECE_B + off);
-        const bf16x8 a_lo = *reinterpret_cast<const bf16x8*>(img + 2 * PIECE_B + off);
+        f_hi = *reinterpret_cast<const bf16x8*>(img + off);
+        f_mid = *reinterpret_cast<const bf16x8*>(img + PIECE_B + off);
+        f_lo = *reinterpret_cast<const bf16x8*>(img + 2 * PIECE_B + off);
+        if constexpr (RLO_LDS) r_lo = rlo[ks * 64];
+      };
+      bf16x8 a_hi, a_mid, a_lo, b_lo = {};
+      frag(0, a_hi, a_mid, a_lo, b_lo);
+#pragma unroll
+      for (int ks = 0; ks < KSN; ++ks) {
+        bf16x8 n_hi = a_hi, n_mid = a_mid, n_lo = a_lo, nb_lo = b_lo;
+        if (ks + 1 < KSN) frag(ks + 1, n_hi, n_mid, n_lo, nb_lo);
+        if constexpr (!RLO_LDS) b_lo = rp[2][ks];
         X = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, rp[0][ks], X, 0, 0, 0);     // smallest terms first
-        X = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, rp[2][ks], X, 0, 0, 0);
+        X = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, X, 0, 0, 0);
         X = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, rp[1][ks], X, 0, 0, 0);
         X = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, rp[0][ks], X, 0, 0, 0);
         X = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, rp[1][ks], X, 0, 0, 0);
         X = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, rp[0][ks], X, 0, 0, 0);
+        a_hi = n_hi; a_mid = n_mid; a_lo = n_lo; b_lo = nb_lo;
+        __builtin_amdgcn_sched_barrier(0);
       }
     } else {
       const float* arow = T + ln * LS + 4 * h;
@@ -480,35 +516,41 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? 2 : 1))) 
       for (int i = 0; i < 16; ++i) {
         const __bf16 hi = (__bf16)coef[i];
         c_hi[i >> 3][i & 7] = hi;
-        c_mid[i >> 3][i & 7] = (__bf16)(coef[i] - (float)hi);
+        c_mid[i >> 3][i & 7] = (TT_BX3_ABL & 8) ? hi : (__bf16)(coef[i] - (float)hi);
       }
       const char* img = reinterpret_cast<const char*>(T);
       const int g16 = (lane >> 4) & 1, q = (lane >> 2) & 3, pp = lane & 3;
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
+      // flat step i = 2 b + s; the four transposing reads of step i+1 are in flight under the three MFMAs of step i
+      constexpr int NSTEP = 2 * ((TT_BX3_ABL & 4) ? 1 : NB);
+      auto frag = [&](int i, bf16x8& k_hi, bf16x8& k_mid) {
+        const int b = i >> 1, s = i & 1;
         const int sub = ((32 * b) >> 7) * HALF_B + 8 * (pp & 1);
         const int ch = (((32 * b) & 127) >> 3) + 2 * g16 + (pp >> 1);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          bf16x8 k_hi, k_mid;
+        for (int half = 0; half < 2; ++half) {
+          const int row = 16 * s + 8 * half + 4 * h + q;
+          const int off = sub + img_off(row, ch);
+          const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + off));
+          const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + PIECE_B + off));
 #pragma unroll
-          for (int half = 0; half < 2; ++half) {
-            const int row = 16 * s + 8 * half + 4 * h + q;
-            const int off = sub + img_off(row, ch);
-            const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) s16x4*)(img + off));
-            const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) s16x4*)(img + PIECE_B + off));
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              k_hi[4 * half + e] = __builtin_bit_cast(__bf16, (short)v0[e]);
-              k_mid[4 * half + e] = __builtin_bit_cast(__bf16, (short)v1[e]);
-            }
+          for (int e = 0; e < 4; ++e) {
+            k_hi[4 * half + e] = __builtin_bit_cast(__bf16, (short)v0[e]);
+            k_mid[4 * half + e] = __builtin_bit_cast(__bf16, (short)v1[e]);
           }
-          G[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_mid, c_hi[s], G[b], 0, 0, 0);
-          G[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_hi, c_mid[s], G[b], 0, 0, 0);
-          G[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_hi, c_hi[s], G[b], 0, 0, 0);
         }
+      };
+      bf16x8 k_hi, k_mid;
+      frag(0, k_hi, k_mid);
+#pragma unroll
+      for (int i = 0; i < NSTEP; ++i) {
+        bf16x8 n_hi = k_hi, n_mid = k_mid;
+        if (i + 1 < NSTEP) frag(i + 1, n_hi, n_mid);
+        const int b = i >> 1, s = i & 1;
+        G[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_mid, c_hi[s], G[b], 0, 0, 0);
+        G[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_hi, c_mid[s], G[b], 0, 0, 0);
+        G[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_hi, c_hi[s], G[b], 0, 0, 0);
+        k_hi = n_hi; k_mid = n_mid;
+        __builtin_amdgcn_sched_barrier(0);
       }
       return;
     } else {
@@ -548,18 +590,38 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? 2 : 1))) 
     }
   };
 
-  {
+  if constexpr (STAG) {
+    // ---- bf16x3, 8 waves: ONE barrier per tile, placed between [GEMM1(t), LDS store of tile t+1] and [epilogue(t),
+    // GEMM2(t)], with a 3-buffer ring.  A wave that passes barrier t knows tile t+1 is complete, so after its GEMM2(t) it
+    // runs straight into GEMM1(t+1); it only waits at barrier t+1 for the others to finish iteration t.  The two waves of
+    // a SIMD therefore drift up to an epilogue + GEMM2 apart: one wave's softmax VALU runs under the other's MFMAs instead
+    // of both sitting in the same phase (bf16 MFMAs leave 3/4 of the SIMD's issue slots free; MI355X_MICROARCH.md "Two
+    // waves per SIMD").  Buffer t is overwritten by the store of iteration t+2, which is behind barrier t+1, i.e. after
+    // every wave has finished GEMM2(t).  Same code and same arithmetic order for every wave. ----
+    if (ntiles > 1) load_tile(1);
+    for (int t = 0; t < ntiles; ++t) {
+      const float* T = smem + (t % 3) * BUF_F;
+      const f32x16 X = gemm1(T);
+      if (t + 1 < ntiles) store_tile((t + 1) % 3);
+      if (t + 2 < ntiles) load_tile(t + 2);
+      __syncthreads();
+      float coef[16];
+      epilogue(T, t, X, coef);
+      gemm2(T, coef);
+    }
+  } else {
     // ---- every wave runs GEMM1 -> epilogue -> GEMM2 per tile; 2 LDS buffers, one barrier per tile ----
     for (int t = 0; t < ntiles; ++t) {
       // FWD/RANK: prefetch the next tile at the top.  BWD/FUSED: registers are tight (rf + G + X + coef), so the
       // prefetch is issued just before GEMM2, whose 16*NB MFMAs (>= 1.7 us at D=128) cover its latency.
-      if constexpr (MODE == MODE_FWD || MODE == MODE_RANK) { if (t + 1 < ntiles) load_tile(t + 1); }
+      // bf16x3: a tile is ~1 us of MFMAs, less than a global round trip under load: the prefetch goes to the top too
+      if constexpr (MODE == MODE_FWD || MODE == MODE_RANK || PREC == 1) { if (t + 1 < ntiles) load_tile(t + 1); }
       const float* T = smem + (t & 1) * BUF_F;
       const f32x16 X = gemm1(T);
       float coef[16];
       epilogue(T, t, X, coef);
       if constexpr (MODE == MODE_BWD || MODE == MODE_FUSED) {
-        if (t + 1 < ntiles) load_tile(t + 1);
+        if constexpr (PREC == 0) { if (t + 1 < ntiles) load_tile(t + 1); }
         gemm2(T, coef);
       }
       if (t + 1 < ntiles) store_tile((t + 1) & 1);
@@ -940,15 +1002,17 @@ WsLayout ws_layout(int64_t nq, int64_t nc, int32_t dim) {
 // slab stores, drain) and ~20 us around the softmax epilogue that the partner wave's MFMAs do not hide (f32-input
 // MFMA runs at the f32 vector rate; a 25 % cut of the epilogue's VALU instructions changed nothing measurable, so the
 // cost is in the GEMM1 -> epilogue -> GEMM2 dependency hand-offs rather than in VALU throughput).
-template <int D, int MODE>
-constexpr int waves_for() { return 4; }
+template <int D, int MODE, int PREC = 0>
+constexpr int waves_for() { return (PREC == 1 && D == 128) ? 8 : 4; }     // bf16x3 at dim 128: 256-row workgroups, one per CU
 
 template <int D, int MODE, int PREC = 0>
 int launch_score(const ScoreArgs& a_in, bool has_ids, hipStream_t stream) {
-  constexpr int W = waves_for<D, MODE>();
+  constexpr int W = waves_for<D, MODE, PREC>();
   const int64_t nrb = (a_in.n_r + W * 32 - 1) / (W * 32);
   const int64_t blocks = nrb * a_in.nsplit;
-  const int lds = Geo<D, PREC>::LDS_BYTES;
+  // bf16x3 with 8 waves: a third tile buffer (staggered wave halves) + the R_lo fragments of the 8 waves
+  const int lds = Geo<D, PREC>::LDS_BYTES +
+                  ((PREC == 1 && W == 8) ? (TT_BX3_STAGGER ? Geo<D, PREC>::BUF_F * 4 : 0) + W * Geo<D, PREC>::KS * 64 * 16 : 0);
   const bool has_hn = (a_in.h_r != nullptr) || (a_in.h_c != nullptr);
   const ScoreArgs& a = a_in;
   auto go = [&](auto kern) -> int {

@@ -504,12 +504,13 @@ class ShardedTwoTowerTrainer:
         ci = self._cand_ids(candidate_ids)
         if self.negatives == "local" or not self.collectives:
             ops.retrieval_fwd_bwd(q, c, inv_t, self.ws, self.lse, self.per_row, self.loss, ut.dz[-1], it.dz[-1], cand_prob=cp,
-                                  sample_weight=sample_weight, cand_ids=ci)
+                                  sample_weight=sample_weight, cand_ids=ci, precision=cfg.scorer_precision)
         else:
             dist.all_gather_into_tensor(self.c_all, c, group=self.group)                       # C4
             off = self.rank * b
             ops.retrieval_fwd_bwd(q, self.c_all, inv_t, self.ws, self.lse, self.per_row, self.loss, ut.dz[-1], self.dc_all,
-                                  diag_offset=off, cand_prob=cp, sample_weight=sample_weight, cand_ids=ci)
+                                  diag_offset=off, cand_prob=cp, sample_weight=sample_weight, cand_ids=ci,
+                                  precision=cfg.scorer_precision)
             dist.reduce_scatter_tensor(it.dz[-1], self.dc_all, op=dist.ReduceOp.SUM, group=self.group)   # C5
 
         # every dx first: the embedding gradient rows travel to their owners beside the dw GEMMs and the dense reduce

@@ -31,7 +31,7 @@ class Retrieval:
     """A factorized retrieval task: in-batch softmax over query x candidate dot products."""
 
     def __init__(self, loss=None, metrics=None, batch_metrics=None, loss_metrics=None, temperature=None,
-                 num_hard_negatives=None, remove_accidental_hits=False, name="retrieval_task"):
+                 num_hard_negatives=None, remove_accidental_hits=False, name="retrieval_task", precision="f32"):
         if loss is not None:
             raise NotImplementedError("Retrieval(loss=...): only the TFRS default loss (categorical cross-entropy "
                                       "from logits, SUM reduction) is implemented in the HIP path")
@@ -55,6 +55,9 @@ class Retrieval:
         self._temperature = temperature
         self._num_hard_negatives = num_hard_negatives
         self._remove_accidental_hits = remove_accidental_hits
+        if precision not in ("f32", "bf16x3"):
+            raise ValueError("precision must be 'f32' or 'bf16x3'")
+        self._precision = precision          # (extension) matrix-product precision of the training passes: torch_ops.py
         self.name = name
         self.last_per_example_loss = None
 
@@ -77,7 +80,7 @@ class Retrieval:
         cp = None if candidate_sampling_probability is None else candidate_sampling_probability.to(torch.float32).contiguous()
         k = 0 if self._num_hard_negatives is None else int(self._num_hard_negatives)
         if torch.is_grad_enabled() and (q.requires_grad or c.requires_grad):
-            loss, per_example, _, _ = torch.ops.twotower.retrieval_loss(q, c, sw, cp, ids, inv_t, diag_offset, k)
+            loss, per_example, _, _ = torch.ops.twotower.retrieval_loss(q, c, sw, cp, ids, inv_t, diag_offset, k, self._precision)
         else:
             loss, per_example = torch.ops.twotower.retrieval_loss_value(q, c, sw, cp, ids, inv_t, diag_offset, k)
         self.last_per_example_loss = per_example

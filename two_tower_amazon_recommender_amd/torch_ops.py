@@ -46,11 +46,13 @@ def _(table, ids):
 @torch.library.custom_op(f"{NS}::retrieval_loss", mutates_args=(), device_types="cuda")
 def retrieval_loss(query_embeddings: Tensor, candidate_embeddings: Tensor, sample_weight: Optional[Tensor],
                    candidate_sampling_probability: Optional[Tensor], candidate_ids: Optional[Tensor],
-                   inv_temperature: float, diag_offset: int, num_hard_negatives: int) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+                   inv_temperature: float, diag_offset: int, num_hard_negatives: int,
+                   precision: str = "f32") -> Tuple[Tensor, Tensor, Tensor, Tensor]:
     """In-batch sampled-softmax loss (SUM) of tfrs.tasks.Retrieval AND its gradients, in the fused two-pass form
     (8*Bq*Bc*D executed FLOPs; the logits never reach HBM).  Returns (loss [], per-example loss [Bq], dLoss/dq, dLoss/dc);
     the autograd formula multiplies the saved gradients by the incoming scalar gradient.  ``candidate_ids`` given =
-    accidental-hit removal; ``num_hard_negatives`` > 0 keeps the positive and the k hardest negatives per query."""
+    accidental-hit removal; ``num_hard_negatives`` > 0 keeps the positive and the k hardest negatives per query;
+    ``precision`` "f32" (exact f32 products) or "bf16x3" (f32-emulated split-bf16 products, dim 128 / 256)."""
     q, c = query_embeddings.contiguous(), candidate_embeddings.contiguous()
     nq, nc, d = q.shape[0], c.shape[0], q.shape[1]
     ws = _ws(nq, nc, d, q.device)
@@ -64,12 +66,13 @@ def retrieval_loss(query_embeddings: Tensor, candidate_embeddings: Tensor, sampl
                                                      diag_offset=diag_offset)
     ops.retrieval_fwd_bwd(q, c, inv_temperature, ws, lse, per_row, loss, dq, dc, sample_weight=sample_weight,
                           cand_prob=candidate_sampling_probability, cand_ids=candidate_ids, diag_offset=diag_offset,
-                          hard_thr=thr)
+                          hard_thr=thr, precision=precision)
     return loss.reshape(()), per_row, dq, dc
 
 
 @retrieval_loss.register_fake
-def _(q, c, sample_weight, candidate_sampling_probability, candidate_ids, inv_temperature, diag_offset, num_hard_negatives):
+def _(q, c, sample_weight, candidate_sampling_probability, candidate_ids, inv_temperature, diag_offset, num_hard_negatives,
+      precision="f32"):
     return q.new_empty(()), q.new_empty((q.shape[0],)), torch.empty_like(q), torch.empty_like(c)
 
 
@@ -81,7 +84,7 @@ def _retrieval_setup(ctx, inputs, output):
 def _retrieval_backward(ctx, g_loss, g_per_example, g_dq, g_dc):
     dq, dc = ctx.saved_tensors
     # the upstream gradient of the scalar loss stays on the device (no host sync)
-    return dq * g_loss, dc * g_loss, None, None, None, None, None, None
+    return dq * g_loss, dc * g_loss, None, None, None, None, None, None, None
 
 
 retrieval_loss.register_autograd(_retrieval_backward, setup_context=_retrieval_setup)

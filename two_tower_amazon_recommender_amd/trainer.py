@@ -49,6 +49,9 @@ class TwoTowerConfig:
     # BASELINE configs[4] "30 categories as hash features": a [n_category_buckets, embedding_dim] table whose row
     # (bucket of the pair's hashed category) is ADDED to the item embedding before the item tower.  0 = no such feature.
     n_category_buckets: int = 0
+    # matrix products of the scorer + softmax loss: "f32" (exact f32 products on the f32-input MFMA: the parity-safe default
+    # and the headline) or "bf16x3" (f32-emulated through a three-way bf16 split on the bf16 MFMA; scorer dim 128 / 256)
+    scorer_precision: str = "f32"
 
     @property
     def user_dims(self) -> list:
@@ -77,6 +80,10 @@ class TwoTowerConfig:
             raise ValueError("temperature must be positive")
         if self.n_category_buckets < 0:
             raise ValueError("n_category_buckets must be >= 0")
+        if self.scorer_precision not in ops.SCORER_PRECISIONS:
+            raise ValueError(f"scorer_precision must be one of {ops.SCORER_PRECISIONS}")
+        if self.scorer_precision == "bf16x3" and self.tower_dims[-1] not in (128, 256):
+            raise ValueError("scorer_precision='bf16x3' needs a scorer dim (last tower dim) of 128 or 256")
 
 
 class Tower:
@@ -326,7 +333,7 @@ class TwoTowerTrainer:
         kw = dict(sample_weight=sample_weight, cand_prob=candidate_sampling_probability, cand_ids=candidate_ids)
         # loss + dq + dc in two fused passes over the logits (never materialised)
         ops.retrieval_fwd_bwd(q, c, 1.0 / cfg.temperature, self.ws, self.lse, self.per_row, self.loss,
-                              ut.dz[-1], it.dz[-1], **kw)
+                              ut.dz[-1], it.dz[-1], precision=cfg.scorer_precision, **kw)
         if cfg.symmetric:
             towers_backward(ut, it, cfg.dropout_rate, lookups=lks if lks[0] else None)
         else:
