@@ -92,7 +92,7 @@ def cpu_share() -> int:
     return max(1, min(n, 16))
 
 
-PMC_FILE = "profiles/pmc_cfg3_sgd.json"     # rocprofv3 --pmc passes of round r01d (scratch/prof_pmc.sh + pmc_summary.py)
+PMC_FILE = "profiles/r02_pmc_cfg3_sgd.json"     # rocprofv3 --pmc passes of round r02 (scratch/prof_pmc.sh + pmc_summary.py)
 
 
 def pmc_traffic(tag):
@@ -187,7 +187,10 @@ def main():
     # kernels' durations come from an untimed detail pass of the same steps right after it.
     all_tags = "score_fused,score_bwd,gather,sparse_plan,sparse_apply,dense_fwd,dense_bwd".split(",")
     timed_tags = os.environ.get("TT_BENCH_TAGS", "score_fused")
-    stride = 4 if args.steps >= 40 else 1            # the dominant kernel is sampled every 4th step (>= 10 samples)
+    # the dominant kernel is bracketed on every 4th step only, whatever --steps is: with a bracket on EVERY launch the two
+    # event records of consecutive launches sit back to back and the bracket itself reads ~20 us long (BENCH_r01: 290.6 us
+    # at stride 1 in a 20-step run vs 269 us in rocprof and 271 us at stride 4)
+    stride = 4 if args.steps >= 8 else 1
     _lib.profile_set_stride(stride)
     _lib.profile_enable(timed_tags, capacity=2 * args.steps + 8)
     torch.cuda.synchronize()
@@ -264,7 +267,7 @@ def main():
         a = alg_flops / t / 1e12
         return {"bound": "mfma", "kernel": name, "achieved": a, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": a / MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                "traffic_source": f"{PMC_FILE} (committed rocprofv3 --pmc passes of round r01d; not re-measured in this run)",
+                "traffic_source": f"{PMC_FILE} (committed rocprofv3 --pmc passes of round r02; not re-measured in this run)",
                 "avg_launch_us": t * 1e6, "dtype": "f32-input MFMA",
                 "executed_tflops": 4.0 * b2d / t / 1e12, "executed_frac": 4.0 * b2d / t / 1e12 / MFMA_F32_PEAK_TFLOPS}
 

@@ -40,12 +40,19 @@ def test_synthetic_init_is_bit_identical_to_oracle(dev):
     ("ref-config-dropout0.1", (5_000, 5_000, 128, [512, 256, 128], 1024), "adagrad", "Z"),
     ("ragged-batch-777", (3_000, 2_000, 64, [96, 64], 777), "adagrad", "Z"),
     ("cfg5-dims-256", (4_000, 4_000, 256, [512, 256], 1536), "adagrad", "U"),
+    # the same bars with the scorer's matrix products in the f32-emulated bf16x3 precision (split-bf16 on the bf16 MFMA)
+    ("cfg3-small-bf16x3", (50_000, 100_000, 128, [256, 128], 8192), "sgd", "U"),
+    ("ref-config-dropout0.1-bf16x3", (5_000, 5_000, 128, [512, 256, 128], 1024), "adagrad", "Z"),
+    ("cfg5-dims-256-bf16x3", (4_000, 4_000, 256, [512, 256], 1536), "adagrad", "U"),
 ])
 def test_train_steps_match_oracle(dev, name, shape, opt, variant):
     n_users, n_items, dim, tower_dims, batch = shape
     seed = 1001
     rate = 0.1 if "dropout" in name else 0.0          # configs/data_config.yaml:58
     cfg, tr, ref = make(dev, n_users, n_items, dim, tower_dims, batch, opt, seed, dropout=rate)
+    if name.endswith("bf16x3"):
+        cfg.scorer_precision = "bf16x3"
+        cfg.validate()
     for step in range(3):
         uid = synth.batch_ids(seed, synth.TID_USER_IDS, step, batch, n_users, variant)
         iid = synth.batch_ids(seed, synth.TID_ITEM_IDS, step, batch, n_items, variant)
