@@ -328,11 +328,20 @@ __global__ __launch_bounds__(256) void gemm_bwd_kernel(BwdBatch pb) {
   const bool is_dw = pb.dw_first ? b < n_dw : b >= n_dx;
   if (is_dw) {
     if (!pb.dw_first) b -= n_dx;
-    const int prob = b / per_w;
-    b -= prob * per_w;
-    const int split = b / per_split;
-    b -= split * per_split;
-    gemm_tile<false, false, true, GK>(pb.aw[prob], split, b % pb.dw_gm, b / pb.dw_gm, smem, gids);
+    // XCD-aware order: the tiles of one (problem, batch split) group read the SAME x / dz slices (A by the column
+    // tiles, B by the row tiles).  Workgroups are dealt round-robin over the 8 XCDs (private L2 each), so in plain index
+    // order a group's tiles land on 8 different L2s and every slice is fetched up to 4x (PMC r02: 102-114 MB per
+    // backward launch against ~45 MB algorithmic).  Here workgroup w takes tile k = (w/8) % T of group (w/8/T)*8 + w%8:
+    // a group's T tiles run back to back on ONE XCD.  (Speed only; any placement computes the same tiles.)
+    const int groups = pb.nprob * pb.splits;
+    int grp = b / per_split, k = b % per_split;
+    if (groups % 8 == 0 && (pb.dw_first || n_dx % 8 == 0)) {
+      const int j = b >> 3;
+      k = j % per_split;
+      grp = (j / per_split) * 8 + (b & 7);
+    }
+    const int prob = grp / pb.splits, split = grp % pb.splits;
+    gemm_tile<false, false, true, GK>(pb.aw[prob], split, k % pb.dw_gm, k / pb.dw_gm, smem, gids);
   } else {
     if (pb.dw_first) b -= n_dw;
     const int prob = b / per_x;
