@@ -50,6 +50,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
+    ap.add_argument("--pre-spin-ms", type=float, default=250.0,
+                    help="before the W warm-up steps, keep the GPU busy this long with forward-only passes over the first "
+                         "batch (no parameter is touched): a fresh process starts at idle clocks and cold TLBs, and a "
+                         "25-step run otherwise measures the ramp (BENCH_r01: FUSED kernel 290 us vs 269 us in steady state)")
     ap.add_argument("--negatives", default="global", choices=["global", "local"],
                     help="N>1: in-batch negatives over the all-gathered GLOBAL batch (parity with the single-device loss; "
                          "default) or over each rank's own batch")
@@ -177,6 +181,15 @@ def main():
         if cids is None:
             return trainer.step(uids[s], iids[s])
         return trainer.step(uids[s], iids[s], category_ids=cids[s])
+    if args.pre_spin_ms > 0:              # device warm-up, not training: forward-only, model state untouched
+        t_spin = time.perf_counter()
+        while (time.perf_counter() - t_spin) * 1e3 < args.pre_spin_ms:
+            for _ in range(8):
+                if cids is None:
+                    trainer.evaluate(uids[0], iids[0])
+                else:
+                    trainer.evaluate(uids[0], iids[0], category_ids=cids[0])
+            torch.cuda.synchronize()
     for s in range(args.warmup):
         step(s)
     torch.cuda.synchronize()

@@ -171,9 +171,11 @@ def _np_plan(ids, rows):
 @pytest.mark.parametrize("n,rows,variant", [(1, 10, "U"), (63, 30, "Z"), (513, 1000, "U"), (4096, 1 << 20, "U"),
                                             (8192, 10_000_000, "U"), (8192, 5_000_000, "Z"), (8192, 30, "Z"),
                                             (8192, 100_000_000, "Z"), (16384, 100_000_000, "U"), (12345, 70_000, "Z"),
-                                            (16385, 10_000_000, "Z"), (40000, 257, "U")])
+                                            (16385, 10_000_000, "Z"), (40000, 257, "U"), (32768, 48_000_000, "Z"),
+                                            (100_000, 30, "Z"), (262_144, 15_000_000, "U"), (300_000, 1000, "Z")])
 def test_sort_plan_is_a_stable_sort_for_every_size_and_key_width(dev, n, rows, variant):
-    """<= 16384 ids: the hand-written one-launch LDS radix sort (1-4 passes of 8/9-bit digits); above: rocPRIM."""
+    """<= 16384 ids: the hand-written one-launch LDS radix sort (1-4 passes of 8/9-bit digits); up to 262144: 16384-id
+    chunks sorted in one launch + a rank-merge launch; above: rocPRIM."""
     ids = synth.batch_ids(31, 3, 0, n, rows, variant)
     plan = ops.SparsePlan(n, dev).run(T(ids, dev), rows)
     sk, so = _np_plan(ids, rows)

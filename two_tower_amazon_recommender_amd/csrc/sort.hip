@@ -9,9 +9,10 @@
 //          the wave's digit counter in LDS — rounds in element order, so equal digits keep their order (stable);
 //   scan   digit-major, wave-minor exclusive scan of the 16 x 2^DBITS counters;
 //   move   keys and positions (u16) scatter inside LDS.
-// Integer-only, LDS-bound; 8192 ids: ~8 us on one CU, on a side stream beside the forward pass (rocPRIM's device radix
-// sort needs 6 launches / ~65 us for the same job).  Above 16384 ids (32-bit keys + 16-bit positions + counters no
-// longer fit 160 KiB of LDS) tt_sparse_plan falls back to rocPRIM with the same clamped keys.
+// Integer-only, VALU-bound by the ballots; 8192 ids: 23-26 us on one CU, on a side stream beside the forward pass (rocPRIM's
+// device radix sort needs 6 launches / ~65 us for the same job).  Above 16384 ids per table (32-bit keys + 16-bit positions
+// + counters no longer fit 160 KiB of LDS) the list is sorted in 16384-id chunks (one workgroup each, same launch) and a
+// second launch merges them by rank (merge_rank_kernel); only beyond 16 chunks (262144 ids) rocPRIM takes over.
 #include "common.h"
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
@@ -19,8 +20,10 @@
 
 namespace {
 
-constexpr int kMaxLdsSortIds = 16384;
-constexpr int kMaxTables = 4;
+constexpr int kMaxLdsSortIds = 16384;   // ids one workgroup sorts in LDS
+constexpr int kMaxTables = 4;           // tables per tt_sparse_plan_batched call
+constexpr int kMaxEntries = 16;         // (table, chunk) entries per launch of the LDS sort
+constexpr int kMaxChunks = 16;          // longer lists (> 262144 ids) fall back to rocPRIM
 
 int id_bits(int64_t num_rows) {
   int bits = 1;
@@ -38,8 +41,42 @@ struct SortTable {
   uint32_t sentinel;
 };
 struct SortBatch {
-  SortTable t[kMaxTables];
+  SortTable t[kMaxEntries];
 };
+
+// ---- lists longer than one workgroup's LDS: chunks of 16384 ids are sorted by the kernel below (one workgroup each,
+// all in one launch; chunk-local positions), then every element finds its place in the whole by binary search in the
+// OTHER chunks: rank = own index + #(keys <= mine) in earlier chunks + #(keys < mine) in later ones — earlier chunks
+// hold the smaller positions, so this is exactly the stable order.  n threads, <= 14 dependent L2 loads per other chunk.
+struct MergeArgs {
+  const int64_t* keys;    // [n]  chunk-wise sorted (clamped) keys
+  const int32_t* lpos;    // [n]  chunk-local positions
+  int64_t* sorted_ids;    // [n]  out
+  int32_t* order;         // [n]  out
+  int32_t n, nchunks;
+};
+
+__global__ __launch_bounds__(256) void merge_rank_kernel(MergeArgs a) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= a.n) return;
+  const int c = e / kMaxLdsSortIds;
+  const int64_t key = a.keys[e];
+  int rank = e - c * kMaxLdsSortIds;
+  for (int o = 0; o < a.nchunks; ++o) {
+    if (o == c) continue;
+    const int64_t* run = a.keys + (int64_t)o * kMaxLdsSortIds;
+    int lo = 0, hi = a.n - o * kMaxLdsSortIds;
+    if (hi > kMaxLdsSortIds) hi = kMaxLdsSortIds;
+    while (lo < hi) {                     // o < c: upper bound (equal keys of earlier chunks go first); o > c: lower bound
+      const int mid = (lo + hi) >> 1;
+      const int64_t v = run[mid];
+      if (o < c ? v <= key : v < key) lo = mid + 1; else hi = mid;
+    }
+    rank += lo;
+  }
+  a.sorted_ids[rank] = key;
+  a.order[rank] = c * kMaxLdsSortIds + a.lpos[e];
+}
 
 template <int DBITS>
 __device__ __forceinline__ uint64_t match_any(uint32_t d) {
@@ -216,33 +253,12 @@ extern "C" int32_t tt_sparse_plan_max_lds_ids(void) { return kMaxLdsSortIds; }
 
 extern "C" int64_t tt_sparse_plan_workspace_bytes(int64_t n_ids) {
   if (n_ids <= kMaxLdsSortIds) return 256;         // the LDS sort needs no global scratch
+  if (n_ids <= (int64_t)kMaxChunks * kMaxLdsSortIds) return align_up(n_ids * 8, 256) + align_up(n_ids * 4, 256);   // chunk-sorted keys + positions
   return align_up((int64_t)rocprim_temp_bytes(n_ids), 256) + 256;
 }
 
-extern "C" int tt_sparse_plan_batched(const tt_sparse_plan_args* tables, int32_t n_tables, tt_stream_t stream_) {
-  TT_REQUIRE(tables != nullptr && n_tables >= 1 && n_tables <= kMaxTables, "tt_sparse_plan_batched: 1..%d tables", kMaxTables);
-  hipStream_t stream = tt::as_stream(stream_);
-  SortBatch b{};
-  int nb = 0, max_n = 0, max_bits = 0;
-  for (int i = 0; i < n_tables; ++i) {
-    const tt_sparse_plan_args& a = tables[i];
-    TT_REQUIRE(a.n_ids >= 0 && a.num_rows > 0, "tt_sparse_plan: bad n_ids/num_rows");
-    TT_REQUIRE(a.n_ids <= 0x7fffffff, "tt_sparse_plan: n_ids must fit in int32");
-    if (a.n_ids == 0) continue;
-    TT_REQUIRE(a.ids && a.sorted_ids && a.order, "tt_sparse_plan: null pointer");
-    const int bits = id_bits(a.num_rows + 1);
-    if (a.n_ids > kMaxLdsSortIds || bits > 31) {   // large id lists: rocPRIM, one table at a time
-      const int rc = plan_rocprim(a, stream);
-      if (rc != TT_OK) return rc;
-      continue;
-    }
-    SortTable& t = b.t[nb++];
-    t.ids = a.ids; t.sorted_ids = a.sorted_ids; t.order = a.order; t.num_rows = a.num_rows; t.n = (int32_t)a.n_ids;
-    t.sentinel = (uint32_t)(((uint64_t)1 << bits) - 1);
-    if ((int)a.n_ids > max_n) max_n = (int)a.n_ids;
-    if (bits > max_bits) max_bits = bits;
-  }
-  if (nb == 0) return TT_OK;
+namespace {
+int launch_entries(SortBatch& b, int nb, int max_n, int max_bits, hipStream_t stream) {
   // digits: 8 bits when the passes needed are the same as with 9 (fewer ballots, smaller counter table)
   const int npass9 = (max_bits + 8) / 9, npass8 = (max_bits + 7) / 8;
   const bool nine = npass9 < npass8;
@@ -254,6 +270,59 @@ extern "C" int tt_sparse_plan_batched(const tt_sparse_plan_args* tables, int32_t
   const int threads = max_n <= 512 * items ? 512 : 1024;
   if (items == 8) return nine ? launch_lds_sort<8, 9>(b, nb, threads, stream) : launch_lds_sort<8, 8>(b, nb, threads, stream);
   return nine ? launch_lds_sort<16, 9>(b, nb, threads, stream) : launch_lds_sort<16, 8>(b, nb, threads, stream);
+}
+}  // namespace
+
+extern "C" int tt_sparse_plan_batched(const tt_sparse_plan_args* tables, int32_t n_tables, tt_stream_t stream_) {
+  TT_REQUIRE(tables != nullptr && n_tables >= 1 && n_tables <= kMaxTables, "tt_sparse_plan_batched: 1..%d tables", kMaxTables);
+  hipStream_t stream = tt::as_stream(stream_);
+  SortBatch b{};
+  MergeArgs merges[kMaxTables];
+  int nb = 0, max_n = 0, max_bits = 0, n_merge = 0, rc;
+  for (int i = 0; i < n_tables; ++i) {
+    const tt_sparse_plan_args& a = tables[i];
+    TT_REQUIRE(a.n_ids >= 0 && a.num_rows > 0, "tt_sparse_plan: bad n_ids/num_rows");
+    TT_REQUIRE(a.n_ids <= 0x7fffffff, "tt_sparse_plan: n_ids must fit in int32");
+    if (a.n_ids == 0) continue;
+    TT_REQUIRE(a.ids && a.sorted_ids && a.order, "tt_sparse_plan: null pointer");
+    const int bits = id_bits(a.num_rows + 1);
+    const int chunks = (int)((a.n_ids + kMaxLdsSortIds - 1) / kMaxLdsSortIds);
+    if (chunks > kMaxChunks || bits > 31) {   // very long id lists: rocPRIM, one table at a time
+      if ((rc = plan_rocprim(a, stream)) != TT_OK) return rc;
+      continue;
+    }
+    int64_t* keys_out = a.sorted_ids;
+    int32_t* pos_out = a.order;
+    if (chunks > 1) {                         // chunk-wise sorted (key, local position) go to the workspace, then the merge
+      const int64_t need = tt_sparse_plan_workspace_bytes(a.n_ids);
+      if (a.workspace == nullptr || a.workspace_bytes < need)
+        return tt::fail(TT_ERR_WORKSPACE, "tt_sparse_plan: workspace %lld < %lld bytes", (long long)a.workspace_bytes, (long long)need);
+      TT_REQUIRE((reinterpret_cast<uintptr_t>(a.workspace) & 255u) == 0, "tt_sparse_plan: workspace must be 256-byte aligned");
+      keys_out = static_cast<int64_t*>(a.workspace);
+      pos_out = reinterpret_cast<int32_t*>(static_cast<char*>(a.workspace) + align_up(a.n_ids * 8, 256));
+      merges[n_merge++] = MergeArgs{keys_out, pos_out, a.sorted_ids, a.order, (int32_t)a.n_ids, chunks};
+    }
+    for (int c = 0; c < chunks; ++c) {
+      if (nb == kMaxEntries) {                // (only with several multi-chunk tables in one call)
+        if ((rc = launch_entries(b, nb, max_n, max_bits, stream)) != TT_OK) return rc;
+        nb = 0; max_n = 0; max_bits = 0;
+      }
+      const int64_t off = (int64_t)c * kMaxLdsSortIds;
+      SortTable& t = b.t[nb++];
+      t.ids = a.ids + off; t.sorted_ids = keys_out + off; t.order = pos_out + off; t.num_rows = a.num_rows;
+      t.n = (int32_t)(a.n_ids - off < kMaxLdsSortIds ? a.n_ids - off : kMaxLdsSortIds);
+      t.sentinel = (uint32_t)(((uint64_t)1 << bits) - 1);
+      if (t.n > max_n) max_n = t.n;
+      if (bits > max_bits) max_bits = bits;
+    }
+  }
+  if (nb > 0 && (rc = launch_entries(b, nb, max_n, max_bits, stream)) != TT_OK) return rc;
+  for (int i = 0; i < n_merge; ++i) {
+    tt::ProfScope prof("sparse_plan", stream);
+    hipLaunchKernelGGL(merge_rank_kernel, dim3((unsigned)((merges[i].n + 255) / 256)), dim3(256), 0, stream, merges[i]);
+    if ((rc = tt::check_launch("tt_sparse_plan(merge)")) != TT_OK) return rc;
+  }
+  return TT_OK;
 }
 
 extern "C" int tt_sparse_plan(const int64_t* ids, int64_t n_ids, int64_t num_rows, void* workspace, int64_t workspace_bytes,
