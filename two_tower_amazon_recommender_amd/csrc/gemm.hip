@@ -22,13 +22,21 @@ using tt::f32x4;
 using tt::f32x16;
 
 constexpr int BM = 64, BN = 64, BK = 32;
-constexpr int PF = 4;                    // k-tiles of global loads kept in flight per thread (register ring)
+constexpr int PF_MAX = 4;                // k-tiles of global loads kept in flight per thread (register ring); the mixed-orientation
+                                         // forward kernel runs with 3 (it spills 22-48 VGPRs at 4 under the 4-waves/SIMD bound)
 constexpr int NST = BM * BK / 4 / 256;   // staged float4 per thread and operand (= 2)
 constexpr int LS_KC = BK + 4;            // [row][k] stride
 constexpr int LS_MC = BM + 4;            // [k][row] stride
 constexpr int TILE_F = (BM * LS_KC > BK * LS_MC) ? BM * LS_KC : BK * LS_MC;   // floats per operand tile
 constexpr int kMaxGatherK = 1024;        // fused-gather dW tiles: ids of one split's batch rows staged in LDS (2 KB up to 256 rows
                                          // per split = batch <= 8192: 4 workgroups per CU still fit; 8 KB up to 1024)
+
+#ifdef TT_GEMM_STAMPS
+__device__ unsigned long long g_stamps[8192 * 4];
+#define STAMP(i) do { if (threadIdx.x == 0) g_stamps[(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) % 8192 * 4 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
 
 struct GemmArgs {
   const float* A;
@@ -178,9 +186,10 @@ struct GemmBatch {
 //    epilogue stores under the next tile's MFMAs), 1-4 workgroups per CU: 125-196 us vs 114 — the cursor state costs
 //    ~50 VGPRs (149-176 -> 3 waves/SIMD instead of 4) and these 4-8 k-tile GEMMs want occupancy (memory-level
 //    parallelism across many small workgroups) more than an in-workgroup pipeline.
-template <bool A_KC, bool B_KC, bool COLSUM, int GK>
+template <bool A_KC, bool B_KC, bool COLSUM, int GK, bool DROP = false>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int zsplit, const int bx, const int by, float* smem,
                                           int32_t* gids) {
+  constexpr int PF = (A_KC && !B_KC) ? 3 : PF_MAX;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, ln = lane & 31;
@@ -230,12 +239,38 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int zsplit, c
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   float colsum = 0.f;
+  STAMP(0);
+  // dx epilogue mask (ReLU output of the previous layer): its 16 values per lane do not depend on the GEMM, so they are
+  // requested BEFORE the operand tiles and folded into 16 bits as soon as they land (the operand loads issued after them
+  // stay in flight): loading them after the MFMAs made the store phase of the masked dx tiles 9.3 us against 3.7-3.9 us
+  // for the other kinds (r02 per-workgroup stamps)
+  float mk[A_KC && B_KC ? 16 : 1];
+  uint32_t mbits = 0xffffu;
+  const bool masked = A_KC && B_KC && p.mask_src != nullptr;
+  if constexpr (A_KC && B_KC) {
+    if (masked) {
+      const int64_t nn = n0 + wn * 32 + ln;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int64_t m = m0 + wm * 32 + tt::acc_row(reg, h);
+        mk[reg] = (nn < p.N && m < p.M) ? p.mask_src[m * p.ldc + nn] : 0.f;
+      }
+    }
+  }
 
 #pragma unroll
   for (int u = 0; u < PF; ++u) {
     if (u < nk) {
       load_a(sa[u], u);
       load_operand<B_KC>(sb[u], p.B, p.ldb, n0, p.N, kbeg + (int64_t)u * BK, kend, tid);
+    }
+  }
+
+  if constexpr (A_KC && B_KC) {
+    if (masked) {
+      mbits = 0u;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) mbits |= (mk[reg] > 0.f ? 1u : 0u) << reg;
     }
   }
 
@@ -253,6 +288,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int zsplit, c
           load_operand<B_KC>(sb[u], p.B, p.ldb, n0, p.N, kbeg + (int64_t)(t + PF) * BK, kend, tid);
         }
         __syncthreads();                              // tile t visible; everyone is done with the other buffer
+        if (t == 0) STAMP(1);
 #pragma unroll
         for (int g = 0; g < BK / 8; ++g) {
           const f32x4 a4 = read_operand<A_KC>(TA, wm * 32 + ln, g, h);
@@ -271,6 +307,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int zsplit, c
     }
   }
 
+  STAMP(2);
   float* C = p.C + (int64_t)zsplit * p.slab_stride;
   const int64_t n = n0 + wn * 32 + ln;
   if (n < p.N) {
@@ -281,11 +318,16 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int zsplit, c
       if (m < p.M) {
         float v = acc[reg] + bias;
         if (p.relu) v = fmaxf(v, 0.f);
-        if (p.drop_p24 != 0u) {      // inverted dropout on the activation (Keras Dropout after the Dense)
+        if constexpr (DROP) {        // inverted dropout on the activation (Keras Dropout after the Dense); compiled in
+                                     // only for dropout launches: its 64-bit hash costs the plain forward kernel registers
           const uint64_t hsh = tt::splitmix(p.drop_key + p.drop_offset + (uint64_t)m * (uint64_t)p.N + (uint64_t)n);
           v = ((uint32_t)(hsh >> 40) < p.drop_p24) ? 0.f : v * p.drop_scale;
         }
-        if (p.mask_src != nullptr) v = p.mask_src[m * p.ldc + n] > 0.f ? v * p.mask_scale : 0.f;
+        if constexpr (A_KC && B_KC) {
+          if (masked) v = ((mbits >> reg) & 1u) ? v * p.mask_scale : 0.f;
+        } else {
+          if (p.mask_src != nullptr) v = p.mask_src[m * p.ldc + n] > 0.f ? v * p.mask_scale : 0.f;
+        }
         C[m * p.ldc + n] = v;
       }
     }
@@ -293,15 +335,22 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int zsplit, c
   if constexpr (COLSUM) {
     if (bx == 0 && tid < BN && n0 + tid < p.N) p.db_slabs[(int64_t)zsplit * p.N + n0 + tid] = colsum;
   }
+#ifdef TT_GEMM_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  STAMP(3);
+#endif
 }
 
 constexpr int kGidsInts(int gk, bool mc) { return (gk != 0 && mc) ? 2 * gk : 1; }
 
-template <bool A_KC, bool B_KC, bool COLSUM, int GK>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmBatch pb) {
+// __launch_bounds__(256, 4): 4 waves per SIMD = 4 workgroups per CU = every tile of a tower launch resident at once.  Without
+// the bound the forward kernels took 122-126 VGPRs + 16 AGPRs = 3 waves/SIMD: 768 of layer 0's 1024 workgroups started, the
+// rest ~10 us later (per-workgroup s_memrealtime stamps, r02: start spread 14 us, launch 22.8 us).
+template <bool A_KC, bool B_KC, bool COLSUM, int GK, bool DROP>
+__global__ __launch_bounds__(256, 4) void gemm_kernel(GemmBatch pb) {
   __shared__ __attribute__((aligned(16))) float smem[2 * 2 * TILE_F];
   __shared__ int32_t gids[kGidsInts(GK, !A_KC)];
-  gemm_tile<A_KC, B_KC, COLSUM, GK>(pb.a[blockIdx.z / pb.splits], blockIdx.z % pb.splits, blockIdx.x, blockIdx.y, smem, gids);
+  gemm_tile<A_KC, B_KC, COLSUM, GK, DROP>(pb.a[blockIdx.z / pb.splits], blockIdx.z % pb.splits, blockIdx.x, blockIdx.y, smem, gids);
 }
 
 // dx AND dw+db of one layer (of both towers) in ONE launch: the two kinds of tiles are independent given dz, so
@@ -316,7 +365,7 @@ struct BwdBatch {
 };
 
 template <int GK>
-__global__ __launch_bounds__(256) void gemm_bwd_kernel(BwdBatch pb) {
+__global__ __launch_bounds__(256, 4) void gemm_bwd_kernel(BwdBatch pb) {
   __shared__ __attribute__((aligned(16))) float smem[2 * 2 * TILE_F];
   __shared__ int32_t gids[kGidsInts(GK, true)];
   const int per_split = pb.dw_gm * pb.dw_gn;
@@ -350,7 +399,7 @@ __global__ __launch_bounds__(256) void gemm_bwd_kernel(BwdBatch pb) {
   }
 }
 
-template <bool A_KC, bool B_KC, bool COLSUM, int GK = 0>
+template <bool A_KC, bool B_KC, bool COLSUM, int GK = 0, bool DROP = false>
 int launch(const GemmArgs* probs, int nprob, int splits, hipStream_t stream, const char* what, const char* tag) {
   const GemmArgs& a0 = probs[0];
   const int64_t gm = (a0.M + BM - 1) / BM, gn = (a0.N + BN - 1) / BN;
@@ -360,7 +409,7 @@ int launch(const GemmArgs* probs, int nprob, int splits, hipStream_t stream, con
   for (int i = 0; i < nprob; ++i) pb.a[i] = probs[i];
   pb.splits = splits;
   tt::ProfScope prof(tag, stream);
-  hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, COLSUM, GK>), dim3((unsigned)gm, (unsigned)gn, (unsigned)(splits * nprob)), dim3(256), 0,
+  hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, COLSUM, GK, DROP>), dim3((unsigned)gm, (unsigned)gn, (unsigned)(splits * nprob)), dim3(256), 0,
                      stream, pb);
   return tt::check_launch(what);
 }
@@ -423,7 +472,10 @@ extern "C" int tt_dense_fwd_batched_f32(const tt_dense_fwd_args* probs, int32_t 
       a[i].drop_offset = counter_offset;
     }
   }
-  if (gather) return launch<true, false, false, 1>(a, n_probs, 1, tt::as_stream(stream), "tt_dense_fwd_f32(lookup)", "dense_fwd");
+  const bool drop = drop_rate > 0.f;
+  if (gather && drop) return launch<true, false, false, 1, true>(a, n_probs, 1, tt::as_stream(stream), "tt_dense_fwd_f32(lookup)", "dense_fwd");
+  if (gather) return launch<true, false, false, 1, false>(a, n_probs, 1, tt::as_stream(stream), "tt_dense_fwd_f32(lookup)", "dense_fwd");
+  if (drop) return launch<true, false, false, 0, true>(a, n_probs, 1, tt::as_stream(stream), "tt_dense_fwd_f32", "dense_fwd");
   return launch<true, false, false>(a, n_probs, 1, tt::as_stream(stream), "tt_dense_fwd_f32", "dense_fwd");
 }
 
@@ -518,3 +570,9 @@ extern "C" int tt_dense_bwd_scaled_f32(const float* x, const float* w, const flo
   const tt_dense_bwd_args q{x, w, dz, dx, dx_relu_src, dw_slabs, db_slabs, {}};
   return tt_dense_bwd_batched_f32(&q, 1, dx_scale, m, k, n, stream_);
 }
+
+#ifdef TT_GEMM_STAMPS
+extern "C" int tt_debug_gemm_stamps(unsigned long long* host_out, int n) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 0 : 2;
+}
+#endif
