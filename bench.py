@@ -198,7 +198,7 @@ def main():
     # Timed region: only the DOMINANT kernel carries hipEvent brackets (each event record is a barrier packet that
     # costs the stream ~4-7 us: bracketing all five kernel families inflated the step by 33 us = 4 %).  The other
     # kernels' durations come from an untimed detail pass of the same steps right after it.
-    all_tags = "score_fused,score_bwd,gather,sparse_plan,sparse_apply,dense_fwd,dense_bwd".split(",")
+    all_tags = "score_fused,score_bwd,gather,sparse_plan,sparse_apply,optimizer,dense_fwd,dense_bwd".split(",")
     timed_tags = os.environ.get("TT_BENCH_TAGS", "score_fused")
     # the dominant kernel is bracketed on every 4th step only, whatever --steps is: with a bracket on EVERY launch the two
     # event records of consecutive launches sit back to back and the bracket itself reads ~20 us long (BENCH_r01: 290.6 us
@@ -227,13 +227,14 @@ def main():
     n_layers = len(tower_dims)
     lookup_us, unfused = None, {}
     if trainer.fuse_lookup and cfg.symmetric and not args.graph:
-        trainer.fuse_lookup = False
-        _lib.profile_enable("dense_fwd,dense_bwd,gather", capacity=2 * n_layers * detail_steps + 8)
+        trainer.fuse_lookup = trainer.fuse_optimizer = False      # every kernel as its own launch
+        _lib.profile_enable("dense_fwd,dense_bwd,gather,sparse_apply,dense_update", capacity=2 * n_layers * detail_steps + 8)
         for s in range(total - detail_steps, total):
             step(s)
         torch.cuda.synchronize()
-        unfused = {t: _lib.profile_read(t, 2 * n_layers * detail_steps + 8)[0] for t in ("dense_fwd", "dense_bwd", "gather")}
-        trainer.fuse_lookup = True
+        unfused = {t: _lib.profile_read(t, 2 * n_layers * detail_steps + 8)[0]
+                   for t in ("dense_fwd", "dense_bwd", "gather", "sparse_apply", "dense_update")}
+        trainer.fuse_lookup = trainer.fuse_optimizer = True
         f_l0 = mean(prof["dense_fwd"][0::n_layers]) - mean(unfused["dense_fwd"][0::n_layers])
         b_l0 = mean(prof["dense_bwd"][n_layers - 1::n_layers]) - mean(unfused["dense_bwd"][n_layers - 1::n_layers])
         lookup_us = (f_l0 + b_l0) * 1e3
@@ -300,7 +301,9 @@ def main():
 
     def per_step(tag):                 # ms per STEP (a step may launch a tagged kernel more than once)
         return sum(prof[tag]) / steps_of[tag]
-    t_gs = max((per_step("gather") + per_step("sparse_apply")) * 1e-3 + max(lookup_us or 0.0, 0.0) * 1e-6, 1e-12)
+    # K2 apply: in the step it is half of the single optimizer launch; its own duration comes from the un-fused detail pass
+    apply_ms = (sum(unfused["sparse_apply"]) / detail_steps) if unfused.get("sparse_apply") else per_step("sparse_apply")
+    t_gs = max((per_step("gather") + apply_ms) * 1e-3 + max(lookup_us or 0.0, 0.0) * 1e-6, 1e-12)
     out = {
         "metric": "user-item pairs/sec (train step) + embedding-gather HBM GB/s, 1/2/4/8 MI355X",
         "value": batch / (dt / args.steps), "unit": "pairs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -319,8 +322,9 @@ def main():
         "roofline_hbm": {"bound": "hbm",
                          "kernel": "K1 + K2 on the critical path: the embedding lookup fused into the first tower layer's GEMM "
                                    "loaders (time = what the layer-0 fwd and bwd launches cost MORE than on a materialised "
-                                   "input, from an un-fused detail pass) + sparse_apply_kernel (ONE launch: "
-                                   "segmented sums, fused SGD/Adagrad, arrival-ticket finish; both tables). EXCLUDED and "
+                                   "input, from an un-fused detail pass) + the sparse apply (segmented sums, fused SGD/Adagrad, "
+                                   "arrival-ticket finish; all tables; timed as its own launch in the un-fused detail pass - in the "
+                                   "step it shares ONE launch with the dense tower update: optimizer_launch_us). EXCLUDED and "
                                    "reported beside it: lds_sort_kernel (the plan: one launch for all tables on a side stream, "
                                    "concurrent with the forward pass). hipEvent brackets add ~3 us to kernels this short; "
                                    "rocprof durations: profiles/",
@@ -330,7 +334,9 @@ def main():
                          "lookup_in_gemm_us": lookup_us,
                          "unfused_gather2_us": (mean(unfused["gather"]) * 1e3) if unfused.get("gather") else None,
                          "gather_us": per_step("gather") * 1e3,
-                         "sparse_apply_us": per_step("sparse_apply") * 1e3,
+                         "sparse_apply_us": apply_ms * 1e3,
+                         "optimizer_launch_us": per_step("optimizer") * 1e3,
+                         "unfused_dense_update_us": (mean(unfused["dense_update"]) * 1e3) if unfused.get("dense_update") else None,
                          "sparse_plan_us_side_stream": per_step("sparse_plan") * 1e3,
                          "frac_with_plan_counted": gs_bytes / (t_gs + per_step("sparse_plan") * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "algorithmic_bytes": gs_bytes},

@@ -52,7 +52,8 @@ const char* tt_last_error(void);
  * tt_profile_enable("score_bwd,gather", 4096) makes every launch of the kernels carrying one
  * of those tags record a hipEvent pair on ITS OWN stream (capacity = launches kept per tag);
  * tags: fill, gather, sparse_plan, sparse_apply, dense_fwd, dense_bwd (dx+dw in one launch), dense_bwd_dx, dense_bwd_dw,
- * dense_update, score_fwd, score_bwd, score_fused, score_rank, score_aux, route, scatter_rows, encode_ids.  An empty string (or NULL) disables it.
+ * dense_update, optimizer (sparse + dense in one launch), score_fwd, score_bwd, score_fused, score_rank, score_aux, route, scatter_rows, encode_ids.
+ * An empty string (or NULL) disables it.
  * tt_profile_read synchronises on the recorded events, writes up to `cap` durations in
  * milliseconds (launch order) to the HOST array `ms`, stores the number of durations written in
  * *count (HOST) and clears the tag.  Disabled = one predictable branch per launch.           */
@@ -283,6 +284,21 @@ typedef struct tt_dense_seg {
 } tt_dense_seg;
 int tt_dense_update_f32(const tt_dense_seg* segs, int32_t n_segs, int32_t opt, int32_t apply,
                         float lr, float eps, tt_stream_t stream);
+
+/* The whole optimizer of a train step in ONE launch: the fused sparse update of up to 3 embedding tables (user, item,
+ * hashed category; same dim and n_ids, each with its own sort plan and apply workspace) AND the dense update of every
+ * tower segment (apply = 1 semantics of tt_dense_update_f32).  Same arithmetic, bit for bit, as tt_sparse_update2_f32 /
+ * tt_sparse_{sgd,adagrad}_f32 followed by tt_dense_update_f32; the two halves are independent and memory-bound, so one
+ * launch overlaps them and saves a launch boundary.  `tables` and `segs` are HOST arrays.                          */
+typedef struct tt_sparse_table {
+  float* table; float* accum;            /* [rows, dim]; accum NULL for SGD        */
+  int64_t rows;
+  const float* grads;                    /* [n_ids, dim] per-position gradient rows */
+  const int64_t* sorted_ids; const int32_t* order;   /* tt_sparse_plan outputs      */
+  void* apply_ws;                        /* tt_sparse_apply_workspace_bytes(n_ids, dim), zeroed once */
+} tt_sparse_table;
+int tt_optimizer_step_f32(int32_t opt, const tt_sparse_table* tables, int32_t n_tables, int32_t dim, int64_t n_ids,
+                          const tt_dense_seg* segs, int32_t n_segs, float lr, float eps, tt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * a3 + a4 — batched dot-product scorer fused with the in-batch sampled-softmax loss

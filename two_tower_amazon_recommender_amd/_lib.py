@@ -52,6 +52,12 @@ class SparsePlanArgs(C.Structure):
                 ("workspace_bytes", C.c_int64), ("sorted_ids", C.c_void_p), ("order", C.c_void_p)]
 
 
+class SparseTable(C.Structure):
+    """Mirror of ``tt_sparse_table`` (one embedding table of the single-launch optimizer step)."""
+    _fields_ = [("table", C.c_void_p), ("accum", C.c_void_p), ("rows", C.c_int64), ("grads", C.c_void_p),
+                ("sorted_ids", C.c_void_p), ("order", C.c_void_p), ("apply_ws", C.c_void_p)]
+
+
 class DenseSeg(C.Structure):
     """Mirror of ``tt_dense_seg`` (include/twotower_hip.h)."""
     _fields_ = [
@@ -97,6 +103,7 @@ SIGNATURES = {
     "tt_dense_bwd_num_slabs": (_i32, [_i64]),
     "tt_dense_bwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
     "tt_dense_update_f32": (C.c_int, [C.POINTER(DenseSeg), _i32, _i32, _i32, _f, _f, _p]),
+    "tt_optimizer_step_f32": (C.c_int, [_i32, C.POINTER(SparseTable), _i32, _i32, _i64, C.POINTER(DenseSeg), _i32, _f, _f, _p]),
     "tt_retrieval_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "tt_retrieval_rank_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "tt_retrieval_fwd_f32": (C.c_int, [_p, _p, _i64, _i64, _i32, _i64, _f, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p]),

@@ -347,7 +347,7 @@ constexpr int kGidsInts(int gk, bool mc) { return (gk != 0 && mc) ? 2 * gk : 1; 
 // the bound the forward kernels took 122-126 VGPRs + 16 AGPRs = 3 waves/SIMD: 768 of layer 0's 1024 workgroups started, the
 // rest ~10 us later (per-workgroup s_memrealtime stamps, r02: start spread 14 us, launch 22.8 us).
 template <bool A_KC, bool B_KC, bool COLSUM, int GK, bool DROP>
-__global__ __launch_bounds__(256, 4) void gemm_kernel(GemmBatch pb) {
+__global__ __launch_bounds__(256, (GK > 256 ? 3 : 4)) void gemm_kernel(GemmBatch pb) {     // (the 8 KB id stage: 3 workgroups per CU by LDS)
   __shared__ __attribute__((aligned(16))) float smem[2 * 2 * TILE_F];
   __shared__ int32_t gids[kGidsInts(GK, !A_KC)];
   gemm_tile<A_KC, B_KC, COLSUM, GK, DROP>(pb.a[blockIdx.z / pb.splits], blockIdx.z % pb.splits, blockIdx.x, blockIdx.y, smem, gids);
@@ -365,7 +365,7 @@ struct BwdBatch {
 };
 
 template <int GK>
-__global__ __launch_bounds__(256, 4) void gemm_bwd_kernel(BwdBatch pb) {
+__global__ __launch_bounds__(256, (GK > 256 ? 3 : 4)) void gemm_bwd_kernel(BwdBatch pb) {
   __shared__ __attribute__((aligned(16))) float smem[2 * 2 * TILE_F];
   __shared__ int32_t gids[kGidsInts(GK, true)];
   const int per_split = pb.dw_gm * pb.dw_gn;

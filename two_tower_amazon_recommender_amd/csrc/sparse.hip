@@ -14,6 +14,7 @@
 // HBM-bound.  Algorithmic bytes per distinct row: 4*dim (grad) + 4*dim (row read) + 4*dim (row write)
 // [+ 8*dim accumulator read/write for Adagrad] + 12 (sorted id + position).
 #include "common.h"
+#include "dense_update_body.h"
 #include <cstring>
 
 namespace {
@@ -22,17 +23,18 @@ using tt::f32x4;
 
 constexpr int kPiece = 64;   // sorted slots per piece: runs are cut at global multiples of 64 slots
 
+constexpr int kMaxSparseTables = 3;   // user, item, hashed category
 struct ApplyArgs {
-  float* table[2];
-  float* accum[2];
-  const float* grads[2];
-  const int64_t* sorted_ids[2];
-  const int32_t* order[2];
-  int64_t rows[2];
+  float* table[kMaxSparseTables];
+  float* accum[kMaxSparseTables];
+  const float* grads[kMaxSparseTables];
+  const int64_t* sorted_ids[kMaxSparseTables];
+  const int32_t* order[kMaxSparseTables];
+  int64_t rows[kMaxSparseTables];
   // per-table piece workspace (tt_sparse_apply_workspace_bytes): sums of the pieces of runs that cross a 64-slot boundary
-  float* p_sum[2];      // [nblk][dim]  first piece of a run that continues past its block (head in block j)
-  float* s_sum[2];      // [nblk][dim]  piece starting exactly at slot 64*j
-  int32_t* p_flag[2];   // [nblk]       arrival ticket of the deferred run whose head is in block j (0 between launches)
+  float* p_sum[kMaxSparseTables];      // [nblk][dim]  first piece of a run that continues past its block (head in block j)
+  float* s_sum[kMaxSparseTables];      // [nblk][dim]  piece starting exactly at slot 64*j
+  int32_t* p_flag[kMaxSparseTables];   // [nblk]       arrival ticket of the deferred run whose head is in block j (0 between launches)
 };
 
 template <int OPT>
@@ -66,9 +68,8 @@ __device__ __forceinline__ void update_row(f32x4* __restrict__ table, f32x4* __r
 // update.  A block holds at most one run head that continues past its end, so the counter is unambiguous; the last
 // arriver leaves it at 0 for the next launch.
 template <int OPT>
-__global__ __launch_bounds__(256, 8) void sparse_apply_kernel(ApplyArgs a, int dim4, int lpr_log2, int64_t n_ids, float lr,
-                                                           float eps) {
-  const int t = blockIdx.y;
+__device__ __forceinline__ void sparse_apply_body(const ApplyArgs& a, const int t, const int64_t bx, int dim4, int lpr_log2,
+                                                  int64_t n_ids, float lr, float eps) {
   f32x4* __restrict__ table = reinterpret_cast<f32x4*>(a.table[t]);
   f32x4* __restrict__ accum = reinterpret_cast<f32x4*>(a.accum[t]);
   const f32x4* __restrict__ grads = reinterpret_cast<const f32x4*>(a.grads[t]);
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256, 8) void sparse_apply_kernel(ApplyArgs a, int d
 
   const int lpr = 1 << lpr_log2;
   const int groups = 256 >> lpr_log2;
-  const int64_t k = (int64_t)blockIdx.x * groups + (threadIdx.x >> lpr_log2);   // sorted slot
+  const int64_t k = bx * groups + (threadIdx.x >> lpr_log2);   // sorted slot
   const int l = threadIdx.x & (lpr - 1);
   if (k >= n_ids) return;
   const int64_t id = sid[k];
@@ -177,6 +178,26 @@ __global__ __launch_bounds__(256, 8) void sparse_apply_kernel(ApplyArgs a, int d
   }
 }
 
+template <int OPT>
+__global__ __launch_bounds__(256, 8) void sparse_apply_kernel(ApplyArgs a, int dim4, int lpr_log2, int64_t n_ids, float lr,
+                                                           float eps) {
+  sparse_apply_body<OPT>(a, blockIdx.y, blockIdx.x, dim4, lpr_log2, n_ids, lr, eps);
+}
+
+// The whole optimizer step of the train step in ONE launch: blockIdx.y < n_tables -> the fused sparse update of table y,
+// else dense segment y - n_tables (csrc/dense_update_body.h).  The two halves are independent and both memory-bound; as
+// two launches they cost 7.5 + 9.0 us plus a launch boundary per step.
+template <int OPT>
+__global__ __launch_bounds__(256, 8) void optimizer_kernel(ApplyArgs a, int n_tables, int dim4, int lpr_log2, int64_t n_ids,
+                                                         int64_t sparse_blocks, tt::SegTable tbl, int dense_blocks, float lr,
+                                                         float eps) {
+  if ((int)blockIdx.y < n_tables) {
+    if ((int64_t)blockIdx.x < sparse_blocks) sparse_apply_body<OPT>(a, blockIdx.y, blockIdx.x, dim4, lpr_log2, n_ids, lr, eps);
+  } else if ((int)blockIdx.x < dense_blocks) {
+    tt::dense_update_body<OPT>(tbl.seg[blockIdx.y - n_tables], blockIdx.x, dense_blocks, 1, lr, eps);
+  }
+}
+
 int64_t align_up(int64_t x, int64_t a);
 
 struct PieceWs {
@@ -190,6 +211,18 @@ PieceWs piece_ws(int64_t n_ids, int32_t dim) {
   w.off_s = w.off_p + align_up(w.nblk * (int64_t)dim * 4, 256);
   w.total = w.off_s + align_up(w.nblk * (int64_t)dim * 4, 256);
   return w;
+}
+
+int prepare_ws(ApplyArgs& a, void* const* ws, int n_tables, int32_t dim, int64_t n_ids, const char* what) {
+  const PieceWs w = piece_ws(n_ids, dim);
+  for (int t = 0; t < n_tables; ++t) {
+    TT_REQUIRE(ws[t] != nullptr && (reinterpret_cast<uintptr_t>(ws[t]) & 255u) == 0, "%s: apply workspace must be non-null, 256-byte aligned", what);
+    char* base = static_cast<char*>(ws[t]);
+    a.p_flag[t] = reinterpret_cast<int32_t*>(base + w.off_flag);
+    a.p_sum[t] = reinterpret_cast<float*>(base + w.off_p);
+    a.s_sum[t] = reinterpret_cast<float*>(base + w.off_s);
+  }
+  return TT_OK;
 }
 
 int launch_apply(int opt, ApplyArgs a, void* const ws[2], int n_tables, int32_t dim, int64_t n_ids, float lr, float eps,
@@ -271,4 +304,53 @@ extern "C" int tt_sparse_update2_f32(int32_t opt, float* table_a, float* accum_a
   a.table[1] = table_b; a.accum[1] = accum_b; a.grads[1] = grads_b; a.sorted_ids[1] = sorted_ids_b; a.order[1] = order_b; a.rows[1] = rows_b;
   void* const ws[2] = {apply_ws_a, apply_ws_b};
   return launch_apply(opt, a, ws, 2, dim, n_ids, lr, eps, tt::as_stream(stream), "tt_sparse_update2_f32");
+}
+
+// ---- the train step's whole optimizer in one launch ---------------------------------------------------------------
+extern "C" int tt_optimizer_step_f32(int32_t opt, const tt_sparse_table* tables, int32_t n_tables, int32_t dim, int64_t n_ids,
+                                     const tt_dense_seg* segs, int32_t n_segs, float lr, float eps, tt_stream_t stream_) {
+  TT_REQUIRE(opt == TT_OPT_SGD || opt == TT_OPT_ADAGRAD, "tt_optimizer_step_f32: unknown optimizer %d", opt);
+  TT_REQUIRE(tables != nullptr && n_tables >= 1 && n_tables <= kMaxSparseTables, "tt_optimizer_step_f32: 1..%d sparse tables", kMaxSparseTables);
+  TT_REQUIRE(segs != nullptr && n_segs >= 1 && n_segs <= TT_MAX_DENSE_SEGS, "tt_optimizer_step_f32: 1..%d dense segments", TT_MAX_DENSE_SEGS);
+  TT_REQUIRE(n_ids > 0 && dim > 0 && dim % 4 == 0, "tt_optimizer_step_f32: bad n_ids/dim");
+  ApplyArgs a{};
+  void* ws[kMaxSparseTables] = {};
+  for (int t = 0; t < n_tables; ++t) {
+    const tt_sparse_table& s = tables[t];
+    TT_REQUIRE(s.table && s.grads && s.sorted_ids && s.order && s.rows > 0, "tt_optimizer_step_f32: table %d: null pointer / bad rows", t);
+    TT_REQUIRE(opt == TT_OPT_SGD || s.accum != nullptr, "tt_optimizer_step_f32: table %d: Adagrad needs the accumulator", t);
+    TT_REQUIRE(tt::aligned16(s.table) && tt::aligned16(s.grads) && tt::aligned16(s.accum), "tt_optimizer_step_f32: table %d: pointers must be 16-byte aligned", t);
+    a.table[t] = s.table; a.accum[t] = s.accum; a.grads[t] = s.grads; a.sorted_ids[t] = s.sorted_ids; a.order[t] = s.order;
+    a.rows[t] = s.rows;
+    ws[t] = s.apply_ws;
+  }
+  int rc = prepare_ws(a, ws, n_tables, dim, n_ids, "tt_optimizer_step_f32");
+  if (rc != TT_OK) return rc;
+  tt::SegTable tbl{};
+  int64_t max_count = 0;
+  for (int i = 0; i < n_segs; ++i) {
+    const tt_dense_seg& s = segs[i];
+    TT_REQUIRE(s.count > 0 && s.n_slabs >= 1 && s.grad_slabs != nullptr && s.param != nullptr, "tt_optimizer_step_f32: segment %d: bad count/slabs/param", i);
+    TT_REQUIRE(opt == TT_OPT_SGD || s.accum != nullptr, "tt_optimizer_step_f32: segment %d: Adagrad needs accum", i);
+    tbl.seg[i] = s;
+    if (s.count > max_count) max_count = s.count;
+  }
+  const int dim4 = dim / 4;
+  int lpr_log2 = 0;
+  while ((1 << lpr_log2) < dim4 && lpr_log2 < 6) ++lpr_log2;
+  const int groups = 256 >> lpr_log2;
+  const int64_t sparse_blocks = (n_ids + groups - 1) / groups;
+  int64_t dense_blocks = (max_count + 255) / 256;
+  if (dense_blocks > 512) dense_blocks = 512;
+  const int64_t gx = sparse_blocks > dense_blocks ? sparse_blocks : dense_blocks;
+  TT_REQUIRE(gx <= 0x7fffffff, "tt_optimizer_step_f32: n_ids too large");
+  hipStream_t stream = tt::as_stream(stream_);
+  tt::ProfScope prof("optimizer", stream);
+  if (opt == TT_OPT_SGD)
+    hipLaunchKernelGGL(optimizer_kernel<TT_OPT_SGD>, dim3((unsigned)gx, (unsigned)(n_tables + n_segs)), dim3(256), 0, stream, a,
+                       n_tables, dim4, lpr_log2, n_ids, sparse_blocks, tbl, (int)dense_blocks, lr, eps);
+  else
+    hipLaunchKernelGGL(optimizer_kernel<TT_OPT_ADAGRAD>, dim3((unsigned)gx, (unsigned)(n_tables + n_segs)), dim3(256), 0, stream, a,
+                       n_tables, dim4, lpr_log2, n_ids, sparse_blocks, tbl, (int)dense_blocks, lr, eps);
+  return tt::check_launch("tt_optimizer_step_f32");
 }

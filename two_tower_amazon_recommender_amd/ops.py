@@ -396,6 +396,25 @@ def dense_update_(segs: list[DenseSeg], opt: str, lr: float, eps: float = 1e-7, 
     _lib.check(lib.tt_dense_update_f32(arr, len(segs), _OPT[opt], int(apply), lr, eps, _stream()), "tt_dense_update_f32")
 
 
+def optimizer_step_(opt: str, tables, segs: list[DenseSeg], lr: float, eps: float = 1e-7):
+    """The train step's whole optimizer in ONE launch: ``tables`` = [(table, accum or None, grads, plan), ...] (up to 3
+    embedding tables of one width whose plans hold the same number of ids) + the dense tower segments."""
+    dim, n_ids = tables[0][0].shape[1], tables[0][3].n_ids
+    arr_t = (_lib.SparseTable * len(tables))()
+    for i, (table, accum, grads, plan) in enumerate(tables):
+        _chk(table, torch.float32, "table", 2)
+        _chk(grads, torch.float32, "grads", 2)
+        if accum is not None:
+            _chk(accum, torch.float32, "accum", 2)
+        if table.shape[1] != dim or plan.n_ids != n_ids or tuple(grads.shape) != (n_ids, dim):
+            raise RuntimeError("optimizer_step_: every table needs the same dim, the same number of ids and [n_ids, dim] gradients")
+        arr_t[i] = _lib.SparseTable(_p(table), _p(accum), table.shape[0], _p(grads), _p(plan.sorted_ids), _p(plan.order),
+                                    _p(plan.apply_ws(dim)))
+    arr_s = (DenseSeg * len(segs))(*segs)
+    _lib.check(_lib.load().tt_optimizer_step_f32(_OPT[opt], arr_t, len(tables), dim, n_ids, arr_s, len(segs), lr, eps, _stream()),
+               "tt_optimizer_step_f32")
+
+
 def make_dense_seg(param, accum, grad_slabs, n_slabs: int, l2: float, grad_out=None) -> DenseSeg:
     count = param.numel()
     return DenseSeg(_p(param), _p(accum), _p(grad_slabs), _p(grad_out), count, count, n_slabs, l2)

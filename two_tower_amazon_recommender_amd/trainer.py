@@ -238,6 +238,7 @@ class TwoTowerTrainer:
         self._side = torch.cuda.Stream(device=dev, priority=-1)
         self.step_index = 0                      # counter of the dropout stream (global batch row = step*batch + r)
         self.fuse_lookup = True                  # K1 inside the first tower layer's GEMMs (False: gather2 launch + acts[0])
+        self.fuse_optimizer = True               # sparse + dense optimizer in one launch (False: dense_update, sparse_update2 [, cat])
         self.flag_poll_every = 50                # steps between asynchronous polls of the out-of-range flag (0 = never)
         self._oob_host = self._oob_event = None
         self._oob_step = -1
@@ -344,6 +345,13 @@ class TwoTowerTrainer:
 
     def apply_gradients(self):
         cfg = self.cfg
+        if self.fuse_optimizer:      # sparse update of every table + dense update of every tower segment: one launch
+            tables = [(self.user_table, self.user_accum, self.user_tower.demb, self.user_plan),
+                      (self.item_table, self.item_accum, self.item_tower.demb, self.item_plan)]
+            if self.cat_table is not None:   # the category row's gradient is the item-tower input gradient itself
+                tables.append((self.cat_table, self.cat_accum, self.item_tower.demb, self.cat_plan))
+            ops.optimizer_step_(cfg.optimizer, tables, self._segs, cfg.learning_rate, cfg.adagrad_epsilon)
+            return
         ops.dense_update_(self._segs, cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon)
         ops.sparse_update2_(cfg.optimizer, self.user_table, self.user_accum, self.user_tower.demb, self.user_plan,
                             self.item_table, self.item_accum, self.item_tower.demb, self.item_plan,
