@@ -150,6 +150,30 @@ def run_distributed(args, rank, world, dev):
     detail_steps = min(args.steps, 20)
     coll = collective_detail(trainer, batches[total - detail_steps:], detail_steps) if trainer.collectives else {}
     trainer.check_ids()
+    # second, separately labelled region: the same steps with the OTHER negatives mode (global <-> local).  With the
+    # weak-scaled family and global negatives the scorer's work per GPU grows with N (B_local x N*B_local logits); the
+    # local line shows the exchange + towers + optimizer scaling alone.
+    other = "local" if negatives == "global" else "global"
+    alt = None
+    if trainer.collectives and world > 1:
+        trainer.set_negatives(other)
+        alt_steps = min(args.steps, 50)
+        for s in range(min(args.warmup, 5)):
+            step(s)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        for s in range(total - alt_steps, total):
+            step(s)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        dta = torch.tensor([time.perf_counter() - ta], dtype=torch.float64, device=dev)
+        dist.all_reduce(dta, op=dist.ReduceOp.MAX)
+        alt = (alt_steps, dta.item())
+        trainer.set_negatives(negatives)
+        trainer.check_ids()
     if rank == 0:
         sec = dt.item()
         sd = tower_dims[-1]
@@ -172,12 +196,18 @@ def run_distributed(args, rank, world, dev):
             "config": {"workload": (f"{name}{' per GPU (weak-scaled family of the N=1 line)' if name == 'cfg3' else ''}, row-sharded: "
                                     f"{cfg.n_users} users x {cfg.n_items} items over {world} GPUs (owner = id % {world}), "
                                     f"emb_dim {dim}, towers {tower}, batch {batch}/GPU (global {world * batch}), in-batch "
-                                    f"negatives {negatives.upper()}, {opt} lr 1e-3, ids {args.ids}"
+                                    f"negatives {negatives.upper()}"
+                                    + (f" (every GPU scores its {batch} queries against all {world * batch} candidates: scorer "
+                                       f"work per GPU grows with N)" if negatives == "global" and name == "cfg3" and world > 1 else "")
+                                    + f", {opt} lr 1e-3, ids {args.ids}"
                                     + (f", + {buckets}-bucket hashed category feature" if buckets else "")),
                        "global_batch": world * batch, "parallelism": f"dp{world} + row-sharded tables (all-to-all)",
                        "negatives": negatives},
             "roofline": roofline, "cpu_baseline": None,
             "collectives": coll or None,
+            "other_negatives": None if alt is None else {
+                "negatives": other, "value": world * batch * alt[0] / alt[1], "unit": "pairs/s", "ms_per_step": alt[1] / alt[0] * 1e3,
+                "steps": alt[0], "note": "same run, same steps, in-batch negatives switched; NOT the headline value"},
             "timing_note": f"hipEvent brackets inside the timed region: score_fused on rank 0, every {stride}th step; "
                            f"collectives: stream time per call, untimed detail pass of {detail_steps} steps",
             "loss_per_pair": loss.item() / (world * batch),

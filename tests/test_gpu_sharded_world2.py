@@ -224,6 +224,18 @@ def _worker_options(rank, world, port, negatives, ret, real=False):
         p_all = synth.uniform_f32(seed, 78, world * b, 0.001, 0.5)
         u, i = tr.synthetic_batch(seed, 0, "Z")
         sl = slice(rank * b, (rank + 1) * b)
+        # set_negatives(): the OTHER slab shape on the same trainer (bench_dist's second region), forward only, then back
+        other = "local" if negatives == "global" else "global"
+        tr.set_negatives(other)
+        ev = tr.evaluate(u, i).item()
+        eu = [synth.batch_ids(seed, synth.TID_USER_IDS, r, b, n_users, "Z") for r in range(world)]
+        ei = [synth.batch_ids(seed, synth.TID_ITEM_IDS, r, b, n_items, "Z") for r in range(world)]
+        if other == "global":
+            want_ev = tt.forward_backward(ref, np.concatenate(eu), np.concatenate(ei), temperature=0.1)["per_row"][sl].sum()
+        else:
+            want_ev = tt.forward_backward(ref, eu[rank], ei[rank], temperature=0.1)["loss"]
+        assert abs(ev - want_ev) <= 1e-4 * abs(want_ev), (ev, want_ev)
+        tr.set_negatives(negatives)
         loss = tr.step(u, i, sample_weight=torch.from_numpy(w_all[sl].copy()).to(dev),
                        candidate_sampling_probability=torch.from_numpy(p_all[sl].copy()).to(dev), candidate_ids=i).item()
         tr.check_ids()

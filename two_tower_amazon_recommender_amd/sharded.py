@@ -401,6 +401,24 @@ class ShardedTwoTowerTrainer:
         if seed is not None:
             self.init_synthetic(seed)
 
+    def set_negatives(self, negatives: str):
+        """Switch between global and local in-batch negatives (the scorer workspace of the other slab shape is allocated
+        on first use; the exchange, the towers and the optimizers are the same)."""
+        if negatives not in ("local", "global"):
+            raise ValueError("negatives must be 'local' or 'global'")
+        if negatives == self.negatives:
+            return
+        b, w, sd = self.cfg.batch_size, self.world, self.cfg.tower_dims[-1]
+        nc = b * w if negatives == "global" else b
+        self._ws_by_mode = getattr(self, "_ws_by_mode", {self.negatives: self.ws})
+        if negatives not in self._ws_by_mode:
+            self._ws_by_mode[negatives] = torch.empty(self.ops.retrieval_workspace_bytes(b, nc, sd), dtype=torch.uint8, device=self.dev)
+        self.ws = self._ws_by_mode[negatives]
+        if negatives == "global" and not hasattr(self, "c_all"):
+            self.c_all = torch.empty(nc, sd, device=self.dev)
+            self.dc_all = torch.empty(nc, sd, device=self.dev)
+        self.negatives = negatives
+
     def init_synthetic(self, seed: int):
         """Same values as the single-GPU trainer / oracle.synthetic_state: each rank fills only its rows."""
         import math
