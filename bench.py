@@ -325,7 +325,7 @@ def main():
                                    "input, from an un-fused detail pass) + the sparse apply (segmented sums, fused SGD/Adagrad, "
                                    "arrival-ticket finish; all tables; timed as its own launch in the un-fused detail pass - in the "
                                    "step it shares ONE launch with the dense tower update: optimizer_launch_us). EXCLUDED and "
-                                   "reported beside it: lds_sort_kernel (the plan: one launch for all tables on a side stream, "
+                                   "reported beside it: part_sort_kernel (the plan: one launch for all tables on a side stream, "
                                    "concurrent with the forward pass). hipEvent brackets add ~3 us to kernels this short; "
                                    "rocprof durations: profiles/",
                          "achieved": gs_bytes / t_gs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -201,6 +201,201 @@ __global__ __launch_bounds__(1024) void lds_sort_kernel(SortBatch batch) {
   }
 }
 
+// ---- partitioned sort: G workgroups per table, NO inter-workgroup synchronisation ---------------------------------
+// One workgroup sorting 8192 ids takes 23-33 us (VALU-bound by the ballots).  Here workgroup g of a table owns the key
+// range [g << rshift, (g+1) << rshift): it scans ALL n ids (L2-resident, 64-128 KB), counts the keys below its range
+// (= its offset in the sorted output) and compacts its own keys into LDS in position order (ballots + a scan of the
+// per-(load, wave) counts), radix-sorts only those (n/G of them on average, low bits only) and writes them at its
+// offset.  Every workgroup derives everything it needs from the ids themselves.  Skew only unbalances the work: one hot
+// range is at worst the single-workgroup sort again (capacity = the whole list).  n <= 16384 (positions as u16, one
+// workgroup's LDS can hold every id).
+struct PartTable {
+  const int64_t* ids;
+  int64_t* sorted_ids;
+  int32_t* order;
+  int64_t num_rows;
+  int32_t n, groups, rshift, npass;
+  uint32_t sentinel;
+};
+struct PartBatch {
+  PartTable t[kMaxTables];
+  int32_t cap;   // LDS capacity in ids: the longest list of the launch, rounded up to 1024
+};
+
+template <int DBITS, int RMAX>
+__device__ __forceinline__ void part_local_sort(const PartTable& t, uint32_t* keys, uint16_t* poss, uint32_t* cnt, uint32_t* wtot,
+                                                uint32_t m, uint32_t offset, uint32_t base_key) {
+  constexpr int RADIX = 1 << DBITS;
+  constexpr int W = 16, T = 1024;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // element e = (w * rounds + r) * 64 + lane
+  const int rounds = (int)((m + T - 1) / T);
+  uint32_t key[RMAX], pos[RMAX];
+#pragma unroll
+  for (int r = 0; r < RMAX; ++r) {
+    key[r] = 0xffffffffu; pos[r] = 0u;
+    if (r < rounds) {
+      const uint32_t e = (uint32_t)((w * rounds + r) * 64 + lane);
+      if (e < m) { key[r] = keys[e]; pos[r] = poss[e]; }
+    }
+  }
+  uint32_t* mycnt = cnt + w * RADIX;
+  for (int p = 0; p < t.npass; ++p) {
+    __syncthreads();                                        // the loads above / of the previous pass are done
+    const int shift = p * DBITS;
+    for (int j = lane; j < RADIX; j += 64) mycnt[j] = 0u;
+    uint32_t dg[RMAX], rk[RMAX], lead[RMAX], old[RMAX];
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+      if (r < rounds) {
+        dg[r] = (key[r] >> shift) & (RADIX - 1);
+        const uint64_t peers = match_any<DBITS>(dg[r]);
+        rk[r] = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+        lead[r] = (uint32_t)__ffsll((unsigned long long)peers) - 1u;
+        old[r] = (uint32_t)__popcll(peers);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r)
+      if (r < rounds && rk[r] == 0u) old[r] = atomicAdd(&mycnt[dg[r]], old[r]);
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r)
+      if (r < rounds) old[r] = (uint32_t)__shfl((int)old[r], (int)lead[r]) + rk[r];
+    __syncthreads();
+    uint32_t v[W], total = 0u;
+    if (tid < RADIX) {
+#pragma unroll
+      for (int ww = 0; ww < W; ++ww) v[ww] = cnt[ww * RADIX + tid];
+#pragma unroll
+      for (int ww = 0; ww < W; ++ww) {
+        const uint32_t x = v[ww];
+        v[ww] = total;
+        total += x;
+      }
+    }
+    uint32_t inc2 = total;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)inc2, o);
+      if (lane >= o) inc2 += up;
+    }
+    if (lane == 63) wtot[w] = inc2;
+    __syncthreads();
+    if (tid < RADIX) {
+      uint32_t base = inc2 - total;
+      for (int ww = 0; ww < w; ++ww) base += wtot[ww];
+#pragma unroll
+      for (int ww = 0; ww < W; ++ww) cnt[ww * RADIX + tid] = base + v[ww];
+    }
+    __syncthreads();
+    if (p + 1 < t.npass) {
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r)
+        if (r < rounds) {
+          const uint32_t dst = mycnt[dg[r]] + old[r];
+          keys[dst] = key[r];
+          poss[dst] = (uint16_t)pos[r];
+        }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r)
+        if (r < rounds) {
+          const uint32_t e = (uint32_t)((w * rounds + r) * 64 + lane);
+          key[r] = keys[e];            // slots >= m hold the padding (all-ones key, sorted last by every pass)
+          pos[r] = poss[e];
+        }
+    } else {
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r)
+        if (r < rounds) {
+          const uint32_t dst = mycnt[dg[r]] + old[r];
+          if (dst < m) {
+            t.sorted_ids[offset + dst] = (int64_t)(key[r] + base_key);
+            t.order[offset + dst] = (int32_t)pos[r];
+          }
+        }
+    }
+  }
+}
+
+template <int DBITS>
+__global__ __launch_bounds__(1024) void part_sort_kernel(PartBatch batch) {
+  constexpr int RADIX = 1 << DBITS;
+  constexpr int W = 16, T = 1024, JMAX = kMaxLdsSortIds / T;   // 16 loads per thread
+  const PartTable t = batch.t[blockIdx.y];
+  const int g = blockIdx.x;
+  if (g >= t.groups) return;
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  uint32_t* keys = smem;                                    // [cap]
+  uint32_t* cnt = keys + batch.cap;                         // [W][RADIX]
+  uint32_t* cjw = cnt + W * RADIX;                          // [JMAX][W] own-range keys per (load, wave) -> exclusive bases
+  uint32_t* wtot = cjw + JMAX * W;                          // [16] scan partials
+  uint32_t* wbel = wtot + 16;                               // [16] keys below the range, per wave
+  uint16_t* poss = reinterpret_cast<uint16_t*>(wbel + 16);  // [cap]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int n = t.n, J = (n + T - 1) / T;
+
+  // ---- scan: every id of the table; clamp; which range ----
+  uint32_t kj[JMAX];
+#pragma unroll
+  for (int j = 0; j < JMAX; ++j) {
+    const int i = j * T + tid;
+    const int64_t id = t.ids[(j < J && i < n) ? i : 0];
+    kj[j] = (j < J && i < n) ? ((id >= 0 && id < t.num_rows) ? (uint32_t)id : t.sentinel) : 0xffffffffu;   // past n: no range
+  }
+  uint32_t below = 0u;
+#pragma unroll
+  for (int j = 0; j < JMAX; ++j) {
+    if (j < J) {
+      const uint32_t b = kj[j] >> t.rshift;
+      const uint64_t mine = __builtin_amdgcn_ballot_w64(b == (uint32_t)g);
+      below += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(b < (uint32_t)g));
+      if (lane == 0) cjw[j * W + w] = (uint32_t)__popcll(mine);
+    }
+  }
+  if (lane == 0) wbel[w] = below;
+  __syncthreads();
+  // exclusive scan of the (load, wave) counts in position order (j major, wave minor); m = keys of this range
+  uint32_t val = (tid < J * W) ? cjw[tid] : 0u, incl = val;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+    if (lane >= o) incl += up;
+  }
+  if (lane == 63) wtot[w] = incl;
+  __syncthreads();
+  uint32_t pre = 0u, m = 0u, offset = 0u;
+  for (int ww = 0; ww < W; ++ww) {
+    const uint32_t x = wtot[ww];
+    if (ww < w) pre += x;
+    m += x;
+    offset += wbel[ww];
+  }
+  __syncthreads();                                          // everyone has read cjw / wtot
+  if (tid < J * W) cjw[tid] = pre + incl - val;
+  __syncthreads();
+  // ---- compaction in position order: local key (range base removed) + position ----
+#pragma unroll
+  for (int j = 0; j < JMAX; ++j) {
+    if (j < J) {
+      const bool mine = (kj[j] >> t.rshift) == (uint32_t)g;
+      const uint64_t mask = __builtin_amdgcn_ballot_w64(mine);
+      if (mine) {
+        const uint32_t dst = cjw[j * W + w] + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        keys[dst] = kj[j] - ((uint32_t)g << t.rshift);
+        poss[dst] = (uint16_t)(j * T + tid);
+      }
+    }
+  }
+  __syncthreads();
+  if (m == 0u) return;
+  // ---- LSD radix sort of the m compacted (local key, position) pairs; the register arrays sized by the rounds needed ----
+  const uint32_t base_key = (uint32_t)g << t.rshift;
+  if (m <= 2u * T) part_local_sort<DBITS, 2>(t, keys, poss, cnt, wtot, m, offset, base_key);
+  else if (m <= 6u * T) part_local_sort<DBITS, 6>(t, keys, poss, cnt, wtot, m, offset, base_key);
+  else part_local_sort<DBITS, 16>(t, keys, poss, cnt, wtot, m, offset, base_key);
+}
+
 int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
 struct ClampKey {
@@ -258,6 +453,45 @@ extern "C" int64_t tt_sparse_plan_workspace_bytes(int64_t n_ids) {
 }
 
 namespace {
+// TT_SORT_GROUPS: 0 = the single-workgroup sort for every list (A/B), k > 0 = force k partitions, unset = n / 256
+// (8192 ids -> 32 workgroups per table: measured 2 tables x 8192 ids 21-25 us single-workgroup -> 9.5-10.9 us, Zipf ids
+// 14-17 us; 128 groups buy another 1-3 us but take every CU from the forward GEMMs the plan runs beside).
+int env_sort_groups() {
+  static const int v = [] {
+    const char* e = std::getenv("TT_SORT_GROUPS");
+    return e ? std::atoi(e) : -1;
+  }();
+  return v;
+}
+
+int part_groups(int n, int bits) {
+  const int forced = env_sort_groups();
+  const int want = forced > 0 ? forced : (n + 255) / 256, cap = forced > 0 ? 256 : 128;
+  int g = 1, lg = 0;
+  while (g < want && g < cap && lg < bits) { g <<= 1; ++lg; }
+  return g;
+}
+
+int launch_part(PartBatch& b, int nb, int max_n, int max_groups, int max_lbits, hipStream_t stream) {
+  const int npass9 = (max_lbits + 8) / 9, npass8 = (max_lbits + 7) / 8;
+  const bool nine = npass9 < npass8;
+  for (int i = 0; i < nb; ++i) {
+    const int lb = b.t[i].rshift;
+    const int np = nine ? (lb + 8) / 9 : (lb + 7) / 8;
+    b.t[i].npass = np < 1 ? 1 : np;
+  }
+  b.cap = (max_n + 1023) / 1024 * 1024;
+  const int radix = nine ? 512 : 256;
+  const int lds = (b.cap + 16 * radix + 16 * 16 + 32) * 4 + b.cap * 2;
+  auto kern = nine ? part_sort_kernel<9> : part_sort_kernel<8>;
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+    return tt::fail(TT_ERR_LAUNCH, "tt_sparse_plan: hipFuncSetAttribute(LDS %d) failed", lds);
+  tt::ProfScope prof("sparse_plan", stream);
+  hipLaunchKernelGGL(kern, dim3((unsigned)max_groups, (unsigned)nb), dim3(1024), lds, stream, b);
+  return tt::check_launch("tt_sparse_plan(partitioned)");
+}
+
 int launch_entries(SortBatch& b, int nb, int max_n, int max_bits, hipStream_t stream) {
   // digits: 8 bits when the passes needed are the same as with 9 (fewer ballots, smaller counter table)
   const int npass9 = (max_bits + 8) / 9, npass8 = (max_bits + 7) / 8;
@@ -277,8 +511,10 @@ extern "C" int tt_sparse_plan_batched(const tt_sparse_plan_args* tables, int32_t
   TT_REQUIRE(tables != nullptr && n_tables >= 1 && n_tables <= kMaxTables, "tt_sparse_plan_batched: 1..%d tables", kMaxTables);
   hipStream_t stream = tt::as_stream(stream_);
   SortBatch b{};
+  PartBatch pb{};
   MergeArgs merges[kMaxTables];
   int nb = 0, max_n = 0, max_bits = 0, n_merge = 0, rc;
+  int npb = 0, p_max_n = 0, p_max_groups = 0, p_max_lbits = 0;
   for (int i = 0; i < n_tables; ++i) {
     const tt_sparse_plan_args& a = tables[i];
     TT_REQUIRE(a.n_ids >= 0 && a.num_rows > 0, "tt_sparse_plan: bad n_ids/num_rows");
@@ -289,6 +525,19 @@ extern "C" int tt_sparse_plan_batched(const tt_sparse_plan_args* tables, int32_t
     const int chunks = (int)((a.n_ids + kMaxLdsSortIds - 1) / kMaxLdsSortIds);
     if (chunks > kMaxChunks || bits > 31) {   // very long id lists: rocPRIM, one table at a time
       if ((rc = plan_rocprim(a, stream)) != TT_OK) return rc;
+      continue;
+    }
+    if (chunks == 1 && env_sort_groups() != 0) {   // one list that fits a workgroup's LDS: key-range partitions, one launch
+      PartTable& t = pb.t[npb++];
+      t.ids = a.ids; t.sorted_ids = a.sorted_ids; t.order = a.order; t.num_rows = a.num_rows; t.n = (int32_t)a.n_ids;
+      t.groups = part_groups(t.n, bits);
+      int lg = 0;
+      while ((1 << lg) < t.groups) ++lg;
+      t.rshift = bits - lg;
+      t.sentinel = (uint32_t)(((uint64_t)1 << bits) - 1);
+      if (t.n > p_max_n) p_max_n = t.n;
+      if (t.groups > p_max_groups) p_max_groups = t.groups;
+      if (t.rshift > p_max_lbits) p_max_lbits = t.rshift;
       continue;
     }
     int64_t* keys_out = a.sorted_ids;
@@ -316,6 +565,7 @@ extern "C" int tt_sparse_plan_batched(const tt_sparse_plan_args* tables, int32_t
       if (bits > max_bits) max_bits = bits;
     }
   }
+  if (npb > 0 && (rc = launch_part(pb, npb, p_max_n, p_max_groups, p_max_lbits, stream)) != TT_OK) return rc;
   if (nb > 0 && (rc = launch_entries(b, nb, max_n, max_bits, stream)) != TT_OK) return rc;
   for (int i = 0; i < n_merge; ++i) {
     tt::ProfScope prof("sparse_plan", stream);

@@ -234,7 +234,7 @@ class SparsePlan:
 
 
 def sparse_plan_batched(plans, ids_list, num_rows_list):
-    """Sort up to 4 id lists (user, item, hashed category, ...) in ONE launch: one workgroup per table."""
+    """Sort up to 4 id lists (user, item, hashed category, ...) in ONE launch (key-range partitions: csrc/sort.hip)."""
     n = len(plans)
     args = []
     for plan, ids, rows in zip(plans, ids_list, num_rows_list):

@@ -372,7 +372,7 @@ class TwoTowerTrainer:
         # the sort plans depend on the ids only: they run on a side stream beside the forward/backward pass
         main = torch.cuda.current_stream()
         self._side.wait_stream(main)
-        with torch.cuda.stream(self._side):        # one launch: one workgroup per table (csrc/sort.hip)
+        with torch.cuda.stream(self._side):        # one launch for all tables (csrc/sort.hip)
             plans, ids, rows = [self.user_plan, self.item_plan], [user_ids, item_ids], [self.cfg.n_users, self.cfg.n_items]
             if loss_kw.get("category_ids") is not None and self.cat_plan is not None:
                 plans.append(self.cat_plan); ids.append(loss_kw["category_ids"]); rows.append(self.cfg.n_category_buckets)
