@@ -303,7 +303,13 @@ def main():
         return sum(prof[tag]) / steps_of[tag]
     # K2 apply: in the step it is half of the single optimizer launch; its own duration comes from the un-fused detail pass
     apply_ms = (sum(unfused["sparse_apply"]) / detail_steps) if unfused.get("sparse_apply") else per_step("sparse_apply")
-    t_gs = max((per_step("gather") + apply_ms) * 1e-3 + max(lookup_us or 0.0, 0.0) * 1e-6, 1e-12)
+    t_gs_noplan = max((per_step("gather") + apply_ms) * 1e-3 + max(lookup_us or 0.0, 0.0) * 1e-6, 1e-12)
+    plan_on_main = not trainer.plan_on_side_stream
+    plan_bytes = 20 * batch * (2 + (1 if cfg.n_category_buckets else 0))     # id read + sorted id + position written, per table
+    # the plan is on the step's critical path when it runs on the main stream (the default): then it is COUNTED
+    t_gs = t_gs_noplan + (per_step("sparse_plan") * 1e-3 if plan_on_main else 0.0)
+    if plan_on_main:
+        gs_bytes += plan_bytes
     out = {
         "metric": "user-item pairs/sec (train step) + embedding-gather HBM GB/s, 1/2/4/8 MI355X",
         "value": batch / (dt / args.steps), "unit": "pairs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -324,10 +330,13 @@ def main():
                                    "loaders (time = what the layer-0 fwd and bwd launches cost MORE than on a materialised "
                                    "input, from an un-fused detail pass) + the sparse apply (segmented sums, fused SGD/Adagrad, "
                                    "arrival-ticket finish; all tables; timed as its own launch in the un-fused detail pass - in the "
-                                   "step it shares ONE launch with the dense tower update: optimizer_launch_us). EXCLUDED and "
-                                   "reported beside it: part_sort_kernel (the plan: one launch for all tables on a side stream, "
-                                   "concurrent with the forward pass). hipEvent brackets add ~3 us to kernels this short; "
-                                   "rocprof durations: profiles/",
+                                   "step it shares ONE launch with the dense tower update: optimizer_launch_us) + "
+                                   + ("part_sort_kernel (the sort plan: one launch for all tables, on the main stream in front "
+                                      "of the forward pass). " if plan_on_main else
+                                      "EXCLUDED and reported beside it: part_sort_kernel (the plan: one launch for all tables on "
+                                      "a side stream, concurrent with the forward pass; TT_PLAN_STREAM=side). ")
+                                   + "Each hipEvent bracket adds ~3 us to kernels this short (frac is a lower bound); rocprof "
+                                     "durations of the same kernels: profiles/",
                          "achieved": gs_bytes / t_gs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": gs_bytes / t_gs / 1e9 / HBM_PEAK_GBS,
                          "traffic": None,
@@ -337,8 +346,9 @@ def main():
                          "sparse_apply_us": apply_ms * 1e3,
                          "optimizer_launch_us": per_step("optimizer") * 1e3,
                          "unfused_dense_update_us": (mean(unfused["dense_update"]) * 1e3) if unfused.get("dense_update") else None,
-                         "sparse_plan_us_side_stream": per_step("sparse_plan") * 1e3,
-                         "frac_with_plan_counted": gs_bytes / (t_gs + per_step("sparse_plan") * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "sparse_plan_us": per_step("sparse_plan") * 1e3,
+                         "sparse_plan_stream": "main" if plan_on_main else "side",
+                         "frac_without_plan": (gs_bytes - (plan_bytes if plan_on_main else 0)) / t_gs_noplan / 1e9 / HBM_PEAK_GBS,
                          "algorithmic_bytes": gs_bytes},
         "loss_per_pair": loss / batch,
     }

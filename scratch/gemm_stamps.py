@@ -44,3 +44,12 @@ run("bwd L1 dx only", lambda: ops.dense_bwd2((ut.acts[1], it.acts[1]), (ut.w[1],
                                              (ut.acts[1], it.acts[1]), none2, none2), 1024)
 run("bwd L1 dw only", lambda: ops.dense_bwd2((ut.acts[1], it.acts[1]), (ut.w[1], it.w[1]), (ut.dz[1], it.dz[1]), none2, none2,
                                              (ut.dw_slabs[1], it.dw_slabs[1]), (ut.db_slabs[1], it.db_slabs[1])), 512)
+run("bwd L1 dx+dw", lambda: ops.dense_bwd2((ut.acts[1], it.acts[1]), (ut.w[1], it.w[1]), (ut.dz[1], it.dz[1]), (ut.dz[0], it.dz[0]),
+                                           (ut.acts[1], it.acts[1]), (ut.dw_slabs[1], it.dw_slabs[1]), (ut.db_slabs[1], it.db_slabs[1])), 1536)
+run("bwd L0 dx+dw (lookup)", lambda: ops.dense_bwd2((None, None), (ut.w[0], it.w[0]), (ut.dz[0], it.dz[0]), (ut.demb, it.demb),
+                                                    none2, (ut.dw_slabs[0], it.dw_slabs[0]), (ut.db_slabs[0], it.db_slabs[0]),
+                                                    lookups=tr._lookups(u, i, None)), 1024)
+run("bwd L1 dx only, NO mask", lambda: ops.dense_bwd2((ut.acts[1], it.acts[1]), (ut.w[1], it.w[1]), (ut.dz[1], it.dz[1]), (ut.dz[0], it.dz[0]),
+                                                      none2, none2, none2), 1024)
+run("bwd L0 dx only", lambda: ops.dense_bwd2((ut.acts[0], it.acts[0]) if ut.acts[0] is not None else (ut.demb, it.demb), (ut.w[0], it.w[0]), (ut.dz[0], it.dz[0]), (ut.demb, it.demb),
+                                             none2, none2, none2), 512)

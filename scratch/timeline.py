@@ -6,8 +6,13 @@ cnt = collections.Counter(r["Queue_Id"] for r in rows if "score_kernel" in r["Ke
 q = cnt.most_common(1)[0][0]
 rows = sorted((r for r in rows if r["Queue_Id"] == q), key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "")[:46] for r in rows]
-g = [i for i, n in enumerate(names) if n.startswith("gather_kernel")]
-steps = [(g[k], g[k + 1]) for k in range(len(g) - 1)][-150:]
+g = [i for i, n in enumerate(names) if n.startswith("gemm_kernel<true, false, false, 1")]   # layer-0 forward (fused lookup) opens a step
+steps = [(g[k], g[k + 1]) for k in range(len(g) - 1)]
+# the timed region's steps only: the usual kernel count, exact-f32 scorer, fused optimizer launch
+steps = [(a, b) for a, b in steps if b - a <= 12 and any("score_kernel<128, 2, false, false, 4, 0>" in names[j] for j in range(a, b))
+         and any(names[j].startswith("optimizer_kernel") for j in range(a, b))]
+mode = collections.Counter(b - a for a, b in steps).most_common(1)[0][0]
+steps = [(a, b) for a, b in steps if b - a == mode][-150:]
 agg, gaps, wall = collections.OrderedDict(), collections.OrderedDict(), 0
 for a, b in steps:
     wall += int(rows[b]["Start_Timestamp"]) - int(rows[a]["Start_Timestamp"])

@@ -362,6 +362,7 @@ struct BwdBatch {
   int dx_gm, dx_gn;      // dx tiles per problem: dx_gm x dx_gn
   int dw_gm, dw_gn;      // dw tiles per problem and split
   int dw_first;          // 1: the dw tiles take the first workgroup indices (when their k-range is the longer one)
+  int dx_pair;           // 1: a dx workgroup computes TWO column tiles (by, by + dx_gn/2) of its row block, one after the other
 };
 
 template <int GK>
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(256, (GK > 256 ? 3 : 4)) void gemm_bwd_kernel(BwdBa
   __shared__ int32_t gids[kGidsInts(GK, true)];
   const int per_split = pb.dw_gm * pb.dw_gn;
   const int per_w = per_split * pb.splits;
-  const int per_x = pb.dx_gm * pb.dx_gn;
+  const int per_x = pb.dx_gm * (pb.dx_pair ? pb.dx_gn / 2 : pb.dx_gn);     // dx WORKGROUPS per problem
   const int n_dw = pb.nprob * per_w, n_dx = pb.nprob * per_x;
   // longest tiles first: workgroups are dispatched in index order, so the short tiles fill the tail
   int b = blockIdx.x;
@@ -396,6 +397,10 @@ __global__ __launch_bounds__(256, (GK > 256 ? 3 : 4)) void gemm_bwd_kernel(BwdBa
     const int prob = b / per_x;
     b -= prob * per_x;
     gemm_tile<true, true, false, 0>(pb.ax[prob], 0, b % pb.dx_gm, b / pb.dx_gm, smem, gids);
+    if (pb.dx_pair) {
+      __syncthreads();                               // every wave is done with the first tile's LDS buffers
+      gemm_tile<true, true, false, 0>(pb.ax[prob], 0, b % pb.dx_gm, b / pb.dx_gm + pb.dx_gn / 2, smem, gids);
+    }
   }
 }
 
@@ -543,7 +548,13 @@ extern "C" int tt_dense_bwd_batched_f32(const tt_dense_bwd_args* probs, int32_t 
     pb.dx_gm = (int)((ax[0].M + BM - 1) / BM); pb.dx_gn = (int)((ax[0].N + BN - 1) / BN);
     pb.dw_gm = (int)((aw[0].M + BM - 1) / BM); pb.dw_gn = (int)((aw[0].N + BN - 1) / BN);
     pb.dw_first = aw[0].k_per_split > ax[0].k_per_split;     // k-tiles per tile: batch/splits rows vs n columns
-    const int64_t blocks = (int64_t)n_probs * ((int64_t)pb.dx_gm * pb.dx_gn + (int64_t)pb.dw_gm * pb.dw_gn * splits);
+    // 4 workgroups per CU are resident (LDS, VGPRs): 1024 on the chip.  When the launch has more AND a dx tile is at most
+    // half as long as a dw tile (layer 1 of cfg3: 1024 dx tiles of 4 k-tiles + 512 dw tiles of 8), the extra workgroups start
+    // when the first ones retire and the launch runs 1.5 rounds (r02 stamps: 512 workgroups started ~20 us late, end 39.7 us,
+    // median workgroup end 22.8 us).  Pairing two dx tiles per workgroup makes every workgroup equally long and all resident.
+    const int64_t dx_tiles = (int64_t)pb.dx_gm * pb.dx_gn, dw_tiles = (int64_t)pb.dw_gm * pb.dw_gn * splits;
+    pb.dx_pair = (n_probs * (dx_tiles + dw_tiles) > 1024 && pb.dx_gn % 2 == 0 && 2 * ax[0].k_per_split <= aw[0].k_per_split) ? 1 : 0;
+    const int64_t blocks = (int64_t)n_probs * (dx_tiles / (pb.dx_pair ? 2 : 1) + dw_tiles);
     TT_REQUIRE(blocks <= 0x7fffffff && (ax[0].M + BM - 1) / BM <= 0x3fffffff, "tt_dense_bwd_f32: grid too large");
     tt::ProfScope prof("dense_bwd", stream);
     if (gather && aw[0].k_per_split <= 256) hipLaunchKernelGGL(gemm_bwd_kernel<256>, dim3((unsigned)blocks), dim3(256), 0, stream, pb);

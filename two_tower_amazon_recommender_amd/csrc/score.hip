@@ -120,7 +120,7 @@ __device__ __forceinline__ Bf3 split3(float x) {
 __device__ __forceinline__ int img_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
 
 template <int D, int MODE, bool HAS_IDS, bool HAS_HN, int WAVES, int PREC>
-__global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? 2 : 1))) void score_kernel(ScoreArgs p) {
+__global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? 2 : 1))) void score_kernel(ScoreArgs p) {   // (min waves per SIMD)
   using G_ = Geo<D, PREC>;
   constexpr int LS = G_::LS, NG = G_::NG, NB = G_::NB, TILE_F = G_::TILE_F, BUF_F = G_::BUF_F;
   constexpr int KS = G_::KS, HALF_B = G_::HALF_B, PIECE_B = G_::PIECE_B;
@@ -960,11 +960,17 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const f32x4* __restri
 
 // ---- host side --------------------------------------------------------------------------------
 
+#ifndef TT_SCORE_WAVES
+#define TT_SCORE_WAVES 4      // waves (32-row fragments) per workgroup of the exact-f32 passes
+#endif
+#ifndef TT_SCORE_WGS
+#define TT_SCORE_WGS 512      // workgroups a pass aims for (two 4-wave workgroups per CU)
+#endif
 int choose_nsplit(int64_t n_r, int64_t n_c) {
-  const int64_t nrb = (n_r + 127) / 128;
+  const int64_t nrb = (n_r + 32 * TT_SCORE_WAVES - 1) / (32 * TT_SCORE_WAVES);
   int ns = 1;
   // 512 workgroups = two per CU measured best at B = 8192 (256: 291 us, 512: 272 us, 1024: 283 us, 2048: 294 us per launch)
-  while (nrb * ns < 512 && (int64_t)ns * 2 * 64 <= n_c && ns < 64) ns *= 2;
+  while (nrb * ns < TT_SCORE_WGS && (int64_t)ns * 2 * 64 <= n_c && ns < 64) ns *= 2;
   return ns;
 }
 
@@ -1003,7 +1009,7 @@ WsLayout ws_layout(int64_t nq, int64_t nc, int32_t dim) {
 // MFMA runs at the f32 vector rate; a 25 % cut of the epilogue's VALU instructions changed nothing measurable, so the
 // cost is in the GEMM1 -> epilogue -> GEMM2 dependency hand-offs rather than in VALU throughput).
 template <int D, int MODE, int PREC = 0>
-constexpr int waves_for() { return (PREC == 1 && D == 128) ? 8 : 4; }     // bf16x3 at dim 128: 256-row workgroups, one per CU
+constexpr int waves_for() { return (PREC == 1 && D == 128) ? 8 : (PREC == 1 ? 4 : TT_SCORE_WAVES); }     // bf16x3 at dim 128: 256-row workgroups, one per CU
 
 template <int D, int MODE, int PREC = 0>
 int launch_score(const ScoreArgs& a_in, bool has_ids, hipStream_t stream) {

@@ -202,19 +202,21 @@ __global__ __launch_bounds__(1024) void lds_sort_kernel(SortBatch batch) {
 }
 
 // ---- partitioned sort: G workgroups per table, NO inter-workgroup synchronisation ---------------------------------
-// One workgroup sorting 8192 ids takes 23-33 us (VALU-bound by the ballots).  Here workgroup g of a table owns the key
-// range [g << rshift, (g+1) << rshift): it scans ALL n ids (L2-resident, 64-128 KB), counts the keys below its range
-// (= its offset in the sorted output) and compacts its own keys into LDS in position order (ballots + a scan of the
-// per-(load, wave) counts), radix-sorts only those (n/G of them on average, low bits only) and writes them at its
-// offset.  Every workgroup derives everything it needs from the ids themselves.  Skew only unbalances the work: one hot
-// range is at worst the single-workgroup sort again (capacity = the whole list).  n <= 16384 (positions as u16, one
-// workgroup's LDS can hold every id).
+// One workgroup sorting 8192 ids takes 21-33 us (VALU-bound by the ballots).  Here workgroup g of a table owns the key
+// range [g * width, (g+1) * width) of the rows (width = ceil(rows / G); the last group also takes the out-of-range
+// sentinel): it scans ALL n ids (L2-resident, 64-128 KB), counts the keys below its range (= its offset in the sorted
+// output) and compacts its own keys into LDS in position order (ballots + a scan of the per-(load, wave) counts), then
+// sorts only those - n/G ~ 128 of them, ranked by counting in one step; a hot range (> 512 keys) by LSD radix passes over
+// its local key bits - and writes them at its offset.  Every workgroup derives everything it needs from the ids
+// themselves.  Skew only unbalances the work: one hot range is at worst the single-workgroup sort again (capacity = the
+// whole list).  n <= 16384 (positions as u16, one workgroup's LDS can hold every id).
 struct PartTable {
   const int64_t* ids;
   int64_t* sorted_ids;
   int32_t* order;
   int64_t num_rows;
-  int32_t n, groups, rshift, npass;
+  int32_t n, groups;
+  uint32_t width, magic;     // key range of a group = width ids (the last group also takes the sentinel); magic = 2^32 / width + 1
   uint32_t sentinel;
 };
 struct PartBatch {
@@ -224,7 +226,7 @@ struct PartBatch {
 
 template <int DBITS, int RMAX>
 __device__ __forceinline__ void part_local_sort(const PartTable& t, uint32_t* keys, uint16_t* poss, uint32_t* cnt, uint32_t* wtot,
-                                                uint32_t m, uint32_t offset, uint32_t base_key) {
+                                                uint32_t m, uint32_t offset, uint32_t base_key, int npass) {
   constexpr int RADIX = 1 << DBITS;
   constexpr int W = 16, T = 1024;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -240,7 +242,7 @@ __device__ __forceinline__ void part_local_sort(const PartTable& t, uint32_t* ke
     }
   }
   uint32_t* mycnt = cnt + w * RADIX;
-  for (int p = 0; p < t.npass; ++p) {
+  for (int p = 0; p < npass; ++p) {
     __syncthreads();                                        // the loads above / of the previous pass are done
     const int shift = p * DBITS;
     for (int j = lane; j < RADIX; j += 64) mycnt[j] = 0u;
@@ -288,7 +290,7 @@ __device__ __forceinline__ void part_local_sort(const PartTable& t, uint32_t* ke
       for (int ww = 0; ww < W; ++ww) cnt[ww * RADIX + tid] = base + v[ww];
     }
     __syncthreads();
-    if (p + 1 < t.npass) {
+    if (p + 1 < npass) {
 #pragma unroll
       for (int r = 0; r < RMAX; ++r)
         if (r < rounds) {
@@ -318,22 +320,39 @@ __device__ __forceinline__ void part_local_sort(const PartTable& t, uint32_t* ke
   }
 }
 
-template <int DBITS>
+// key range of a (clamped) key: key / width by multiply-high + one correction, capped to the last group (which also
+// takes the sentinel 2^bits - 1 of the out-of-range ids); ids past n carry 0xffffffff and belong to no group
+__device__ __forceinline__ uint32_t bucket_of(uint32_t key, const PartTable& t) {
+  if (key == 0xffffffffu) return 0xffffffffu;
+  uint32_t q = __umulhi(key, t.magic);
+  q -= (q * t.width > key) ? 1u : 0u;
+  return q < (uint32_t)t.groups ? q : (uint32_t)t.groups - 1u;
+}
+
+#ifdef TT_SORT_STAMPS
+__device__ unsigned long long g_sort_stamps[1024 * 8];
+#define SSTAMP(i) do { if (threadIdx.x == 0) g_sort_stamps[((blockIdx.x + gridDim.x * blockIdx.y) % 1024) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SSTAMP(i) do {} while (0)
+#endif
+
+template <int DBITS, int JMAX>     // JMAX: ids per thread of the scan (8: lists <= 8192, 16: <= 16384)
 __global__ __launch_bounds__(1024) void part_sort_kernel(PartBatch batch) {
   constexpr int RADIX = 1 << DBITS;
-  constexpr int W = 16, T = 1024, JMAX = kMaxLdsSortIds / T;   // 16 loads per thread
+  constexpr int W = 16, T = 1024;
   const PartTable t = batch.t[blockIdx.y];
   const int g = blockIdx.x;
   if (g >= t.groups) return;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint32_t* keys = smem;                                    // [cap]
-  uint32_t* cnt = keys + batch.cap;                         // [W][RADIX]
+  uint32_t* cnt = keys + batch.cap + 64;                    // [W][RADIX]   (keys: cap + 64 slots of padding)
   uint32_t* cjw = cnt + W * RADIX;                          // [JMAX][W] own-range keys per (load, wave) -> exclusive bases
   uint32_t* wtot = cjw + JMAX * W;                          // [16] scan partials
   uint32_t* wbel = wtot + 16;                               // [16] keys below the range, per wave
   uint16_t* poss = reinterpret_cast<uint16_t*>(wbel + 16);  // [cap]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int n = t.n, J = (n + T - 1) / T;
+  SSTAMP(0);
 
   // ---- scan: every id of the table; clamp; which range ----
   uint32_t kj[JMAX];
@@ -347,14 +366,16 @@ __global__ __launch_bounds__(1024) void part_sort_kernel(PartBatch batch) {
 #pragma unroll
   for (int j = 0; j < JMAX; ++j) {
     if (j < J) {
-      const uint32_t b = kj[j] >> t.rshift;
+      const uint32_t b = bucket_of(kj[j], t);
       const uint64_t mine = __builtin_amdgcn_ballot_w64(b == (uint32_t)g);
       below += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(b < (uint32_t)g));
       if (lane == 0) cjw[j * W + w] = (uint32_t)__popcll(mine);
     }
   }
   if (lane == 0) wbel[w] = below;
+  SSTAMP(1);
   __syncthreads();
+  SSTAMP(2);
   // exclusive scan of the (load, wave) counts in position order (j major, wave minor); m = keys of this range
   uint32_t val = (tid < J * W) ? cjw[tid] : 0u, incl = val;
 #pragma unroll
@@ -374,26 +395,63 @@ __global__ __launch_bounds__(1024) void part_sort_kernel(PartBatch batch) {
   __syncthreads();                                          // everyone has read cjw / wtot
   if (tid < J * W) cjw[tid] = pre + incl - val;
   __syncthreads();
+  SSTAMP(3);
   // ---- compaction in position order: local key (range base removed) + position ----
 #pragma unroll
   for (int j = 0; j < JMAX; ++j) {
     if (j < J) {
-      const bool mine = (kj[j] >> t.rshift) == (uint32_t)g;
+      const bool mine = bucket_of(kj[j], t) == (uint32_t)g;
       const uint64_t mask = __builtin_amdgcn_ballot_w64(mine);
       if (mine) {
         const uint32_t dst = cjw[j * W + w] + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-        keys[dst] = kj[j] - ((uint32_t)g << t.rshift);
+        keys[dst] = kj[j] - (uint32_t)g * t.width;
         poss[dst] = (uint16_t)(j * T + tid);
       }
     }
   }
+  if (tid < 64) keys[m + (uint32_t)tid] = 0xffffffffu;          // padding for the 4-wide rank loop (LDS holds cap + 64 keys)
   __syncthreads();
+  SSTAMP(4);
   if (m == 0u) return;
-  // ---- LSD radix sort of the m compacted (local key, position) pairs; the register arrays sized by the rounds needed ----
-  const uint32_t base_key = (uint32_t)g << t.rshift;
-  if (m <= 2u * T) part_local_sort<DBITS, 2>(t, keys, poss, cnt, wtot, m, offset, base_key);
-  else if (m <= 6u * T) part_local_sort<DBITS, 6>(t, keys, poss, cnt, wtot, m, offset, base_key);
-  else part_local_sort<DBITS, 16>(t, keys, poss, cnt, wtot, m, offset, base_key);
+  const uint32_t base_key = (uint32_t)g * t.width;
+  if (m <= 512u) {
+    // ---- the usual case (n / groups ~ 128 keys): rank by counting, no further barrier.  P = 1024 / pow2(m) threads per
+    // element e, each compares a 1/P slice of the keys: rank = #(smaller keys) + #(equal keys at an earlier position);
+    // the compaction left the keys in position order, so "earlier position" is "smaller index": stable. ----
+    uint32_t lp = 4;                                        // log2 P: 16 threads per element up to 64 keys ... 2 up to 512
+    while ((T >> lp) < m) --lp;
+    const uint32_t e = (uint32_t)tid >> lp, sub = (uint32_t)tid & ((1u << lp) - 1u), P = 1u << lp;
+    const uint32_t key = keys[e < m ? e : 0u];
+    uint32_t c = 0u;
+    // 4 keys per LDS read; the slots m .. m+63 were filled with 0xffffffff (larger than any local key) before the barrier
+    for (uint32_t j = 4u * sub; j < m; j += 4u * P) {
+      const uint4 k4 = *reinterpret_cast<const uint4*>(keys + j);
+      c += (k4.x < key || (k4.x == key && j < e)) ? 1u : 0u;
+      c += (k4.y < key || (k4.y == key && j + 1u < e)) ? 1u : 0u;
+      c += (k4.z < key || (k4.z == key && j + 2u < e)) ? 1u : 0u;
+      c += (k4.w < key || (k4.w == key && j + 3u < e)) ? 1u : 0u;
+    }
+    for (uint32_t o = 1u; o < P; o <<= 1) c += (uint32_t)__shfl_xor((int)c, (int)o);
+    if (sub == 0u && e < m) {
+      t.sorted_ids[offset + c] = (int64_t)(key + base_key);
+      t.order[offset + c] = (int32_t)poss[e];
+    }
+    SSTAMP(5);
+    return;
+  }
+  // ---- a hot key range: LSD radix sort of the m compacted (local key, position) pairs; register arrays by rounds needed;
+  // passes by the bits of this group's largest local key (the last group's is the sentinel's) ----
+  const uint32_t local_max = g == t.groups - 1 ? t.sentinel - base_key : t.width - 1u;
+  const int lbits = 32 - __builtin_clz(local_max | 1u);
+  const int npass = (lbits + DBITS - 1) / DBITS;
+  if constexpr (JMAX <= 8) {
+    if (m <= 2u * T) part_local_sort<DBITS, 2>(t, keys, poss, cnt, wtot, m, offset, base_key, npass);
+    else part_local_sort<DBITS, 8>(t, keys, poss, cnt, wtot, m, offset, base_key, npass);
+  } else {
+    if (m <= 2u * T) part_local_sort<DBITS, 2>(t, keys, poss, cnt, wtot, m, offset, base_key, npass);
+    else if (m <= 6u * T) part_local_sort<DBITS, 6>(t, keys, poss, cnt, wtot, m, offset, base_key, npass);
+    else part_local_sort<DBITS, 16>(t, keys, poss, cnt, wtot, m, offset, base_key, npass);
+  }
 }
 
 int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
@@ -444,6 +502,12 @@ int plan_rocprim(const tt_sparse_plan_args& a, hipStream_t stream) {
 
 }  // namespace
 
+#ifdef TT_SORT_STAMPS
+extern "C" int tt_debug_sort_stamps(unsigned long long* host_out, int n) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_sort_stamps), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 0 : 2;
+}
+#endif
+
 extern "C" int32_t tt_sparse_plan_max_lds_ids(void) { return kMaxLdsSortIds; }
 
 extern "C" int64_t tt_sparse_plan_workspace_bytes(int64_t n_ids) {
@@ -453,9 +517,10 @@ extern "C" int64_t tt_sparse_plan_workspace_bytes(int64_t n_ids) {
 }
 
 namespace {
-// TT_SORT_GROUPS: 0 = the single-workgroup sort for every list (A/B), k > 0 = force k partitions, unset = n / 256
-// (8192 ids -> 32 workgroups per table: measured 2 tables x 8192 ids 21-25 us single-workgroup -> 9.5-10.9 us, Zipf ids
-// 14-17 us; 128 groups buy another 1-3 us but take every CU from the forward GEMMs the plan runs beside).
+// TT_SORT_GROUPS: 0 = the single-workgroup sort for every list (A/B), k > 0 = force k partitions, unset = n / 128
+// (8192 ids -> 64 workgroups per table).  Measured, 2 tables x 8192 ids: 21-25 us single-workgroup -> 9.5-10 us (of which
+// ~9 us is the host call rate of the microbench), Zipf ids 12-15 us; in the cfg3 step (plan on the main stream) 16 / 32 /
+// 64 / 128 groups: 0.6787 / 0.6780 / 0.6766 / 0.6773 ms.
 int env_sort_groups() {
   static const int v = [] {
     const char* e = std::getenv("TT_SORT_GROUPS");
@@ -464,26 +529,24 @@ int env_sort_groups() {
   return v;
 }
 
-int part_groups(int n, int bits) {
+int part_groups(int n, int64_t num_rows) {
   const int forced = env_sort_groups();
-  const int want = forced > 0 ? forced : (n + 255) / 256, cap = forced > 0 ? 256 : 128;
-  int g = 1, lg = 0;
-  while (g < want && g < cap && lg < bits) { g <<= 1; ++lg; }
-  return g;
+  int64_t g = forced > 0 ? forced : (n + 127) / 128;
+  const int64_t cap = forced > 0 ? 256 : 128;
+  if (g > cap) g = cap;
+  if (g > num_rows / 2) g = num_rows / 2;          // a group is at least 2 ids wide (the multiply-high division needs width >= 2)
+  return g < 1 ? 1 : (int)g;
 }
 
 int launch_part(PartBatch& b, int nb, int max_n, int max_groups, int max_lbits, hipStream_t stream) {
+  // digits (hot ranges only): 8 bits when the passes needed are the same as with 9 (fewer ballots, smaller counter table)
   const int npass9 = (max_lbits + 8) / 9, npass8 = (max_lbits + 7) / 8;
   const bool nine = npass9 < npass8;
-  for (int i = 0; i < nb; ++i) {
-    const int lb = b.t[i].rshift;
-    const int np = nine ? (lb + 8) / 9 : (lb + 7) / 8;
-    b.t[i].npass = np < 1 ? 1 : np;
-  }
   b.cap = (max_n + 1023) / 1024 * 1024;
   const int radix = nine ? 512 : 256;
-  const int lds = (b.cap + 16 * radix + 16 * 16 + 32) * 4 + b.cap * 2;
-  auto kern = nine ? part_sort_kernel<9> : part_sort_kernel<8>;
+  const int lds = (b.cap + 64 + 16 * radix + 16 * 16 + 32) * 4 + b.cap * 2;
+  const bool small = max_n <= 8 * 1024;
+  auto kern = small ? (nine ? part_sort_kernel<9, 8> : part_sort_kernel<8, 8>) : (nine ? part_sort_kernel<9, 16> : part_sort_kernel<8, 16>);
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
     return tt::fail(TT_ERR_LAUNCH, "tt_sparse_plan: hipFuncSetAttribute(LDS %d) failed", lds);
@@ -530,14 +593,15 @@ extern "C" int tt_sparse_plan_batched(const tt_sparse_plan_args* tables, int32_t
     if (chunks == 1 && env_sort_groups() != 0) {   // one list that fits a workgroup's LDS: key-range partitions, one launch
       PartTable& t = pb.t[npb++];
       t.ids = a.ids; t.sorted_ids = a.sorted_ids; t.order = a.order; t.num_rows = a.num_rows; t.n = (int32_t)a.n_ids;
-      t.groups = part_groups(t.n, bits);
-      int lg = 0;
-      while ((1 << lg) < t.groups) ++lg;
-      t.rshift = bits - lg;
+      t.groups = part_groups(t.n, a.num_rows);
+      t.width = (uint32_t)((a.num_rows + t.groups - 1) / t.groups);
+      if (t.width < 2u) t.width = 2u;
+      t.magic = (uint32_t)((((uint64_t)1 << 32) / t.width) + 1u);
       t.sentinel = (uint32_t)(((uint64_t)1 << bits) - 1);
+      const int lbits = id_bits((int64_t)t.width);
       if (t.n > p_max_n) p_max_n = t.n;
       if (t.groups > p_max_groups) p_max_groups = t.groups;
-      if (t.rshift > p_max_lbits) p_max_lbits = t.rshift;
+      if (lbits > p_max_lbits) p_max_lbits = lbits;
       continue;
     }
     int64_t* keys_out = a.sorted_ids;

@@ -17,6 +17,7 @@ implemented the step itself (``src/training/__init__.py:1``).
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
 
 import torch
@@ -236,6 +237,10 @@ class TwoTowerTrainer:
         # high priority = a hardware queue of its own (ROCm pools queues per priority): the sort plans always run BESIDE
         # the main stream's kernels, whatever other streams the process has created
         self._side = torch.cuda.Stream(device=dev, priority=-1)
+        # where the sort plan runs: in front of the forward pass on the main stream (default since the partitioned sort:
+        # ~6 us of kernel), or beside it on the side stream (TT_PLAN_STREAM=side: two cross-stream waits per step, which
+        # cost more than the kernel: cfg3 step 0.687-0.689 ms against 0.677-0.681 ms; DESIGN.md section 4, K2 plan)
+        self.plan_on_side_stream = os.environ.get("TT_PLAN_STREAM", "main") == "side"
         self.step_index = 0                      # counter of the dropout stream (global batch row = step*batch + r)
         self.fuse_lookup = True                  # K1 inside the first tower layer's GEMMs (False: gather2 launch + acts[0])
         self.fuse_optimizer = True               # sparse + dense optimizer in one launch (False: dense_update, sparse_update2 [, cat])
@@ -369,16 +374,20 @@ class TwoTowerTrainer:
                           loss_kw.get("candidate_sampling_probability"), loss_kw.get("candidate_ids"))
         if self.flag_poll_every and self.step_index % self.flag_poll_every == 0:
             self.poll_ids()
-        # the sort plans depend on the ids only: they run on a side stream beside the forward/backward pass
+        # the sort plans depend on the ids only: one launch for all tables, in front of the forward pass (or beside it)
         main = torch.cuda.current_stream()
-        self._side.wait_stream(main)
-        with torch.cuda.stream(self._side):        # one launch for all tables (csrc/sort.hip)
-            plans, ids, rows = [self.user_plan, self.item_plan], [user_ids, item_ids], [self.cfg.n_users, self.cfg.n_items]
-            if loss_kw.get("category_ids") is not None and self.cat_plan is not None:
-                plans.append(self.cat_plan); ids.append(loss_kw["category_ids"]); rows.append(self.cfg.n_category_buckets)
+        plans, ids, rows = [self.user_plan, self.item_plan], [user_ids, item_ids], [self.cfg.n_users, self.cfg.n_items]
+        if loss_kw.get("category_ids") is not None and self.cat_plan is not None:
+            plans.append(self.cat_plan); ids.append(loss_kw["category_ids"]); rows.append(self.cfg.n_category_buckets)
+        if self.plan_on_side_stream:
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):    # one launch for all tables (csrc/sort.hip)
+                ops.sparse_plan_batched(plans, ids, rows)
+        else:
             ops.sparse_plan_batched(plans, ids, rows)
         loss = self.forward_backward(user_ids, item_ids, **loss_kw)
-        main.wait_stream(self._side)
+        if self.plan_on_side_stream:
+            main.wait_stream(self._side)
         self.apply_gradients()
         return loss
 
