@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TT_ABI_VERSION 5
+#define TT_ABI_VERSION 6
 
 enum {
   TT_OK = 0,
@@ -249,15 +249,22 @@ typedef struct tt_dense_lookup {
   const float* table2; const int64_t* ids2; int64_t table2_rows;     /* optional */
   int32_t* oob_flag;                                                 /* optional */
 } tt_dense_lookup;
+/* ReLU sign bits (optional, n % 32 == 0): the forward pass can write, beside y, one bit per element — word
+ * [row][col / 32] of a [m, n/32] uint32 array, bit col % 32 = (y[row][col] > 0) — and the backward pass of the NEXT layer
+ * takes them as its dx mask (`dx_relu_bits`, [m, k/32]) instead of re-reading the whole activation through
+ * `dx_relu_src`: 1/32 of the mask bytes (cfg3: 0.5 MB instead of 16.8 MB per step) and no 4-byte strided loads in
+ * front of the dx tiles.  Same mask, same results bit for bit.                                                       */
 typedef struct tt_dense_fwd_args {
   const float* x; const float* w; const float* b; float* y;
   uint64_t dropout_tensor_id;       /* counter stream of this problem's dropout mask (ignored at rate 0) */
   tt_dense_lookup lookup;           /* x may be NULL when lookup.ids is given */
+  uint32_t* relu_bits;              /* optional [m, n/32]: sign bits of y (after ReLU / dropout), see above */
 } tt_dense_fwd_args;
 typedef struct tt_dense_bwd_args {
   const float* x; const float* w; const float* dz; float* dx; const float* dx_relu_src;
   float* dw_slabs; float* db_slabs;
   tt_dense_lookup lookup;           /* x may be NULL when lookup.ids is given (dW reads the table rows) */
+  const uint32_t* dx_relu_bits;     /* optional [m, k/32]: the dx mask as sign bits; takes precedence over dx_relu_src */
 } tt_dense_bwd_args;
 int tt_dense_fwd_batched_f32(const tt_dense_fwd_args* probs, int32_t n_probs, int64_t m, int32_t k, int32_t n,
                              int32_t relu, float drop_rate, uint64_t seed, uint64_t counter_offset,

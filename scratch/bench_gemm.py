@@ -40,14 +40,18 @@ def main():
     for l in range(2):
         hidden = l < 1
         res[f"fwd_L{l}"] = t(lambda: ops.dense_fwd2((ut.acts[l], it.acts[l]), (ut.w[l], it.w[l]), (ut.b[l], it.b[l]),
-                                                    (ut.acts[l + 1], it.acts[l + 1]), relu=hidden))
+                                                    (ut.acts[l + 1], it.acts[l + 1]), relu=hidden, relu_bits=(ut.bits[l + 1], it.bits[l + 1])))
     for l in (1, 0):
         dxs = (ut.dz[l - 1], it.dz[l - 1]) if l > 0 else (ut.demb, it.demb)
         masks = (ut.acts[l], it.acts[l]) if l > 0 else none2
-        res[f"bwd_L{l}"] = t(lambda: ops.dense_bwd2((ut.acts[l], it.acts[l]), (ut.w[l], it.w[l]), (ut.dz[l], it.dz[l]), dxs, masks,
-                                                    (ut.dw_slabs[l], it.dw_slabs[l]), (ut.db_slabs[l], it.db_slabs[l])))
+        bits = (ut.bits[l], it.bits[l]) if l > 0 else none2        # the train step's form: sign bits instead of the float mask
+        res[f"bwd_L{l}"] = t(lambda: ops.dense_bwd2((ut.acts[l], it.acts[l]), (ut.w[l], it.w[l]), (ut.dz[l], it.dz[l]), dxs, none2,
+                                                    (ut.dw_slabs[l], it.dw_slabs[l]), (ut.db_slabs[l], it.db_slabs[l]), dx_relu_bits=bits))
+        if l > 0:
+            res[f"bwd_L{l}_float_mask"] = t(lambda: ops.dense_bwd2((ut.acts[l], it.acts[l]), (ut.w[l], it.w[l]), (ut.dz[l], it.dz[l]), dxs, masks,
+                                                                   (ut.dw_slabs[l], it.dw_slabs[l]), (ut.db_slabs[l], it.db_slabs[l])))
         res[f"bwd_L{l}_dx_only"] = t(lambda: ops.dense_bwd2((ut.acts[l], it.acts[l]), (ut.w[l], it.w[l]), (ut.dz[l], it.dz[l]), dxs,
-                                                            masks, none2, none2))
+                                                            none2, none2, none2, dx_relu_bits=bits))
         res[f"bwd_L{l}_dw_only"] = t(lambda: ops.dense_bwd2((ut.acts[l], it.acts[l]), (ut.w[l], it.w[l]), (ut.dz[l], it.dz[l]), none2,
                                                             none2, (ut.dw_slabs[l], it.dw_slabs[l]), (ut.db_slabs[l], it.db_slabs[l])))
     res["towers_fwd_all"] = t(lambda: towers_forward(ut, it))

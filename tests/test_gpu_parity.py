@@ -347,6 +347,48 @@ def test_dense_bwd(dev, m, k, n, mask):
     assert rel_err(db_s.sum(0).cpu().numpy(), dz64.sum(0)) <= 1e-5
 
 
+@pytest.mark.parametrize("m,k,n,rate", [(8192, 128, 256, 0.0), (1000, 64, 96, 0.0), (77, 36, 32, 0.0), (2048, 128, 256, 0.1)])
+def test_relu_sign_bits_are_the_activation_mask_bit_for_bit(dev, m, k, n, rate):
+    """The forward GEMM's optional sign-bit output (word [row][col/32], bit col%32 = (y > 0), after ReLU and dropout) and
+    the next layer's dx taking it as its mask (dx_relu_bits): the same mask as re-reading y through dx_relu_src, so dx is
+    bit-identical; ragged tile edges and the batched two-tower launches included."""
+    x = T(synth.uniform_f32(41, 1, m * k, -1.0, 2.0).reshape(m, k), dev)
+    w = T(synth.dense_kernel(41, 2, k, n), dev)
+    b = T(synth.uniform_f32(41, 3, n, -0.1, 0.2), dev)
+    bits = torch.full((m, n // 32), -1, dtype=torch.int32, device=dev)
+    drop = (rate, 5, synth.dropout_tid(0, 0), 0) if rate > 0 else None
+    y = ops.dense_fwd(x, w, b, True, dropout=drop, relu_bits=bits)
+    y_plain = ops.dense_fwd(x, w, b, True, dropout=drop)
+    assert torch.equal(y, y_plain)
+    want = ((y > 0).view(m, n // 32, 32).to(torch.int64) << torch.arange(32, device=dev)).sum(-1)
+    assert torch.equal(bits.to(torch.int64) & 0xffffffff, want)
+    # the next layer (n -> 64): dx masked by the bits == dx masked by y
+    w2 = T(synth.dense_kernel(41, 4, n, 64), dev)
+    dz = T(synth.uniform_f32(41, 5, m * 64, -1.0, 2.0).reshape(m, 64), dev)
+    dx_a, dx_b = torch.full((m, n), float("nan"), device=dev), torch.full((m, n), float("nan"), device=dev)
+    ops.dense_bwd(y, w2, dz, dx_a, y, None, None, dx_scale=1.25)
+    ops.dense_bwd(y, w2, dz, dx_b, None, None, None, dx_scale=1.25, dx_relu_bits=bits)
+    assert torch.equal(dx_a, dx_b)
+    assert (dx_b[y <= 0] == 0).all()
+    # batched (two problems per launch), fused dx + dw launch
+    ns = ops.dense_bwd_num_slabs(m)
+    bits2 = torch.empty_like(bits)
+    y2 = torch.empty_like(y)
+    ops.dense_fwd2((x, x), (w, w), (b, b), (y, y2), relu=True, dropout=None if drop is None else (rate, 5, (drop[2], drop[2]), 0),
+                   relu_bits=(bits, bits2))
+    assert torch.equal(bits, bits2) and torch.equal(y, y2)
+    dws = [torch.empty(ns, n, 64, device=dev) for _ in range(4)]
+    dbs = [torch.empty(ns, 64, device=dev) for _ in range(4)]
+    dxs = [torch.full((m, n), float("nan"), device=dev) for _ in range(4)]
+    ops.dense_bwd2((y, y), (w2, w2), (dz, dz), (dxs[0], dxs[1]), (y, y), (dws[0], dws[1]), (dbs[0], dbs[1]), dx_scale=1.25)
+    ops.dense_bwd2((y, y), (w2, w2), (dz, dz), (dxs[2], dxs[3]), (None, None), (dws[2], dws[3]), (dbs[2], dbs[3]), dx_scale=1.25,
+                   dx_relu_bits=(bits, bits2))
+    assert torch.equal(dxs[0], dxs[2]) and torch.equal(dxs[1], dxs[3]) and torch.equal(dxs[2], dx_a)
+    assert torch.equal(dws[0], dws[2]) and torch.equal(dbs[1], dbs[3])
+    with pytest.raises(RuntimeError):
+        ops.dense_fwd(x, w, b, True, relu_bits=torch.empty(m, n // 32 + 1, dtype=torch.int32, device=dev))
+
+
 def test_dense_bwd_dx_only_then_dw_only_equals_one_call(dev):
     """dw_slabs = db_slabs = NULL skips the weight gradients, dx = NULL skips dx: the two half calls (the sharded
     trainer's dx-first order) write exactly what the full call writes; neither NULL-everything is accepted."""

@@ -15,7 +15,7 @@ import threading
 _PKG = pathlib.Path(__file__).resolve().parent
 # TT_LIB_PATH: load another build of the same C ABI (kernel A/B experiments); the product default is the in-tree library
 LIB_PATH = pathlib.Path(os.environ["TT_LIB_PATH"]) if os.environ.get("TT_LIB_PATH") else _PKG / "libtwotower_hip.so"
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 TT_OK, TT_ERR_INVALID_ARG, TT_ERR_LAUNCH, TT_ERR_UNSUPPORTED, TT_ERR_WORKSPACE = range(5)
 TT_OPT_SGD, TT_OPT_ADAGRAD = 0, 1
@@ -32,13 +32,13 @@ class DenseLookup(C.Structure):
 class DenseFwdArgs(C.Structure):
     """Mirror of ``tt_dense_fwd_args``."""
     _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("b", C.c_void_p), ("y", C.c_void_p), ("dropout_tensor_id", C.c_uint64),
-                ("lookup", DenseLookup)]
+                ("lookup", DenseLookup), ("relu_bits", C.c_void_p)]
 
 
 class DenseBwdArgs(C.Structure):
     """Mirror of ``tt_dense_bwd_args``."""
     _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("dz", C.c_void_p), ("dx", C.c_void_p), ("dx_relu_src", C.c_void_p),
-                ("dw_slabs", C.c_void_p), ("db_slabs", C.c_void_p), ("lookup", DenseLookup)]
+                ("dw_slabs", C.c_void_p), ("db_slabs", C.c_void_p), ("lookup", DenseLookup), ("dx_relu_bits", C.c_void_p)]
 
 
 class RouteTable(C.Structure):

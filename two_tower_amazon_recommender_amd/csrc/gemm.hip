@@ -49,6 +49,8 @@ struct GemmArgs {
   const float* bias;    // [N] or null
   int relu;
   const float* mask_src;   // [M][ldc] or null: C *= (mask_src > 0)
+  const uint32_t* mask_bits;   // [M][N/32] or null: the same mask as sign bits (N % 32 == 0); takes precedence over mask_src
+  uint32_t* relu_bits;     // fwd, [M][N/32] or null: written beside C, bit = (C > 0)
   float mask_scale;        // multiplies the kept entries of the masked epilogue (1/(1-p) under dropout, else 1)
   uint32_t drop_p24;       // fwd dropout: element dropped iff 24-bit hash < drop_p24 (0 = no dropout)
   float drop_scale;        // 1/(1-p)
@@ -245,9 +247,15 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int zsplit, c
   // stay in flight): loading them after the MFMAs made the store phase of the masked dx tiles 9.3 us against 3.7-3.9 us
   // for the other kinds (r02 per-workgroup stamps)
   float mk[A_KC && B_KC ? 16 : 1];
-  uint32_t mbits = 0xffffu;
-  const bool masked = A_KC && B_KC && p.mask_src != nullptr;
+  uint32_t mbits = 0xffffu, mword = 0u;
+  const bool bitmask = A_KC && B_KC && p.mask_bits != nullptr;
+  const bool masked = A_KC && B_KC && p.mask_src != nullptr && !bitmask;
   if constexpr (A_KC && B_KC) {
+    if (bitmask) {          // sign bits: lane l < 32 fetches the 32-column word of tile row l of this wave's 32x32 block
+      const int64_t m = m0 + wm * 32 + ln;
+      const int64_t nw = (n0 + wn * 32) >> 5;
+      mword = (m < p.M && nw < (p.N >> 5)) ? p.mask_bits[m * (p.N >> 5) + nw] : 0u;
+    }
     if (masked) {
       const int64_t nn = n0 + wn * 32 + ln;
 #pragma unroll
@@ -271,6 +279,15 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int zsplit, c
       mbits = 0u;
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) mbits |= (mk[reg] > 0.f ? 1u : 0u) << reg;
+    }
+    if (bitmask) {          // register `reg` of lane half h is tile row acc_row(reg, h), column ln
+      mbits = 0u;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)mword, tt::acc_row(reg, 0));
+        const uint32_t w1 = (uint32_t)__builtin_amdgcn_readlane((int)mword, tt::acc_row(reg, 1));
+        mbits |= (((h ? w1 : w0) >> ln) & 1u) << reg;
+      }
     }
   }
 
@@ -310,6 +327,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int zsplit, c
   STAMP(2);
   float* C = p.C + (int64_t)zsplit * p.slab_stride;
   const int64_t n = n0 + wn * 32 + ln;
+  uint32_t posbits = 0u;                        // fwd: (C > 0) of this lane's 16 elements
   if (n < p.N) {
     const float bias = p.bias != nullptr ? p.bias[n] : 0.f;
 #pragma unroll
@@ -324,12 +342,27 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int zsplit, c
           v = ((uint32_t)(hsh >> 40) < p.drop_p24) ? 0.f : v * p.drop_scale;
         }
         if constexpr (A_KC && B_KC) {
-          if (masked) v = ((mbits >> reg) & 1u) ? v * p.mask_scale : 0.f;
+          if (masked || bitmask) v = ((mbits >> reg) & 1u) ? v * p.mask_scale : 0.f;
         } else {
           if (p.mask_src != nullptr) v = p.mask_src[m * p.ldc + n] > 0.f ? v * p.mask_scale : 0.f;
         }
         C[m * p.ldc + n] = v;
+        if constexpr (A_KC && !B_KC) posbits |= (v > 0.f ? 1u : 0u) << reg;
       }
+    }
+  }
+  if constexpr (A_KC && !B_KC) {
+    if (p.relu_bits != nullptr) {      // (workgroup-uniform) one ballot per register: low half = tile row acc_row(reg, 0), high = (reg, 1)
+      uint32_t myword = 0u;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const uint64_t b = __builtin_amdgcn_ballot_w64(((posbits >> reg) & 1u) != 0u);
+        if (lane == tt::acc_row(reg, 0)) myword = (uint32_t)b;
+        if (lane == tt::acc_row(reg, 1)) myword = (uint32_t)(b >> 32);
+      }
+      const int64_t m = m0 + wm * 32 + lane;
+      const int64_t nw = (n0 + wn * 32) >> 5;
+      if (lane < 32 && m < p.M && nw < (p.N >> 5)) p.relu_bits[m * (p.N >> 5) + nw] = myword;
     }
   }
   if constexpr (COLSUM) {
@@ -468,6 +501,8 @@ extern "C" int tt_dense_fwd_batched_f32(const tt_dense_fwd_args* probs, int32_t 
     TT_REQUIRE(tt::aligned16(q.x) && tt::aligned16(q.w) && tt::aligned16(q.y), "tt_dense_fwd_f32: pointers must be 16-byte aligned");
     a[i].A = q.x; a[i].B = q.w; a[i].C = q.y; a[i].M = m; a[i].N = n; a[i].K = k; a[i].lda = k; a[i].ldb = n; a[i].ldc = n;
     a[i].bias = q.b; a[i].relu = relu; a[i].mask_scale = 1.f; a[i].k_per_split = (k + BK - 1) / BK * BK;
+    TT_REQUIRE(q.relu_bits == nullptr || n % 32 == 0, "tt_dense_fwd_f32: relu_bits need n %% 32 == 0 (n=%d)", n);
+    a[i].relu_bits = q.relu_bits;
     int rc = set_lookup(a[i], q.lookup, q.x, m, "tt_dense_fwd_f32");
     if (rc != TT_OK) return rc;
     if (drop_rate > 0.f) {
@@ -486,14 +521,14 @@ extern "C" int tt_dense_fwd_batched_f32(const tt_dense_fwd_args* probs, int32_t 
 
 extern "C" int tt_dense_fwd_f32(const float* x, const float* w, const float* b, float* y, int64_t m, int32_t k,
                                 int32_t n, int32_t relu, tt_stream_t stream) {
-  const tt_dense_fwd_args q{x, w, b, y, 0, {}};
+  const tt_dense_fwd_args q{x, w, b, y, 0, {}, nullptr};
   return tt_dense_fwd_batched_f32(&q, 1, m, k, n, relu, 0.f, 0, 0, stream);
 }
 
 extern "C" int tt_dense_fwd_dropout_f32(const float* x, const float* w, const float* b, float* y, int64_t m, int32_t k,
                                         int32_t n, int32_t relu, float drop_rate, uint64_t seed, uint64_t tensor_id,
                                         uint64_t counter_offset, tt_stream_t stream) {
-  const tt_dense_fwd_args q{x, w, b, y, tensor_id, {}};
+  const tt_dense_fwd_args q{x, w, b, y, tensor_id, {}, nullptr};
   return tt_dense_fwd_batched_f32(&q, 1, m, k, n, relu, drop_rate, seed, counter_offset, stream);
 }
 
@@ -529,6 +564,8 @@ extern "C" int tt_dense_bwd_batched_f32(const tt_dense_bwd_args* probs, int32_t 
     // dx[m][k] = sum_n dz[m][n] * w[k][n]
     ax[i].A = q.dz; ax[i].B = q.w; ax[i].C = q.dx; ax[i].M = m; ax[i].N = k; ax[i].K = n; ax[i].lda = n; ax[i].ldb = n; ax[i].ldc = k;
     ax[i].mask_src = q.dx_relu_src; ax[i].mask_scale = dx_scale; ax[i].k_per_split = (n + BK - 1) / BK * BK;
+    TT_REQUIRE(q.dx_relu_bits == nullptr || k % 32 == 0, "tt_dense_bwd_f32: dx_relu_bits need k %% 32 == 0 (k=%d)", k);
+    ax[i].mask_bits = q.dx_relu_bits;
     // dw[k][n] = sum_b x[b][k] * dz[b][n], split over the batch into slabs; db rides along
     aw[i].A = q.x; aw[i].B = q.dz; aw[i].C = q.dw_slabs; aw[i].M = k; aw[i].N = n; aw[i].K = m; aw[i].lda = k; aw[i].ldb = n; aw[i].ldc = n;
     aw[i].k_per_split = ((m + splits - 1) / splits + BK - 1) / BK * BK;
@@ -578,7 +615,7 @@ extern "C" int tt_dense_bwd_f32(const float* x, const float* w, const float* dz,
 extern "C" int tt_dense_bwd_scaled_f32(const float* x, const float* w, const float* dz, float* dx, const float* dx_relu_src,
                                        float dx_scale, float* dw_slabs, float* db_slabs, int64_t m, int32_t k, int32_t n,
                                        tt_stream_t stream_) {
-  const tt_dense_bwd_args q{x, w, dz, dx, dx_relu_src, dw_slabs, db_slabs, {}};
+  const tt_dense_bwd_args q{x, w, dz, dx, dx_relu_src, dw_slabs, db_slabs, {}, nullptr};
   return tt_dense_bwd_batched_f32(&q, 1, dx_scale, m, k, n, stream_);
 }
 

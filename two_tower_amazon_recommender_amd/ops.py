@@ -318,9 +318,25 @@ def _in_shape(x, lookup):
     return x.shape[0], x.shape[1]
 
 
-def dense_fwd(x, w, b, relu: bool, out=None, dropout=None, lookup=None):
+def relu_bits_like(m: int, n: int, device) -> torch.Tensor:
+    """[m, n/32] int32 buffer for the sign bits a forward layer writes beside its output (n % 32 == 0)."""
+    if n % 32:
+        raise RuntimeError(f"relu bits need a layer width that is a multiple of 32, got {n}")
+    return torch.empty((m, n // 32), dtype=torch.int32, device=device)
+
+
+def _chk_bits(bits, m, n, what):
+    if bits is None:
+        return
+    if bits.dtype != torch.int32 or not bits.is_cuda or not bits.is_contiguous() or tuple(bits.shape) != (m, n // 32) or n % 32:
+        raise RuntimeError(f"{what}: expected a contiguous CUDA int32 tensor [{m}, {n}/32] (width a multiple of 32), got "
+                           f"{bits.dtype} {tuple(bits.shape)}")
+
+
+def dense_fwd(x, w, b, relu: bool, out=None, dropout=None, lookup=None, relu_bits=None):
     """y = act(x@w+b); ``dropout`` = (rate, seed, tensor_id, counter_offset) applies inverted dropout to y.
-    With ``lookup`` (make_lookup) x is ignored: the input rows come from the embedding table."""
+    With ``lookup`` (make_lookup) x is ignored: the input rows come from the embedding table.
+    ``relu_bits`` (relu_bits_like): also written, bit = (y > 0) — the next layer's backward takes it as its dx mask."""
     _chk(w, torch.float32, "w", 2)
     if b is not None:
         _chk(b, torch.float32, "b", 1)
@@ -334,8 +350,9 @@ def dense_fwd(x, w, b, relu: bool, out=None, dropout=None, lookup=None):
     if tuple(out.shape) != (m, n):
         raise RuntimeError(f"dense_fwd: out must be [{m},{n}], got {tuple(out.shape)}")
     rate, seed, tid, off = dropout if dropout is not None else (0.0, 0, 0, 0)
+    _chk_bits(relu_bits, m, n, "dense_fwd: relu_bits")
     arr = (_lib.DenseFwdArgs * 1)(_lib.DenseFwdArgs(None if lookup is not None else _p(x), _p(w), _p(b), _p(out), tid,
-                                                    lookup if lookup is not None else _no_lookup()))
+                                                    lookup if lookup is not None else _no_lookup(), _p(relu_bits)))
     _lib.check(_lib.load().tt_dense_fwd_batched_f32(arr, 1, m, k, n, int(relu), rate, seed, off, _stream()),
                "tt_dense_fwd_batched_f32")
     return out
@@ -345,9 +362,10 @@ def dense_bwd_num_slabs(m: int) -> int:
     return int(_lib.load().tt_dense_bwd_num_slabs(m))
 
 
-def dense_bwd(x, w, dz, dx, dx_relu_src, dw_slabs, db_slabs, dx_scale: float = 1.0, lookup=None):
+def dense_bwd(x, w, dz, dx, dx_relu_src, dw_slabs, db_slabs, dx_scale: float = 1.0, lookup=None, dx_relu_bits=None):
     """dx = dz@w^T (* (dx_relu_src>0)); dw_slabs/db_slabs get the split-K partials.  With ``lookup`` the layer's input
-    (needed by dw = x^T dz) is read from the embedding table."""
+    (needed by dw = x^T dz) is read from the embedding table.  ``dx_relu_bits`` (the sign bits the previous layer's
+    forward wrote) replaces ``dx_relu_src`` as the mask."""
     _chk(w, torch.float32, "w", 2)
     _chk(dz, torch.float32, "dz", 2)
     m, k = _in_shape(x, lookup)
@@ -362,31 +380,39 @@ def dense_bwd(x, w, dz, dx, dx_relu_src, dw_slabs, db_slabs, dx_scale: float = 1
         _chk(db_slabs, torch.float32, "db_slabs")
         if dw_slabs.numel() < ns * k * n or db_slabs.numel() < ns * n:
             raise RuntimeError("dense_bwd: slab buffers too small")
+    _chk_bits(dx_relu_bits, m, k, "dense_bwd: dx_relu_bits")
     arr = (_lib.DenseBwdArgs * 1)(_lib.DenseBwdArgs(None if lookup is not None else _p(x), _p(w), _p(dz), _p(dx), _p(dx_relu_src),
-                                                    _p(dw_slabs), _p(db_slabs), lookup if lookup is not None else _no_lookup()))
+                                                    _p(dw_slabs), _p(db_slabs), lookup if lookup is not None else _no_lookup(),
+                                                    _p(dx_relu_bits)))
     _lib.check(_lib.load().tt_dense_bwd_batched_f32(arr, 1, dx_scale, m, k, n, _stream()), "tt_dense_bwd_batched_f32")
     return ns
 
 
-def dense_fwd2(xs, ws, bs, ys, relu: bool, dropout=None, lookups=None):
+def dense_fwd2(xs, ws, bs, ys, relu: bool, dropout=None, lookups=None, relu_bits=(None, None)):
     """Layer l of both towers in one launch: ys[i] = act(xs[i] @ ws[i] + bs[i]).  dropout = (rate, seed, (tid_a, tid_b), offset).
     lookups = (lookup_a, lookup_b): the towers' first layer reads its input rows from the embedding tables."""
     m, k = _in_shape(xs[0], None if lookups is None else lookups[0])
     n = ws[0].shape[1]
     rate, seed, tids, off = dropout if dropout is not None else (0.0, 0, (0, 0), 0)
+    for i in range(2):
+        _chk_bits(relu_bits[i], m, n, "dense_fwd2: relu_bits")
     arr = (_lib.DenseFwdArgs * 2)(*[_lib.DenseFwdArgs(None if lookups is not None else _p(xs[i]), _p(ws[i]), _p(bs[i]), _p(ys[i]),
-                                                      tids[i], lookups[i] if lookups is not None else _no_lookup()) for i in range(2)])
+                                                      tids[i], lookups[i] if lookups is not None else _no_lookup(),
+                                                      _p(relu_bits[i])) for i in range(2)])
     _lib.check(_lib.load().tt_dense_fwd_batched_f32(arr, 2, m, k, n, int(relu), rate, seed, off, _stream()),
                "tt_dense_fwd_batched_f32")
 
 
-def dense_bwd2(xs, ws, dzs, dxs, dx_relu_srcs, dw_slabs, db_slabs, dx_scale: float = 1.0, lookups=None):
+def dense_bwd2(xs, ws, dzs, dxs, dx_relu_srcs, dw_slabs, db_slabs, dx_scale: float = 1.0, lookups=None, dx_relu_bits=(None, None)):
     """Backward of layer l of both towers: one launch (dx and dw+db tiles side by side; dx only / dw only: one each)."""
     m, k = _in_shape(xs[0], None if lookups is None else lookups[0])
     n = ws[0].shape[1]
+    for i in range(2):
+        _chk_bits(dx_relu_bits[i], m, k, "dense_bwd2: dx_relu_bits")
     arr = (_lib.DenseBwdArgs * 2)(*[_lib.DenseBwdArgs(None if lookups is not None else _p(xs[i]), _p(ws[i]), _p(dzs[i]), _p(dxs[i]),
                                                      _p(dx_relu_srcs[i]), _p(dw_slabs[i]), _p(db_slabs[i]),
-                                                     lookups[i] if lookups is not None else _no_lookup()) for i in range(2)])
+                                                     lookups[i] if lookups is not None else _no_lookup(),
+                                                     _p(dx_relu_bits[i])) for i in range(2)])
     _lib.check(_lib.load().tt_dense_bwd_batched_f32(arr, 2, dx_scale, m, k, n, _stream()), "tt_dense_bwd_batched_f32")
 
 

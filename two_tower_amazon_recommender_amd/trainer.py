@@ -111,6 +111,10 @@ class Tower:
         # dz[l]: gradient w.r.t. the pre-activation of layer l; dz[n_layers-1] is the scorer's dq/dc
         self.dz = [torch.empty(b, self.dims[l + 1], device=dev) for l in range(self.n_layers)]
         self.demb = torch.empty(b, self.dims[0], device=dev)
+        # sign bits of the hidden (ReLU) activations, written by the forward GEMM's epilogue and read by the next layer's dx
+        # epilogue as its mask: [b, n/32] words instead of re-reading acts[l] (indexed like acts; None where n % 32 != 0)
+        self.bits = [None] + [ops.relu_bits_like(b, self.dims[l + 1], dev) if (l < self.n_layers - 1 and self.dims[l + 1] % 32 == 0)
+                              else None for l in range(self.n_layers)]
         self.dw_slabs = [torch.empty(ns, self.dims[l], self.dims[l + 1], device=dev) for l in range(self.n_layers)]
         self.db_slabs = [torch.empty(ns, self.dims[l + 1], device=dev) for l in range(self.n_layers)]
 
@@ -130,7 +134,7 @@ class Tower:
                 rate, seed, tower, row0 = dropout
                 d = (rate, seed, TID_DROPOUT_BASE + 2 * l + tower, row0 * self.dims[l + 1])
             ops.dense_fwd(self.acts[l], self.w[l], self.b[l], relu=hidden, out=self.acts[l + 1], dropout=d,
-                          lookup=lookup if l == 0 else None)
+                          lookup=lookup if l == 0 else None, relu_bits=self.bits[l + 1])
         return self.acts[-1]
 
     def backward(self, dropout_rate: float = 0.0, dx: bool = True, dw: bool = True, lookup=None):
@@ -142,10 +146,11 @@ class Tower:
             scale = (one / (one - torch.tensor(dropout_rate, dtype=torch.float32))).item()
         for l in range(self.n_layers - 1, -1, -1):
             dxo = (self.dz[l - 1] if l > 0 else self.demb) if dx else None
-            mask_src = self.acts[l] if (l > 0 and dx) else None       # acts[l] = (dropped-out) ReLU output of layer l-1
+            bits = self.bits[l] if (l > 0 and dx) else None
+            mask_src = self.acts[l] if (l > 0 and dx and bits is None) else None   # acts[l] = (dropped-out) ReLU output of layer l-1
             ops.dense_bwd(self.acts[l], self.w[l], self.dz[l], dxo, mask_src, self.dw_slabs[l] if dw else None,
                           self.db_slabs[l] if dw else None, dx_scale=scale if l > 0 else 1.0,
-                          lookup=lookup if l == 0 else None)
+                          lookup=lookup if l == 0 else None, dx_relu_bits=bits)
 
     def segments(self, l2: float, grad_flat=None, grad_offset: int = 0):
         segs = []
@@ -170,7 +175,7 @@ def towers_forward(ut: "Tower", it: "Tower", dropout=None, lookups=None):
             rate, seed, row0 = dropout
             d = (rate, seed, (TID_DROPOUT_BASE + 2 * l, TID_DROPOUT_BASE + 2 * l + 1), row0 * ut.dims[l + 1])
         ops.dense_fwd2((ut.acts[l], it.acts[l]), (ut.w[l], it.w[l]), (ut.b[l], it.b[l]), (ut.acts[l + 1], it.acts[l + 1]),
-                       relu=hidden, dropout=d, lookups=lookups if l == 0 else None)
+                       relu=hidden, dropout=d, lookups=lookups if l == 0 else None, relu_bits=(ut.bits[l + 1], it.bits[l + 1]))
     return ut.acts[-1], it.acts[-1]
 
 
@@ -186,10 +191,11 @@ def towers_backward(ut: "Tower", it: "Tower", dropout_rate: float = 0.0, on_embe
 
     def layer(l, dx: bool, dw: bool):
         dxs = ((ut.dz[l - 1], it.dz[l - 1]) if l > 0 else (ut.demb, it.demb)) if dx else none2
-        masks = (ut.acts[l], it.acts[l]) if (l > 0 and dx) else none2
+        bits = (ut.bits[l], it.bits[l]) if (l > 0 and dx and ut.bits[l] is not None) else none2
+        masks = (ut.acts[l], it.acts[l]) if (l > 0 and dx and bits[0] is None) else none2
         ops.dense_bwd2((ut.acts[l], it.acts[l]), (ut.w[l], it.w[l]), (ut.dz[l], it.dz[l]), dxs, masks,
                        (ut.dw_slabs[l], it.dw_slabs[l]) if dw else none2, (ut.db_slabs[l], it.db_slabs[l]) if dw else none2,
-                       dx_scale=scale if l > 0 else 1.0, lookups=lookups if l == 0 else None)
+                       dx_scale=scale if l > 0 else 1.0, lookups=lookups if l == 0 else None, dx_relu_bits=bits)
 
     if on_embedding_grads is None:
         for l in range(ut.n_layers - 1, -1, -1):
