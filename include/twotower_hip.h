@@ -123,10 +123,11 @@ int tt_hash_bucket_u8(const uint8_t* rows_u8, int64_t n, int32_t width, int64_t 
  *   2^bits - 1 >= num_rows (bits = bit length of num_rows): such ids sort last, can never cut the run of a
  *   valid id, and the apply kernels skip them.
  * Only the ids are needed, so the plan can run before / beside the forward pass.  Up to
- * tt_sparse_plan_max_lds_ids() (16384) ids per table the sort is ONE launch of a hand-written LDS radix sort (one
- * workgroup per table; tt_sparse_plan_batched sorts up to 4 tables — user, item, hashed category — in that one
- * launch) and needs no workspace; up to 16x that, 16384-id chunks are sorted by the same launch into the workspace
- * and a second launch merges them by rank; only longer lists fall back to rocPRIM's device radix sort.
+ * tt_sparse_plan_max_lds_ids() (16384) ids per table the sort is ONE launch of a hand-written LDS sort (n/128
+ * workgroups per table, each sorting the ids of its own row range; tt_sparse_plan_batched sorts up to 4 tables —
+ * user, item, hashed category — in that one launch) and needs no workspace; up to 16x that, 16384-id chunks are
+ * radix-sorted by one launch into the workspace and a second launch merges them by rank; only longer lists fall back
+ * to rocPRIM's device radix sort.
  *
  * tt_sparse_{sgd,adagrad}_f32: for every distinct id u (rows >= num_rows are skipped):
  *   g  = sum of grads[p, :] over the positions p of u in ascending p.  Order of the f32 adds: the run of u in

@@ -16,12 +16,14 @@ for c in cfg3 cfg4 cfg5; do
 done
 echo "== kernel microbenches"
 timeout -k 10 200 python scratch/bench_k2.py > $out/k2_batch.jsonl 2>/dev/null
+timeout -k 10 200 python scratch/bench_sort.py > $out/sort_plan.jsonl 2>/dev/null
 timeout -k 10 300 python bench_kernels.py > $out/kernels_largeB.jsonl 2>/dev/null
 timeout -k 10 100 python scratch/bench_gemm.py > $out/gemm_launches.json 2>/dev/null
 timeout -k 10 200 python scratch/bench_score.py > $out/score_f32_vs_bf16x3.jsonl 2>/dev/null
 echo "== rocprof kernel trace"
 bash scratch/prof.sh r02b --steps 200 --warmup 20 > /dev/null 2>&1
 cp gpurun_out/prof_r02b/trace_kernel_stats.csv $out/bench_cfg3_kernel_stats.csv; cp gpurun_out/prof_r02b/bench.json $out/bench_cfg3_under_rocprof.json
+python scratch/timeline.py gpurun_out/prof_r02b/trace_kernel_trace.csv > $out/bench_cfg3_timeline.txt 2>&1
 echo "== PMC passes"
 bash scratch/prof_pmc.sh r02 --steps 40 --warmup 10 > /dev/null 2>&1
 python scratch/pmc_summary.py gpurun_out/pmc_r02 $out/pmc_cfg3_sgd.json

@@ -15,6 +15,7 @@
 // from rows padded to BK+4 floats (conflict-free); an m-contiguous operand is read with ds_read_b32.
 // The embedding lookup of a tower's first layer is fused into the A loader (fwd and dW): see GemmArgs::a_ids.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -591,6 +592,7 @@ extern "C" int tt_dense_bwd_batched_f32(const tt_dense_bwd_args* probs, int32_t 
     // median workgroup end 22.8 us).  Pairing two dx tiles per workgroup makes every workgroup equally long and all resident.
     const int64_t dx_tiles = (int64_t)pb.dx_gm * pb.dx_gn, dw_tiles = (int64_t)pb.dw_gm * pb.dw_gn * splits;
     pb.dx_pair = (n_probs * (dx_tiles + dw_tiles) > 1024 && pb.dx_gn % 2 == 0 && 2 * ax[0].k_per_split <= aw[0].k_per_split) ? 1 : 0;
+    if (const char* e = std::getenv("TT_GEMM_DX_PAIR")) pb.dx_pair = (std::atoi(e) != 0 && pb.dx_gn % 2 == 0) ? 1 : 0;
     const int64_t blocks = (int64_t)n_probs * (dx_tiles / (pb.dx_pair ? 2 : 1) + dw_tiles);
     TT_REQUIRE(blocks <= 0x7fffffff && (ax[0].M + BM - 1) / BM <= 0x3fffffff, "tt_dense_bwd_f32: grid too large");
     tt::ProfScope prof("dense_bwd", stream);
