@@ -14,6 +14,7 @@
 // + counters no longer fit 160 KiB of LDS) the list is sorted in 16384-id chunks (one workgroup each, same launch) and a
 // second launch merges them by rank (merge_rank_kernel); only beyond 16 chunks (262144 ids) rocPRIM takes over.
 #include "common.h"
+#include "part_sort.h"
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
@@ -78,21 +79,6 @@ __global__ __launch_bounds__(256) void merge_rank_kernel(MergeArgs a) {
   a.order[rank] = c * kMaxLdsSortIds + a.lpos[e];
 }
 
-template <int DBITS>
-__device__ __forceinline__ uint64_t match_any(uint32_t d) {
-  // per bit: the lane's bit as an all-ones / all-zeros word (v_bfe_i32), one v_cmp (= the ballot), and for each half
-  // of the mask  peers &= ~(ballot ^ word)  (v_xnor + v_and): 6 VALU instructions per bit
-  uint32_t lo = ~0u, hi = ~0u;
-#pragma unroll
-  for (int b = 0; b < DBITS; ++b) {
-    const int32_t word = ((int32_t)(d << (31 - b))) >> 31;
-    const uint64_t m = __builtin_amdgcn_ballot_w64(word != 0);
-    lo &= ~((uint32_t)m ^ (uint32_t)word);
-    hi &= ~((uint32_t)(m >> 32) ^ (uint32_t)word);
-  }
-  return ((uint64_t)hi << 32) | lo;
-}
-
 // element i of the workgroup's sequence sits in (wave, round, lane) = (i / (64*ITEMS), (i / 64) % ITEMS, i % 64)
 template <int ITEMS, int DBITS>
 __global__ __launch_bounds__(1024) void lds_sort_kernel(SortBatch batch) {
@@ -130,7 +116,7 @@ __global__ __launch_bounds__(1024) void lds_sort_kernel(SortBatch batch) {
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r) {
       dg[r] = (key[r] >> shift) & (RADIX - 1);
-      const uint64_t peers = match_any<DBITS>(dg[r]);
+      const uint64_t peers = tt::match_any<DBITS>(dg[r]);
       rk[r] = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
       lead[r] = (uint32_t)__ffsll((unsigned long long)peers) - 1u;
       old[r] = (uint32_t)__popcll(peers);                  // the leader's increment
@@ -201,257 +187,19 @@ __global__ __launch_bounds__(1024) void lds_sort_kernel(SortBatch batch) {
   }
 }
 
-// ---- partitioned sort: G workgroups per table, NO inter-workgroup synchronisation ---------------------------------
-// One workgroup sorting 8192 ids takes 21-33 us (VALU-bound by the ballots).  Here workgroup g of a table owns the key
-// range [g * width, (g+1) * width) of the rows (width = ceil(rows / G); the last group also takes the out-of-range
-// sentinel): it scans ALL n ids (L2-resident, 64-128 KB), counts the keys below its range (= its offset in the sorted
-// output) and compacts its own keys into LDS in position order (ballots + a scan of the per-(load, wave) counts), then
-// sorts only those - n/G ~ 128 of them, ranked by counting in one step; a hot range (> 512 keys) by LSD radix passes over
-// its local key bits - and writes them at its offset.  Every workgroup derives everything it needs from the ids
-// themselves.  Skew only unbalances the work: one hot range is at worst the single-workgroup sort again (capacity = the
-// whole list).  n <= 16384 (positions as u16, one workgroup's LDS can hold every id).
-struct PartTable {
-  const int64_t* ids;
-  int64_t* sorted_ids;
-  int32_t* order;
-  int64_t num_rows;
-  int32_t n, groups;
-  uint32_t width, magic;     // key range of a group = width ids (the last group also takes the sentinel); magic = 2^32 / width + 1
-  uint32_t sentinel;
-};
+// ---- partitioned sort (csrc/part_sort.h): G workgroups per table, each sorting the ids of its own row range ----
 struct PartBatch {
-  PartTable t[kMaxTables];
+  tt::PartTable t[kMaxTables];
   int32_t cap;   // LDS capacity in ids: the longest list of the launch, rounded up to 1024
 };
 
-template <int DBITS, int RMAX>
-__device__ __forceinline__ void part_local_sort(const PartTable& t, uint32_t* keys, uint16_t* poss, uint32_t* cnt, uint32_t* wtot,
-                                                uint32_t m, uint32_t offset, uint32_t base_key, int npass) {
-  constexpr int RADIX = 1 << DBITS;
-  constexpr int W = 16, T = 1024;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  // element e = (w * rounds + r) * 64 + lane
-  const int rounds = (int)((m + T - 1) / T);
-  uint32_t key[RMAX], pos[RMAX];
-#pragma unroll
-  for (int r = 0; r < RMAX; ++r) {
-    key[r] = 0xffffffffu; pos[r] = 0u;
-    if (r < rounds) {
-      const uint32_t e = (uint32_t)((w * rounds + r) * 64 + lane);
-      if (e < m) { key[r] = keys[e]; pos[r] = poss[e]; }
-    }
-  }
-  uint32_t* mycnt = cnt + w * RADIX;
-  for (int p = 0; p < npass; ++p) {
-    __syncthreads();                                        // the loads above / of the previous pass are done
-    const int shift = p * DBITS;
-    for (int j = lane; j < RADIX; j += 64) mycnt[j] = 0u;
-    uint32_t dg[RMAX], rk[RMAX], lead[RMAX], old[RMAX];
-#pragma unroll
-    for (int r = 0; r < RMAX; ++r) {
-      if (r < rounds) {
-        dg[r] = (key[r] >> shift) & (RADIX - 1);
-        const uint64_t peers = match_any<DBITS>(dg[r]);
-        rk[r] = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
-        lead[r] = (uint32_t)__ffsll((unsigned long long)peers) - 1u;
-        old[r] = (uint32_t)__popcll(peers);
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < RMAX; ++r)
-      if (r < rounds && rk[r] == 0u) old[r] = atomicAdd(&mycnt[dg[r]], old[r]);
-#pragma unroll
-    for (int r = 0; r < RMAX; ++r)
-      if (r < rounds) old[r] = (uint32_t)__shfl((int)old[r], (int)lead[r]) + rk[r];
-    __syncthreads();
-    uint32_t v[W], total = 0u;
-    if (tid < RADIX) {
-#pragma unroll
-      for (int ww = 0; ww < W; ++ww) v[ww] = cnt[ww * RADIX + tid];
-#pragma unroll
-      for (int ww = 0; ww < W; ++ww) {
-        const uint32_t x = v[ww];
-        v[ww] = total;
-        total += x;
-      }
-    }
-    uint32_t inc2 = total;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t up = (uint32_t)__shfl_up((int)inc2, o);
-      if (lane >= o) inc2 += up;
-    }
-    if (lane == 63) wtot[w] = inc2;
-    __syncthreads();
-    if (tid < RADIX) {
-      uint32_t base = inc2 - total;
-      for (int ww = 0; ww < w; ++ww) base += wtot[ww];
-#pragma unroll
-      for (int ww = 0; ww < W; ++ww) cnt[ww * RADIX + tid] = base + v[ww];
-    }
-    __syncthreads();
-    if (p + 1 < npass) {
-#pragma unroll
-      for (int r = 0; r < RMAX; ++r)
-        if (r < rounds) {
-          const uint32_t dst = mycnt[dg[r]] + old[r];
-          keys[dst] = key[r];
-          poss[dst] = (uint16_t)pos[r];
-        }
-      __syncthreads();
-#pragma unroll
-      for (int r = 0; r < RMAX; ++r)
-        if (r < rounds) {
-          const uint32_t e = (uint32_t)((w * rounds + r) * 64 + lane);
-          key[r] = keys[e];            // slots >= m hold the padding (all-ones key, sorted last by every pass)
-          pos[r] = poss[e];
-        }
-    } else {
-#pragma unroll
-      for (int r = 0; r < RMAX; ++r)
-        if (r < rounds) {
-          const uint32_t dst = mycnt[dg[r]] + old[r];
-          if (dst < m) {
-            t.sorted_ids[offset + dst] = (int64_t)(key[r] + base_key);
-            t.order[offset + dst] = (int32_t)pos[r];
-          }
-        }
-    }
-  }
-}
-
-// key range of a (clamped) key: key / width by multiply-high + one correction, capped to the last group (which also
-// takes the sentinel 2^bits - 1 of the out-of-range ids); ids past n carry 0xffffffff and belong to no group
-__device__ __forceinline__ uint32_t bucket_of(uint32_t key, const PartTable& t) {
-  if (key == 0xffffffffu) return 0xffffffffu;
-  uint32_t q = __umulhi(key, t.magic);
-  q -= (q * t.width > key) ? 1u : 0u;
-  return q < (uint32_t)t.groups ? q : (uint32_t)t.groups - 1u;
-}
-
-#ifdef TT_SORT_STAMPS
-__device__ unsigned long long g_sort_stamps[1024 * 8];
-#define SSTAMP(i) do { if (threadIdx.x == 0) g_sort_stamps[((blockIdx.x + gridDim.x * blockIdx.y) % 1024) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define SSTAMP(i) do {} while (0)
-#endif
-
 template <int DBITS, int JMAX>     // JMAX: ids per thread of the scan (8: lists <= 8192, 16: <= 16384)
 __global__ __launch_bounds__(1024) void part_sort_kernel(PartBatch batch) {
-  constexpr int RADIX = 1 << DBITS;
-  constexpr int W = 16, T = 1024;
-  const PartTable t = batch.t[blockIdx.y];
-  const int g = blockIdx.x;
-  if (g >= t.groups) return;
+  const tt::PartTable t = batch.t[blockIdx.y];
+  if ((int)blockIdx.x >= t.groups) return;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  uint32_t* keys = smem;                                    // [cap]
-  uint32_t* cnt = keys + batch.cap + 64;                    // [W][RADIX]   (keys: cap + 64 slots of padding)
-  uint32_t* cjw = cnt + W * RADIX;                          // [JMAX][W] own-range keys per (load, wave) -> exclusive bases
-  uint32_t* wtot = cjw + JMAX * W;                          // [16] scan partials
-  uint32_t* wbel = wtot + 16;                               // [16] keys below the range, per wave
-  uint16_t* poss = reinterpret_cast<uint16_t*>(wbel + 16);  // [cap]
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int n = t.n, J = (n + T - 1) / T;
-  SSTAMP(0);
-
-  // ---- scan: every id of the table; clamp; which range ----
-  uint32_t kj[JMAX];
-#pragma unroll
-  for (int j = 0; j < JMAX; ++j) {
-    const int i = j * T + tid;
-    const int64_t id = t.ids[(j < J && i < n) ? i : 0];
-    kj[j] = (j < J && i < n) ? ((id >= 0 && id < t.num_rows) ? (uint32_t)id : t.sentinel) : 0xffffffffu;   // past n: no range
-  }
-  uint32_t below = 0u;
-#pragma unroll
-  for (int j = 0; j < JMAX; ++j) {
-    if (j < J) {
-      const uint32_t b = bucket_of(kj[j], t);
-      const uint64_t mine = __builtin_amdgcn_ballot_w64(b == (uint32_t)g);
-      below += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(b < (uint32_t)g));
-      if (lane == 0) cjw[j * W + w] = (uint32_t)__popcll(mine);
-    }
-  }
-  if (lane == 0) wbel[w] = below;
-  SSTAMP(1);
-  __syncthreads();
-  SSTAMP(2);
-  // exclusive scan of the (load, wave) counts in position order (j major, wave minor); m = keys of this range
-  uint32_t val = (tid < J * W) ? cjw[tid] : 0u, incl = val;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
-    if (lane >= o) incl += up;
-  }
-  if (lane == 63) wtot[w] = incl;
-  __syncthreads();
-  uint32_t pre = 0u, m = 0u, offset = 0u;
-  for (int ww = 0; ww < W; ++ww) {
-    const uint32_t x = wtot[ww];
-    if (ww < w) pre += x;
-    m += x;
-    offset += wbel[ww];
-  }
-  __syncthreads();                                          // everyone has read cjw / wtot
-  if (tid < J * W) cjw[tid] = pre + incl - val;
-  __syncthreads();
-  SSTAMP(3);
-  // ---- compaction in position order: local key (range base removed) + position ----
-#pragma unroll
-  for (int j = 0; j < JMAX; ++j) {
-    if (j < J) {
-      const bool mine = bucket_of(kj[j], t) == (uint32_t)g;
-      const uint64_t mask = __builtin_amdgcn_ballot_w64(mine);
-      if (mine) {
-        const uint32_t dst = cjw[j * W + w] + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-        keys[dst] = kj[j] - (uint32_t)g * t.width;
-        poss[dst] = (uint16_t)(j * T + tid);
-      }
-    }
-  }
-  if (tid < 64) keys[m + (uint32_t)tid] = 0xffffffffu;          // padding for the 4-wide rank loop (LDS holds cap + 64 keys)
-  __syncthreads();
-  SSTAMP(4);
-  if (m == 0u) return;
-  const uint32_t base_key = (uint32_t)g * t.width;
-  if (m <= 512u) {
-    // ---- the usual case (n / groups ~ 128 keys): rank by counting, no further barrier.  P = 1024 / pow2(m) threads per
-    // element e, each compares a 1/P slice of the keys: rank = #(smaller keys) + #(equal keys at an earlier position);
-    // the compaction left the keys in position order, so "earlier position" is "smaller index": stable. ----
-    uint32_t lp = 4;                                        // log2 P: 16 threads per element up to 64 keys ... 2 up to 512
-    while ((T >> lp) < m) --lp;
-    const uint32_t e = (uint32_t)tid >> lp, sub = (uint32_t)tid & ((1u << lp) - 1u), P = 1u << lp;
-    const uint32_t key = keys[e < m ? e : 0u];
-    uint32_t c = 0u;
-    // 4 keys per LDS read; the slots m .. m+63 were filled with 0xffffffff (larger than any local key) before the barrier
-    for (uint32_t j = 4u * sub; j < m; j += 4u * P) {
-      const uint4 k4 = *reinterpret_cast<const uint4*>(keys + j);
-      c += (k4.x < key || (k4.x == key && j < e)) ? 1u : 0u;
-      c += (k4.y < key || (k4.y == key && j + 1u < e)) ? 1u : 0u;
-      c += (k4.z < key || (k4.z == key && j + 2u < e)) ? 1u : 0u;
-      c += (k4.w < key || (k4.w == key && j + 3u < e)) ? 1u : 0u;
-    }
-    for (uint32_t o = 1u; o < P; o <<= 1) c += (uint32_t)__shfl_xor((int)c, (int)o);
-    if (sub == 0u && e < m) {
-      t.sorted_ids[offset + c] = (int64_t)(key + base_key);
-      t.order[offset + c] = (int32_t)poss[e];
-    }
-    SSTAMP(5);
-    return;
-  }
-  // ---- a hot key range: LSD radix sort of the m compacted (local key, position) pairs; register arrays by rounds needed;
-  // passes by the bits of this group's largest local key (the last group's is the sentinel's) ----
-  const uint32_t local_max = g == t.groups - 1 ? t.sentinel - base_key : t.width - 1u;
-  const int lbits = 32 - __builtin_clz(local_max | 1u);
-  const int npass = (lbits + DBITS - 1) / DBITS;
-  if constexpr (JMAX <= 8) {
-    if (m <= 2u * T) part_local_sort<DBITS, 2>(t, keys, poss, cnt, wtot, m, offset, base_key, npass);
-    else part_local_sort<DBITS, 8>(t, keys, poss, cnt, wtot, m, offset, base_key, npass);
-  } else {
-    if (m <= 2u * T) part_local_sort<DBITS, 2>(t, keys, poss, cnt, wtot, m, offset, base_key, npass);
-    else if (m <= 6u * T) part_local_sort<DBITS, 6>(t, keys, poss, cnt, wtot, m, offset, base_key, npass);
-    else part_local_sort<DBITS, 16>(t, keys, poss, cnt, wtot, m, offset, base_key, npass);
-  }
+  uint32_t offset, base_key;
+  (void)tt::part_sort_body<DBITS, JMAX, true>(t, (int)blockIdx.x, batch.cap, smem, offset, base_key);
 }
 
 int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
@@ -544,7 +292,7 @@ int launch_part(PartBatch& b, int nb, int max_n, int max_groups, int max_lbits, 
   const bool nine = npass9 < npass8;
   b.cap = (max_n + 1023) / 1024 * 1024;
   const int radix = nine ? 512 : 256;
-  const int lds = (b.cap + 64 + 16 * radix + 16 * 16 + 32) * 4 + b.cap * 2;
+  const int lds = tt::part_sort_lds_bytes(b.cap, radix);
   const bool small = max_n <= 8 * 1024;
   auto kern = small ? (nine ? part_sort_kernel<9, 8> : part_sort_kernel<8, 8>) : (nine ? part_sort_kernel<9, 16> : part_sort_kernel<8, 16>);
   if (lds > 64 * 1024 &&
@@ -591,7 +339,7 @@ extern "C" int tt_sparse_plan_batched(const tt_sparse_plan_args* tables, int32_t
       continue;
     }
     if (chunks == 1 && env_sort_groups() != 0) {   // one list that fits a workgroup's LDS: key-range partitions, one launch
-      PartTable& t = pb.t[npb++];
+      tt::PartTable& t = pb.t[npb++];
       t.ids = a.ids; t.sorted_ids = a.sorted_ids; t.order = a.order; t.num_rows = a.num_rows; t.n = (int32_t)a.n_ids;
       t.groups = part_groups(t.n, a.num_rows);
       t.width = (uint32_t)((a.num_rows + t.groups - 1) / t.groups);
