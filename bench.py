@@ -148,7 +148,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    from two_tower_amazon_recommender_amd import _lib
+    from two_tower_amazon_recommender_amd import _lib, ops
     from two_tower_amazon_recommender_amd.trainer import TwoTowerConfig, TwoTowerTrainer
 
     if world > 1 or os.environ.get("TT_FORCE_DIST"):      # TT_FORCE_DIST=1: exercise the sharded path on one rank
@@ -228,12 +228,12 @@ def main():
     lookup_us, unfused = None, {}
     if trainer.fuse_lookup and cfg.symmetric and not args.graph:
         trainer.fuse_lookup = trainer.fuse_optimizer = False      # every kernel as its own launch
-        _lib.profile_enable("dense_fwd,dense_bwd,gather,sparse_apply,dense_update", capacity=2 * n_layers * detail_steps + 8)
+        _lib.profile_enable("dense_fwd,dense_bwd,gather,sparse_apply,sparse_plan,dense_update", capacity=2 * n_layers * detail_steps + 8)
         for s in range(total - detail_steps, total):
             step(s)
         torch.cuda.synchronize()
         unfused = {t: _lib.profile_read(t, 2 * n_layers * detail_steps + 8)[0]
-                   for t in ("dense_fwd", "dense_bwd", "gather", "sparse_apply", "dense_update")}
+                   for t in ("dense_fwd", "dense_bwd", "gather", "sparse_apply", "sparse_plan", "dense_update")}
         trainer.fuse_lookup = trainer.fuse_optimizer = True
         f_l0 = mean(prof["dense_fwd"][0::n_layers]) - mean(unfused["dense_fwd"][0::n_layers])
         b_l0 = mean(prof["dense_bwd"][n_layers - 1::n_layers]) - mean(unfused["dense_bwd"][n_layers - 1::n_layers])
@@ -307,9 +307,18 @@ def main():
     plan_on_main = not trainer.plan_on_side_stream
     plan_bytes = 20 * batch * (2 + (1 if cfg.n_category_buckets else 0))     # id read + sorted id + position written, per table
     # the plan is on the step's critical path when it runs on the main stream (the default): then it is COUNTED
-    t_gs = t_gs_noplan + (per_step("sparse_plan") * 1e-3 if plan_on_main else 0.0)
-    if plan_on_main:
+    fused_sort = trainer.fuse_sort and trainer.fuse_optimizer and batch <= ops.sparse_plan_max_lds_ids()
+    plan_ms = (sum(unfused["sparse_plan"]) / detail_steps) if unfused.get("sparse_plan") else per_step("sparse_plan")
+    if fused_sort:
+        # no plan launch: the optimizer launch sorts each row range in LDS and applies the update itself.  Its WHOLE duration
+        # is counted (the dense tower update runs beside the sorting workgroups inside it and ends first)
+        plan_bytes = 8 * batch * (2 + (1 if cfg.n_category_buckets else 0))  # the ids, read once per table (algorithmic)
+        t_gs = max(per_step("optimizer") * 1e-3 + max(lookup_us or 0.0, 0.0) * 1e-6, 1e-12)
         gs_bytes += plan_bytes
+    else:
+        t_gs = t_gs_noplan + (plan_ms * 1e-3 if plan_on_main else 0.0)
+        if plan_on_main:
+            gs_bytes += plan_bytes
     out = {
         "metric": "user-item pairs/sec (train step) + embedding-gather HBM GB/s, 1/2/4/8 MI355X",
         "value": batch / (dt / args.steps), "unit": "pairs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -328,13 +337,18 @@ def main():
         "roofline_hbm": {"bound": "hbm",
                          "kernel": "K1 + K2 on the critical path: the embedding lookup fused into the first tower layer's GEMM "
                                    "loaders (time = what the layer-0 fwd and bwd launches cost MORE than on a materialised "
-                                   "input, from an un-fused detail pass) + the sparse apply (segmented sums, fused SGD/Adagrad, "
-                                   "arrival-ticket finish; all tables; timed as its own launch in the un-fused detail pass - in the "
-                                   "step it shares ONE launch with the dense tower update: optimizer_launch_us) + "
-                                   + ("part_sort_kernel (the sort plan: one launch for all tables, on the main stream in front "
-                                      "of the forward pass). " if plan_on_main else
-                                      "EXCLUDED and reported beside it: part_sort_kernel (the plan: one launch for all tables on "
-                                      "a side stream, concurrent with the forward pass; TT_PLAN_STREAM=side). ")
+                                   "input, from an un-fused detail pass) + "
+                                   + ("optimizer_ids_kernel, the step's ONE optimizer launch, whole duration: every table's ids "
+                                      "are sorted per row range in LDS by the workgroups that then sum the duplicate gradient rows "
+                                      "and apply fused SGD/Adagrad to exactly those rows (no plan launch, no sorted ids in HBM); "
+                                      "the dense tower update runs in the same launch beside them. " if fused_sort else
+                                      "the sparse apply (segmented sums, fused SGD/Adagrad, arrival-ticket finish; all tables; timed "
+                                      "as its own launch in the un-fused detail pass - in the step it shares ONE launch with the "
+                                      "dense tower update: optimizer_launch_us) + "
+                                      + ("part_sort_kernel (the sort plan: one launch for all tables, on the main stream in front "
+                                         "of the forward pass). " if plan_on_main else
+                                         "EXCLUDED and reported beside it: part_sort_kernel (the plan: one launch for all tables on "
+                                         "a side stream, concurrent with the forward pass; TT_PLAN_STREAM=side). "))
                                    + "Each hipEvent bracket adds ~3 us to kernels this short (frac is a lower bound); rocprof "
                                      "durations of the same kernels: profiles/",
                          "achieved": gs_bytes / t_gs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -346,9 +360,11 @@ def main():
                          "sparse_apply_us": apply_ms * 1e3,
                          "optimizer_launch_us": per_step("optimizer") * 1e3,
                          "unfused_dense_update_us": (mean(unfused["dense_update"]) * 1e3) if unfused.get("dense_update") else None,
-                         "sparse_plan_us": per_step("sparse_plan") * 1e3,
-                         "sparse_plan_stream": "main" if plan_on_main else "side",
-                         "frac_without_plan": (gs_bytes - (plan_bytes if plan_on_main else 0)) / t_gs_noplan / 1e9 / HBM_PEAK_GBS,
+                         "sparse_plan_us": plan_ms * 1e3,
+                         "sparse_plan_stream": "inside the optimizer launch (un-fused detail pass figure above)" if fused_sort
+                                               else ("main" if plan_on_main else "side"),
+                         "sort_fused_into_optimizer_launch": bool(fused_sort),
+                         "frac_without_plan": (gs_bytes - (plan_bytes if (plan_on_main or fused_sort) else 0)) / t_gs_noplan / 1e9 / HBM_PEAK_GBS,
                          "algorithmic_bytes": gs_bytes},
         "loss_per_pair": loss / batch,
     }

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TT_ABI_VERSION 6
+#define TT_ABI_VERSION 7
 
 enum {
   TT_OK = 0,
@@ -307,6 +307,20 @@ typedef struct tt_sparse_table {
 } tt_sparse_table;
 int tt_optimizer_step_f32(int32_t opt, const tt_sparse_table* tables, int32_t n_tables, int32_t dim, int64_t n_ids,
                           const tt_dense_seg* segs, int32_t n_segs, float lr, float eps, tt_stream_t stream);
+
+/* The same step from the RAW ids (n_ids <= tt_sparse_plan_max_lds_ids(), else TT_ERR_UNSUPPORTED): no tt_sparse_plan
+ * launch and no sorted ids in HBM — the sorting workgroups of each table (one per row range) apply the update to their
+ * own rows inside the one optimizer launch.  Same results, bit for bit, as tt_sparse_plan_batched +
+ * tt_optimizer_step_f32 (same piece boundaries at global multiples of 64 sorted slots).                            */
+typedef struct tt_sparse_table_ids {
+  float* table; float* accum;            /* [rows, dim]; accum NULL for SGD        */
+  int64_t rows;
+  const float* grads;                    /* [n_ids, dim] per-position gradient rows */
+  const int64_t* ids;                    /* [n_ids] the batch's ids, unsorted       */
+  void* apply_ws;                        /* tt_sparse_apply_workspace_bytes(n_ids, dim) */
+} tt_sparse_table_ids;
+int tt_optimizer_step_ids_f32(int32_t opt, const tt_sparse_table_ids* tables, int32_t n_tables, int32_t dim, int64_t n_ids,
+                              const tt_dense_seg* segs, int32_t n_segs, float lr, float eps, tt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * a3 + a4 — batched dot-product scorer fused with the in-batch sampled-softmax loss

@@ -1,0 +1,33 @@
+"""Phase stamps of optimizer_ids_kernel's sorting workgroups (debug build of sparse.hip with -DTT_SORT_STAMPS via TT_LIB_PATH):
+0 start, 1 ids counted, 2 barrier, 3 scan done, 4 compaction done, 5 ranked (sorted pairs in LDS), 6 rows updated."""
+import ctypes as C
+import os
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from two_tower_amazon_recommender_amd import _lib
+from two_tower_amazon_recommender_amd.trainer import TwoTowerConfig, TwoTowerTrainer
+
+dev = torch.device("cuda:0")
+lib = _lib.load()
+lib.tt_debug_opt_stamps.restype = C.c_int
+lib.tt_debug_opt_stamps.argtypes = [C.c_void_p, C.c_int]
+cfg = TwoTowerConfig(n_users=5_000_000, n_items=10_000_000, embedding_dim=128, tower_dims=[256, 128], batch_size=8192)
+tr = TwoTowerTrainer(cfg, dev, seed=3)
+u, i = tr.synthetic_batch(3, 0)
+for _ in range(5):
+    tr.step(u, i)
+torch.cuda.synchronize()
+buf = np.zeros(1024 * 8, dtype=np.uint64)
+assert lib.tt_debug_opt_stamps(buf.ctypes.data, buf.size) == 0
+allw = buf.reshape(1024, 8)[:, :7].astype(np.int64)
+s = allw[:256]
+s = s[s[:, 6] > s[:, 0]]
+t0 = s[:, 0].min()
+us = (s - t0) / 100.0
+print(len(s), "sorting WGs; mean stamp times (us):", us.mean(0).round(2).tolist(), "max end", us[:, 6].max(), "start spread", us[:, 0].max())
+d = allw[256:256 + 64]
+d = d[d[:, 6] > d[:, 0]]
+ud = (d - t0) / 100.0
+print(len(d), "dense blocks: start", ud[:, 0].round(2).tolist()[:40], "end", ud[:, 6].round(2).tolist()[:40])

@@ -282,6 +282,65 @@ def test_sparse_heavy_hitters_are_split_into_pieces_bit_exact(dev, opt, n):
     assert np.array_equal(d_table.cpu().numpy().view(np.uint32), ref.view(np.uint32))
 
 
+@pytest.mark.parametrize("opt", ["sgd", "adagrad"])
+@pytest.mark.parametrize("n,dim,rows,kind", [(8192, 128, (5_000_000, 100_000), "U"), (8192, 128, (100_000, 3_000), "Z"),
+                                             (16384, 128, (1_000_000, 50_000), "Z"), (1000, 32, (777, 40), "U"),
+                                             (4096, 256, (20_000, 20_000), "Z"), (9000, 128, (1000, 1000), "heavy"),
+                                             (300, 64, (5, 1), "U")])
+def test_optimizer_step_from_raw_ids_matches_plan_then_step_bit_for_bit(dev, opt, n, dim, rows, kind):
+    """tt_optimizer_step_ids_f32 — the optimizer launch sorts the ids of each row range in LDS and updates those rows
+    itself, no plan launch, no sorted ids in HBM — against tt_sparse_plan_batched + tt_optimizer_step_f32 (itself
+    bit-exact vs the oracle above): tables, accumulators and dense parameters identical bit for bit, for uniform / Zipf /
+    heavy-hitter ids (runs of thousands, several pieces), out-of-range and padding ids, three tables (the third with 30
+    rows: every id hundreds of times), tiny tables."""
+    rng = np.random.default_rng(5)
+    rows3 = list(rows) + [30]
+    ids = []
+    for t, r in enumerate(rows3):
+        if kind == "heavy":
+            x = np.concatenate([np.full(7000, 17 % r), np.full(129, 18 % r), np.full(64, 400 % r), rng.integers(0, r, n - 7000 - 129 - 64)])
+            rng.shuffle(x)
+        elif kind == "Z":
+            x = synth.ids_powerlaw(5, 3 + t, n, r)
+        else:
+            x = rng.integers(0, r, n)
+        x = x.astype(np.int64)
+        x[rng.integers(0, n, 5)] = -1                     # padding
+        x[rng.integers(0, n, 5)] = r + 3                  # out of range: skipped
+        ids.append(T(x, dev))
+    grads = [T(synth.uniform_f32(6, 9 + t, n * dim, -1.0, 2.0).reshape(n, dim), dev) for t in range(3)]
+    wslab = T(synth.uniform_f32(6, 20, 4 * 1000, -1.0, 2.0).reshape(4, 1000), dev)
+
+    def state():
+        tabs = [T(synth.embedding_table(7, 1 + t, r, dim), dev) for t, r in enumerate(rows3)]
+        accs = [torch.full_like(x, 0.1) if opt == "adagrad" else None for x in tabs]
+        w = T(synth.uniform_f32(7, 30, 1000, -1.0, 2.0), dev)
+        wacc = torch.full_like(w, 0.1) if opt == "adagrad" else None
+        return tabs, accs, w, wacc
+
+    plans = [ops.SparsePlan(n, dev) for _ in range(3)]
+    # reference: plan launch + optimizer step
+    ta, aa, wa, wacca = state()
+    ops.sparse_plan_batched(plans, ids, rows3)
+    ops.optimizer_step_(opt, [(ta[t], aa[t], grads[t], plans[t]) for t in range(3)],
+                        [ops.make_dense_seg(wa, wacca, wslab, 4, 1e-6)], 0.01, 1e-7)
+    # from the raw ids
+    tb, ab, wb, waccb = state()
+    ops.optimizer_step_ids_(opt, [(tb[t], ab[t], grads[t], ids[t], plans[t]) for t in range(3)],
+                            [ops.make_dense_seg(wb, waccb, wslab, 4, 1e-6)], 0.01, 1e-7)
+    for t in range(3):
+        assert torch.equal(ta[t], tb[t]), f"table {t}"
+        if opt == "adagrad":
+            assert torch.equal(aa[t], ab[t]), f"accumulator {t}"
+    assert torch.equal(wa, wb)
+    changed = (tb[0] != T(synth.embedding_table(7, 1, rows3[0], dim), dev)).any(1)
+    assert changed.sum().item() > 0
+    with pytest.raises(NotImplementedError):
+        big = ops.SparsePlan(20000, dev)
+        ops.optimizer_step_ids_(opt, [(tb[0], ab[0], torch.empty(20000, dim, device=dev), torch.zeros(20000, dtype=torch.int64, device=dev), big)],
+                                [ops.make_dense_seg(wb, waccb, wslab, 4, 1e-6)], 0.01, 1e-7)
+
+
 def test_sparse_update_is_run_to_run_deterministic(dev):
     rows, dim, n = 1000, 128, 8192                     # heavy duplication
     table = synth.embedding_table(24, 1, rows, dim)

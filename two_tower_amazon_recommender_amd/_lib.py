@@ -15,7 +15,7 @@ import threading
 _PKG = pathlib.Path(__file__).resolve().parent
 # TT_LIB_PATH: load another build of the same C ABI (kernel A/B experiments); the product default is the in-tree library
 LIB_PATH = pathlib.Path(os.environ["TT_LIB_PATH"]) if os.environ.get("TT_LIB_PATH") else _PKG / "libtwotower_hip.so"
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 TT_OK, TT_ERR_INVALID_ARG, TT_ERR_LAUNCH, TT_ERR_UNSUPPORTED, TT_ERR_WORKSPACE = range(5)
 TT_OPT_SGD, TT_OPT_ADAGRAD = 0, 1
@@ -56,6 +56,12 @@ class SparseTable(C.Structure):
     """Mirror of ``tt_sparse_table`` (one embedding table of the single-launch optimizer step)."""
     _fields_ = [("table", C.c_void_p), ("accum", C.c_void_p), ("rows", C.c_int64), ("grads", C.c_void_p),
                 ("sorted_ids", C.c_void_p), ("order", C.c_void_p), ("apply_ws", C.c_void_p)]
+
+
+class SparseTableIds(C.Structure):
+    """Mirror of ``tt_sparse_table_ids`` (one embedding table of the optimizer step that starts from the raw ids)."""
+    _fields_ = [("table", C.c_void_p), ("accum", C.c_void_p), ("rows", C.c_int64), ("grads", C.c_void_p),
+                ("ids", C.c_void_p), ("apply_ws", C.c_void_p)]
 
 
 class DenseSeg(C.Structure):
@@ -104,6 +110,7 @@ SIGNATURES = {
     "tt_dense_bwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
     "tt_dense_update_f32": (C.c_int, [C.POINTER(DenseSeg), _i32, _i32, _i32, _f, _f, _p]),
     "tt_optimizer_step_f32": (C.c_int, [_i32, C.POINTER(SparseTable), _i32, _i32, _i64, C.POINTER(DenseSeg), _i32, _f, _f, _p]),
+    "tt_optimizer_step_ids_f32": (C.c_int, [_i32, C.POINTER(SparseTableIds), _i32, _i32, _i64, C.POINTER(DenseSeg), _i32, _f, _f, _p]),
     "tt_retrieval_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "tt_retrieval_rank_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "tt_retrieval_fwd_f32": (C.c_int, [_p, _p, _i64, _i64, _i32, _i64, _f, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p]),

@@ -27,16 +27,17 @@ __device__ __forceinline__ float apply_one(const tt_dense_seg& s, int64_t i, flo
 
 // One thread owns 4 consecutive elements (float4 loads when the segment allows it) and keeps 8 slabs' loads in
 // flight; the additions stay in slab order (the oracle's order).
-template <int OPT>
+// (TPB = threads per block of the launch; every element is summed and updated on its own, so TPB changes nothing in the results)
+template <int OPT, int TPB = 256>
 __device__ __forceinline__ void dense_update_body(const tt_dense_seg& s, const int bx, const int nbx, int apply, float lr, float eps) {
-  const int64_t stride = (int64_t)nbx * 256;
+  const int64_t stride = (int64_t)nbx * TPB;
   const bool vec = (s.count % 4 == 0) && (s.slab_stride % 4 == 0) && al16(s.grad_slabs) &&
                    (s.grad_out == nullptr || al16(s.grad_out)) && (!apply || al16(s.param)) &&
                    (!apply || OPT == TT_OPT_SGD || al16(s.accum));
   if (vec) {
     const int64_t n4 = s.count / 4, st4 = s.slab_stride / 4;
     const f32x4* __restrict__ gs = reinterpret_cast<const f32x4*>(s.grad_slabs);
-    for (int64_t i = (int64_t)bx * 256 + threadIdx.x; i < n4; i += stride) {
+    for (int64_t i = (int64_t)bx * TPB + threadIdx.x; i < n4; i += stride) {
       f32x4 g = gs[i];
       for (int k0 = 1; k0 < s.n_slabs; k0 += 8) {
         f32x4 v[8];
@@ -58,7 +59,7 @@ __device__ __forceinline__ void dense_update_body(const tt_dense_seg& s, const i
     }
     return;
   }
-  for (int64_t i = (int64_t)bx * 256 + threadIdx.x; i < s.count; i += stride) {
+  for (int64_t i = (int64_t)bx * TPB + threadIdx.x; i < s.count; i += stride) {
     float g = s.grad_slabs[i];
     for (int k = 1; k < s.n_slabs; ++k) g = __fadd_rn(g, s.grad_slabs[(int64_t)k * s.slab_stride + i]);
     if (s.grad_out != nullptr) s.grad_out[i] = g;

@@ -42,8 +42,8 @@ struct PartTable {
 };
 
 #ifdef TT_SORT_STAMPS
-__device__ unsigned long long g_sort_stamps[1024 * 8];
-#define SSTAMP(i) do { if (threadIdx.x == 0) g_sort_stamps[((blockIdx.x + gridDim.x * blockIdx.y) % 1024) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+static __device__ unsigned long long g_sort_stamps[1024 * 8];   // (one copy per translation unit: debug builds only)
+#define SSTAMP(i) do { if (threadIdx.x == 0) tt::g_sort_stamps[((blockIdx.x + gridDim.x * blockIdx.y) % 1024) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define SSTAMP(i) do {} while (0)
 #endif

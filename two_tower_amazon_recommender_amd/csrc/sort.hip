@@ -252,7 +252,7 @@ int plan_rocprim(const tt_sparse_plan_args& a, hipStream_t stream) {
 
 #ifdef TT_SORT_STAMPS
 extern "C" int tt_debug_sort_stamps(unsigned long long* host_out, int n) {
-  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_sort_stamps), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 0 : 2;
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(tt::g_sort_stamps), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 0 : 2;
 }
 #endif
 

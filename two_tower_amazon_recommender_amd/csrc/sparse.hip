@@ -15,6 +15,8 @@
 // [+ 8*dim accumulator read/write for Adagrad] + 12 (sorted id + position).
 #include "common.h"
 #include "dense_update_body.h"
+#include "part_sort.h"
+#include <cstdlib>
 #include <cstring>
 
 namespace {
@@ -37,15 +39,14 @@ struct ApplyArgs {
   int32_t* p_flag[kMaxSparseTables];   // [nblk]       arrival ticket of the deferred run whose head is in block j (0 between launches)
 };
 
+// the update of 4 elements of a row given its (already loaded) weights w and accumulator acc
 template <int OPT>
-__device__ __forceinline__ void update_row(f32x4* __restrict__ table, f32x4* __restrict__ accum, int64_t off, const f32x4& g,
-                                           float lr, float eps) {
-  f32x4 w = table[off];
+__device__ __forceinline__ void update_store(f32x4* __restrict__ table, f32x4* __restrict__ accum, int64_t off, f32x4 w, f32x4 acc,
+                                             const f32x4& g, float lr, float eps) {
   if constexpr (OPT == TT_OPT_SGD) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) w[e] = __fsub_rn(w[e], __fmul_rn(lr, g[e]));
   } else {
-    f32x4 acc = accum[off];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       acc[e] = __fadd_rn(acc[e], __fmul_rn(g[e], g[e]));
@@ -55,6 +56,15 @@ __device__ __forceinline__ void update_row(f32x4* __restrict__ table, f32x4* __r
     accum[off] = acc;
   }
   table[off] = w;
+}
+
+template <int OPT>
+__device__ __forceinline__ void update_row(f32x4* __restrict__ table, f32x4* __restrict__ accum, int64_t off, const f32x4& g,
+                                           float lr, float eps) {
+  const f32x4 w = table[off];
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (OPT != TT_OPT_SGD) acc = accum[off];
+  update_store<OPT>(table, accum, off, w, acc, g, lr, eps);
 }
 
 // Summation order (the oracle's dedup_sum restates it): a run of equal ids occupies consecutive sorted slots; it is cut
@@ -195,6 +205,178 @@ __global__ __launch_bounds__(256, 8) void optimizer_kernel(ApplyArgs a, int n_ta
     if ((int64_t)blockIdx.x < sparse_blocks) sparse_apply_body<OPT>(a, blockIdx.y, blockIdx.x, dim4, lpr_log2, n_ids, lr, eps);
   } else if ((int)blockIdx.x < dense_blocks) {
     tt::dense_update_body<OPT>(tbl.seg[blockIdx.y - n_tables], blockIdx.x, dense_blocks, 1, lr, eps);
+  }
+}
+
+// ---- the optimizer step FROM THE RAW IDS: sort + apply in one workgroup (no plan launch, no sorted ids in HBM) --------
+// Workgroup g of table t sorts the ids of its row range in LDS (csrc/part_sort.h) — that is: it knows the position
+// `offset` of its first key in the table's sorted list and holds its m (local key, batch position) pairs in sorted
+// order — and applies the update to exactly those rows itself: equal ids share a row range, so every run of the sorted
+// list lies inside ONE workgroup and the arrival tickets of sparse_apply_body are not needed.  Summation order is the
+// same as there, bit for bit: a run is cut into pieces at GLOBAL multiples of 64 sorted slots (offset + i), each piece is
+// summed sequentially, the pieces are added in index order (phase B, after a workgroup barrier; piece sums travel
+// through the same p_sum / s_sum workspace).
+struct FusedTables {
+  tt::PartTable part[kMaxSparseTables];
+  int32_t cap;
+  int32_t first[kMaxSparseTables + 1];        // flat workgroup index of table t's group 0; first[n_tables] = first dense block
+  int32_t seg_first[TT_MAX_DENSE_SEGS + 1];   // flat index (from first[n_tables]) of segment s's block 0
+};
+
+template <int OPT, int DBITS>
+__device__ __forceinline__ void apply_from_lds(const ApplyArgs& a, const int t, const uint32_t* K, const uint16_t* P, const uint32_t m,
+                                               const uint32_t offset, const uint32_t base_key, int dim4, int lpr_log2, float lr,
+                                               float eps, int* s_multi) {
+  f32x4* __restrict__ table = reinterpret_cast<f32x4*>(a.table[t]);
+  f32x4* __restrict__ accum = reinterpret_cast<f32x4*>(a.accum[t]);
+  const f32x4* __restrict__ grads = reinterpret_cast<const f32x4*>(a.grads[t]);
+  const int64_t rows = a.rows[t];
+  const int lpr = 1 << lpr_log2;
+  const uint32_t ngroups = 1024u >> lpr_log2;
+  const uint32_t grp = threadIdx.x >> lpr_log2;
+  const int l = threadIdx.x & (lpr - 1);
+
+  // what slot i has to do: 0 nothing (inside a piece / skipped id), else the end e of its piece
+  auto piece = [&](uint32_t i, uint32_t& e, bool& run_head, bool& continues) -> bool {
+    if (i >= m) return false;
+    const uint32_t key = K[i];
+    run_head = (i == 0u) || (K[i - 1u] != key);               // runs never cross a workgroup: slot 0 always starts one
+    const uint32_t kg = offset + i;
+    if (!run_head && (kg % kPiece) != 0u) return false;
+    if ((int64_t)base_key + key >= rows) return false;        // the out-of-range sentinel is skipped
+    uint32_t iend = i + (kPiece - kg % kPiece);
+    if (iend > m) iend = m;
+    e = i + 1u;
+    while (e < iend && K[e] == key) ++e;
+    continues = (e == iend) && (iend < m) && (K[iend] == key);
+    return true;
+  };
+
+  // ---- phase A: every piece is summed; whole runs (the usual case) are applied at once.  A lane group owns the slots
+  // grp, grp + ngroups, ...: the first gradient row AND the table (accumulator) row of its first RP slots are requested
+  // before any of them is finished (one memory round trip for the usual 2-3 slots per group instead of one per slot). ----
+  bool multi = false;
+  auto finish = [&](uint32_t i, uint32_t e, bool head, bool cont, bool pre, const f32x4& g0, const f32x4& w0, const f32x4& a0) {
+    const int64_t id = (int64_t)base_key + K[i];
+    const bool whole = head && !cont;
+    const int64_t blk = (int64_t)(offset + i) / kPiece;
+    for (int c = l; c < dim4; c += lpr) {
+      const bool first = pre && c == l;
+      f32x4 g = first ? g0 : grads[(int64_t)P[i] * dim4 + c];
+      uint32_t j = i + 1u;
+      while (j + 3u < e) {
+        f32x4 r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r[u] = grads[(int64_t)P[j + u] * dim4 + c];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) g[q] = __fadd_rn(g[q], r[u][q]);
+        j += 4u;
+      }
+      while (j < e) {
+        const f32x4 g1 = grads[(int64_t)P[j] * dim4 + c];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g[q] = __fadd_rn(g[q], g1[q]);
+        ++j;
+      }
+      if (whole) {
+        if (first) update_store<OPT>(table, accum, id * dim4 + c, w0, a0, g, lr, eps);
+        else update_row<OPT>(table, accum, id * dim4 + c, g, lr, eps);
+      } else if (head) {
+        reinterpret_cast<f32x4*>(a.p_sum[t])[blk * dim4 + c] = g;
+      } else {
+        reinterpret_cast<f32x4*>(a.s_sum[t])[blk * dim4 + c] = g;
+      }
+    }
+    multi = multi || !whole;
+  };
+  constexpr int RP = 4;
+  {
+    f32x4 g0[RP], w0[RP], a0[RP];
+    uint32_t ee[RP];
+    bool act[RP], hd[RP], ct[RP];
+#pragma unroll
+    for (int r = 0; r < RP; ++r) {
+      const uint32_t i = grp + (uint32_t)r * ngroups;
+      ee[r] = 0u; hd[r] = false; ct[r] = false;
+      g0[r] = f32x4{0.f, 0.f, 0.f, 0.f}; w0[r] = g0[r]; a0[r] = g0[r];
+      act[r] = piece(i, ee[r], hd[r], ct[r]);
+      if (act[r] && l < dim4) {
+        g0[r] = grads[(int64_t)P[i] * dim4 + l];
+        if (hd[r] && !ct[r]) {
+          const int64_t off = ((int64_t)base_key + K[i]) * dim4 + l;
+          w0[r] = table[off];
+          if constexpr (OPT != TT_OPT_SGD) a0[r] = accum[off];
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RP; ++r)
+      if (act[r]) finish(grp + (uint32_t)r * ngroups, ee[r], hd[r], ct[r], true, g0[r], w0[r], a0[r]);
+  }
+  for (uint32_t i = grp + RP * ngroups; i < m; i += ngroups) {     // (a hot range: more than RP slots per lane group)
+    uint32_t e = 0u;
+    bool head = false, cont = false;
+    const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (piece(i, e, head, cont)) finish(i, e, head, cont, false, z, z, z);
+  }
+  if (multi && l == 0) *s_multi = 1;
+  // ---- phase B (only when some run of this workgroup has several pieces): the run's head adds the pieces in index order ----
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  if (*s_multi == 0) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  for (uint32_t h = grp; h < m; h += ngroups) {
+    uint32_t he = 0u;
+    bool hh = false, hc = false;
+    if (!piece(h, he, hh, hc) || !hh || !hc) continue;        // heads of multi-piece runs only
+    const uint32_t key = K[h];
+    uint32_t last = he;                                       // one past the last slot of the run
+    while (last < m && K[last] == key) ++last;
+    const int64_t id = (int64_t)base_key + key;
+    const int64_t jh = (int64_t)(offset + h) / kPiece, jl = (int64_t)(offset + last - 1u) / kPiece;
+    const f32x4* Ps = reinterpret_cast<const f32x4*>(a.p_sum[t]);
+    const f32x4* Ss = reinterpret_cast<const f32x4*>(a.s_sum[t]);
+    for (int c = l; c < dim4; c += lpr) {
+      f32x4 g = Ps[jh * dim4 + c];
+      for (int64_t mb = jh + 1; mb <= jl; ++mb) {
+        const f32x4 sv = Ss[mb * dim4 + c];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g[q] = __fadd_rn(g[q], sv[q]);
+      }
+      update_row<OPT>(table, accum, id * dim4 + c, g, lr, eps);
+    }
+  }
+}
+
+template <int OPT, int DBITS, int JMAX>
+__global__ __launch_bounds__(1024) void optimizer_ids_kernel(ApplyArgs a, FusedTables ft, int n_tables, int dim4, int lpr_log2,
+                                                              tt::SegTable tbl, int dense_blocks, float lr, float eps) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  __shared__ int s_multi;
+  // flat grid: exactly the dense blocks each segment needs FIRST (a sorting workgroup fills a CU - 16 waves at up to 128
+  // VGPRs - so dense blocks dispatched behind 256 of them would only start when those retire: r02 stamps, 10 us late),
+  // then the sorting workgroups of table 0, 1, (2); the host keeps the total at one workgroup per CU
+  const int b = (int)blockIdx.x - ft.seg_first[dense_blocks];
+  if (b >= 0) {
+    int ti = 0;
+    while (ti + 1 < n_tables && b >= ft.first[ti + 1]) ++ti;
+    const tt::PartTable& t = ft.part[ti];
+    if (threadIdx.x == 0) s_multi = 0;
+    uint32_t offset, base_key;
+    const uint32_t m = tt::part_sort_body<DBITS, JMAX, false>(t, b - ft.first[ti], ft.cap, smem, offset, base_key);
+    if (m == 0u) return;
+    apply_from_lds<OPT, DBITS>(a, ti, tt::part_keys(smem), tt::part_poss<DBITS>(smem, ft.cap), m, offset, base_key, dim4,
+                               lpr_log2, lr, eps, &s_multi);
+    SSTAMP(6);
+  } else {
+    const int d = (int)blockIdx.x;
+    int si = 0;
+    while (si + 1 < dense_blocks && d >= ft.seg_first[si + 1]) ++si;        // (dense_blocks = number of segments here)
+    SSTAMP(0);
+    tt::dense_update_body<OPT, 1024>(tbl.seg[si], d - ft.seg_first[si], ft.seg_first[si + 1] - ft.seg_first[si], 1, lr, eps);
+    SSTAMP(6);
   }
 }
 
@@ -354,3 +536,100 @@ extern "C" int tt_optimizer_step_f32(int32_t opt, const tt_sparse_table* tables,
                        n_tables, dim4, lpr_log2, n_ids, sparse_blocks, tbl, (int)dense_blocks, lr, eps);
   return tt::check_launch("tt_optimizer_step_f32");
 }
+
+// The same optimizer step from the RAW ids: no tt_sparse_plan launch, no sorted ids / positions in HBM.  One launch: the
+// sorting workgroups of every table (n/64 per table, csrc/part_sort.h) apply the update to the rows of their own key
+// range, the dense segments are updated beside them.  n_ids <= tt_sparse_plan_max_lds_ids(); same results, bit for bit, as
+// tt_sparse_plan_batched + tt_optimizer_step_f32.
+extern "C" int tt_optimizer_step_ids_f32(int32_t opt, const tt_sparse_table_ids* tables, int32_t n_tables, int32_t dim, int64_t n_ids,
+                                         const tt_dense_seg* segs, int32_t n_segs, float lr, float eps, tt_stream_t stream_) {
+  TT_REQUIRE(opt == TT_OPT_SGD || opt == TT_OPT_ADAGRAD, "tt_optimizer_step_ids_f32: unknown optimizer %d", opt);
+  TT_REQUIRE(tables != nullptr && n_tables >= 1 && n_tables <= kMaxSparseTables, "tt_optimizer_step_ids_f32: 1..%d sparse tables", kMaxSparseTables);
+  TT_REQUIRE(segs != nullptr && n_segs >= 1 && n_segs <= TT_MAX_DENSE_SEGS, "tt_optimizer_step_ids_f32: 1..%d dense segments", TT_MAX_DENSE_SEGS);
+  TT_REQUIRE(n_ids > 0 && dim > 0 && dim % 4 == 0, "tt_optimizer_step_ids_f32: bad n_ids/dim");
+  if (n_ids > tt::kPartSortMaxIds)
+    return tt::fail(TT_ERR_UNSUPPORTED, "tt_optimizer_step_ids_f32: n_ids %lld > %d (use tt_sparse_plan_batched + tt_optimizer_step_f32)",
+                    (long long)n_ids, tt::kPartSortMaxIds);
+  ApplyArgs a{};
+  FusedTables ft{};
+  void* ws[kMaxSparseTables] = {};
+  int max_groups = 0, max_lbits = 1;
+  for (int i = 0; i < n_segs; ++i) {                      // one thread per 4 elements, at most 16 blocks per segment
+    int64_t nb = (segs[i].count / 4 + 1023) / 1024;
+    if (nb < 1) nb = 1;
+    if (nb > 16) nb = 16;
+    ft.seg_first[i + 1] = ft.seg_first[i] + (int32_t)nb;
+  }
+  // sorting workgroups: ~64 ids each (two rounds of the apply's 32 lane groups), and no more than fit beside the dense
+  // blocks at one workgroup per CU
+  int64_t group_cap = (256 - ft.seg_first[n_segs]) / n_tables;
+  if (group_cap < 16) group_cap = 16;
+  for (int t = 0; t < n_tables; ++t) {
+    const tt_sparse_table_ids& s = tables[t];
+    TT_REQUIRE(s.table && s.grads && s.ids && s.rows > 0, "tt_optimizer_step_ids_f32: table %d: null pointer / bad rows", t);
+    TT_REQUIRE(s.rows <= 0x7fffffff, "tt_optimizer_step_ids_f32: table %d: rows must fit in 31 bits", t);
+    TT_REQUIRE(opt == TT_OPT_SGD || s.accum != nullptr, "tt_optimizer_step_ids_f32: table %d: Adagrad needs the accumulator", t);
+    TT_REQUIRE(tt::aligned16(s.table) && tt::aligned16(s.grads) && tt::aligned16(s.accum), "tt_optimizer_step_ids_f32: table %d: pointers must be 16-byte aligned", t);
+    a.table[t] = s.table; a.accum[t] = s.accum; a.grads[t] = s.grads; a.rows[t] = s.rows;
+    ws[t] = s.apply_ws;
+    int bits = 1;
+    while (bits < 63 && ((int64_t)1 << bits) < s.rows + 1) ++bits;
+    tt::PartTable& p = ft.part[t];
+    p.ids = s.ids; p.sorted_ids = nullptr; p.order = nullptr; p.num_rows = s.rows; p.n = (int32_t)n_ids;
+    int64_t g = (n_ids + 63) / 64;
+    if (g > 128) g = 128;
+    if (g > group_cap) g = group_cap;
+    if (g > s.rows / 2) g = s.rows / 2;
+    p.groups = g < 1 ? 1 : (int32_t)g;
+    p.width = (uint32_t)((s.rows + p.groups - 1) / p.groups);
+    if (p.width < 2u) p.width = 2u;
+    p.magic = (uint32_t)((((uint64_t)1 << 32) / p.width) + 1u);
+    p.sentinel = (uint32_t)(((uint64_t)1 << bits) - 1);
+    int lb = 1;
+    while (((int64_t)1 << lb) < (int64_t)p.width) ++lb;
+    if (lb > max_lbits) max_lbits = lb;
+    if (p.groups > max_groups) max_groups = p.groups;
+    ft.first[t + 1] = ft.first[t] + p.groups;
+  }
+  int rc = prepare_ws(a, ws, n_tables, dim, n_ids, "tt_optimizer_step_ids_f32");
+  if (rc != TT_OK) return rc;
+  tt::SegTable tbl{};
+  int64_t max_count = 0;
+  for (int i = 0; i < n_segs; ++i) {
+    const tt_dense_seg& s = segs[i];
+    TT_REQUIRE(s.count > 0 && s.n_slabs >= 1 && s.grad_slabs != nullptr && s.param != nullptr, "tt_optimizer_step_ids_f32: segment %d: bad count/slabs/param", i);
+    TT_REQUIRE(opt == TT_OPT_SGD || s.accum != nullptr, "tt_optimizer_step_ids_f32: segment %d: Adagrad needs accum", i);
+    tbl.seg[i] = s;
+    if (s.count > max_count) max_count = s.count;
+  }
+  const int dim4 = dim / 4;
+  int lpr_log2 = 0;
+  while ((1 << lpr_log2) < dim4 && lpr_log2 < 6) ++lpr_log2;
+  (void)max_count; (void)max_groups;
+  const int64_t gx = (int64_t)ft.first[n_tables] + ft.seg_first[n_segs];
+  ft.cap = (int32_t)((n_ids + 1023) / 1024 * 1024);
+  const bool nine = (max_lbits + 8) / 9 < (max_lbits + 7) / 8;     // digits of the hot-range radix passes (csrc/sort.hip)
+  const bool small = n_ids <= 8 * 1024;
+  const int lds = tt::part_sort_lds_bytes(ft.cap, nine ? 512 : 256);
+  hipStream_t stream = tt::as_stream(stream_);
+  auto go = [&](auto kern) -> int {
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return tt::fail(TT_ERR_LAUNCH, "tt_optimizer_step_ids_f32: hipFuncSetAttribute(LDS %d) failed", lds);
+    tt::ProfScope prof("optimizer", stream);
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(1024), lds, stream, a, ft, n_tables, dim4, lpr_log2, tbl, n_segs, lr, eps);
+    return tt::check_launch("tt_optimizer_step_ids_f32");
+  };
+  if (opt == TT_OPT_SGD) {
+    if (small) return nine ? go(optimizer_ids_kernel<TT_OPT_SGD, 9, 8>) : go(optimizer_ids_kernel<TT_OPT_SGD, 8, 8>);
+    return nine ? go(optimizer_ids_kernel<TT_OPT_SGD, 9, 16>) : go(optimizer_ids_kernel<TT_OPT_SGD, 8, 16>);
+  }
+  if (small) return nine ? go(optimizer_ids_kernel<TT_OPT_ADAGRAD, 9, 8>) : go(optimizer_ids_kernel<TT_OPT_ADAGRAD, 8, 8>);
+  return nine ? go(optimizer_ids_kernel<TT_OPT_ADAGRAD, 9, 16>) : go(optimizer_ids_kernel<TT_OPT_ADAGRAD, 8, 16>);
+}
+
+#ifdef TT_SORT_STAMPS
+extern "C" int tt_debug_opt_stamps(unsigned long long* host_out, int n) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(tt::g_sort_stamps), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 0 : 2;
+}
+#endif

@@ -441,6 +441,33 @@ def optimizer_step_(opt: str, tables, segs: list[DenseSeg], lr: float, eps: floa
                "tt_optimizer_step_f32")
 
 
+def sparse_plan_max_lds_ids() -> int:
+    """Longest id list the one-launch LDS sort (and the optimizer step from raw ids) takes: 16384."""
+    return int(_lib.load().tt_sparse_plan_max_lds_ids())
+
+
+def optimizer_step_ids_(opt: str, tables, segs: list[DenseSeg], lr: float, eps: float = 1e-7):
+    """The same step from the RAW ids, no sort-plan launch: ``tables`` = [(table, accum or None, grads, ids, plan), ...]
+    (``plan`` only lends its apply workspace); n_ids <= sparse_plan_max_lds_ids().  Bit-identical to
+    ``sparse_plan_batched`` + ``optimizer_step_``."""
+    dim, n_ids = tables[0][0].shape[1], tables[0][3].numel()
+    arr_t = (_lib.SparseTableIds * len(tables))()
+    for i, (table, accum, grads, ids, plan) in enumerate(tables):
+        _chk(table, torch.float32, "table", 2)
+        _chk(grads, torch.float32, "grads", 2)
+        _chk(ids, torch.int64, "ids", 1)
+        if accum is not None:
+            _chk(accum, torch.float32, "accum", 2)
+            if accum.shape != table.shape:
+                raise RuntimeError("optimizer_step_ids_: accum must have the table's shape")
+        if table.shape[1] != dim or ids.numel() != n_ids or plan.n_ids != n_ids or tuple(grads.shape) != (n_ids, dim):
+            raise RuntimeError("optimizer_step_ids_: every table needs the same dim, the same number of ids and [n_ids, dim] gradients")
+        arr_t[i] = _lib.SparseTableIds(_p(table), _p(accum), table.shape[0], _p(grads), _p(ids), _p(plan.apply_ws(dim)))
+    arr_s = (DenseSeg * len(segs))(*segs)
+    _lib.check(_lib.load().tt_optimizer_step_ids_f32(_OPT[opt], arr_t, len(tables), dim, n_ids, arr_s, len(segs), lr, eps, _stream()),
+               "tt_optimizer_step_ids_f32")
+
+
 def make_dense_seg(param, accum, grad_slabs, n_slabs: int, l2: float, grad_out=None) -> DenseSeg:
     count = param.numel()
     return DenseSeg(_p(param), _p(accum), _p(grad_slabs), _p(grad_out), count, count, n_slabs, l2)

@@ -249,6 +249,7 @@ class TwoTowerTrainer:
         self.plan_on_side_stream = os.environ.get("TT_PLAN_STREAM", "main") == "side"
         self.step_index = 0                      # counter of the dropout stream (global batch row = step*batch + r)
         self.fuse_lookup = True                  # K1 inside the first tower layer's GEMMs (False: gather2 launch + acts[0])
+        self.fuse_sort = os.environ.get("TT_FUSE_SORT", "1") != "0"   # the optimizer launch sorts the ids itself (no plan launch)
         self.fuse_optimizer = True               # sparse + dense optimizer in one launch (False: dense_update, sparse_update2 [, cat])
         self.flag_poll_every = 50                # steps between asynchronous polls of the out-of-range flag (0 = never)
         self._oob_host = self._oob_event = None
@@ -354,8 +355,16 @@ class TwoTowerTrainer:
         self.step_index += 1
         return self.loss
 
-    def apply_gradients(self):
+    def apply_gradients(self, step_ids=None):
+        """``step_ids`` = [user ids, item ids (, category ids)]: the optimizer launch sorts them itself (no plan launch ran)."""
         cfg = self.cfg
+        if step_ids is not None:     # sort + sparse update of every table + dense update: ONE launch, straight from the raw ids
+            tables = [(self.user_table, self.user_accum, self.user_tower.demb, step_ids[0], self.user_plan),
+                      (self.item_table, self.item_accum, self.item_tower.demb, step_ids[1], self.item_plan)]
+            if self.cat_table is not None:
+                tables.append((self.cat_table, self.cat_accum, self.item_tower.demb, step_ids[2], self.cat_plan))
+            ops.optimizer_step_ids_(cfg.optimizer, tables, self._segs, cfg.learning_rate, cfg.adagrad_epsilon)
+            return
         if self.fuse_optimizer:      # sparse update of every table + dense update of every tower segment: one launch
             tables = [(self.user_table, self.user_accum, self.user_tower.demb, self.user_plan),
                       (self.item_table, self.item_accum, self.item_tower.demb, self.item_plan)]
@@ -385,6 +394,14 @@ class TwoTowerTrainer:
         plans, ids, rows = [self.user_plan, self.item_plan], [user_ids, item_ids], [self.cfg.n_users, self.cfg.n_items]
         if loss_kw.get("category_ids") is not None and self.cat_plan is not None:
             plans.append(self.cat_plan); ids.append(loss_kw["category_ids"]); rows.append(self.cfg.n_category_buckets)
+        # fuse_sort: no plan launch at all - the optimizer launch's workgroups sort the ids of their own row range in LDS
+        # and update exactly those rows (tt_optimizer_step_ids_f32; lists up to 16384 ids)
+        fused_sort = (self.fuse_sort and self.fuse_optimizer and user_ids.numel() <= ops.sparse_plan_max_lds_ids()
+                      and (self.cat_table is None) == (len(ids) == 2))
+        if fused_sort:
+            loss = self.forward_backward(user_ids, item_ids, **loss_kw)
+            self.apply_gradients(step_ids=ids)
+            return loss
         if self.plan_on_side_stream:
             self._side.wait_stream(main)
             with torch.cuda.stream(self._side):    # one launch for all tables (csrc/sort.hip)
