@@ -157,12 +157,12 @@ __device__ __forceinline__ void part_local_sort(const PartTable& t, uint32_t* ke
 
 
 // LDS layout of one sorting workgroup (uint32 words from `smem`; part_sort_lds_bytes): keys [cap + 64] | counters
-// [16][RADIX] | per-(load, wave) counts [JMAX][16] | 2 x 16 scan partials | positions u16 [cap]
-__host__ __device__ inline int part_sort_lds_bytes(int cap, int radix) { return (cap + 64 + 16 * radix + 16 * 16 + 32) * 4 + cap * 2; }
+// [16][RADIX] | per-(load, wave) counts [16][16] | 2 x 16 scan partials | 16 counters | positions u16 [cap]
+__host__ __device__ inline int part_sort_lds_bytes(int cap, int radix) { return (cap + 64 + 16 * radix + 16 * 16 + 48) * 4 + cap * 2; }
 __device__ __forceinline__ uint32_t* part_keys(uint32_t* smem) { return smem; }
 template <int DBITS>
 __device__ __forceinline__ uint16_t* part_poss(uint32_t* smem, int cap) {
-  return reinterpret_cast<uint16_t*>(smem + cap + 64 + 16 * (1 << DBITS) + 16 * 16 + 32);
+  return reinterpret_cast<uint16_t*>(smem + cap + 64 + 16 * (1 << DBITS) + 16 * 16 + 48);
 }
 
 // The body of one sorting workgroup (1024 threads), group g of table t.  TO_GLOBAL: the sorted (id, position) pairs go to
@@ -180,7 +180,8 @@ __device__ __forceinline__ uint32_t part_sort_body(const PartTable& t, const int
   uint32_t* cjw = cnt + W * RADIX;                          // [JMAX][W] own-range keys per (load, wave) -> exclusive bases
   uint32_t* wtot = cjw + 16 * W;                            // [16] scan partials (cjw sized for JMAX = 16: one layout)
   uint32_t* wbel = wtot + 16;                               // [16] keys below the range, per wave
-  uint16_t* poss = reinterpret_cast<uint16_t*>(wbel + 16);  // [cap]
+  uint32_t* ctr = wbel + 16;                                // [16] ctr[0] = keys of this range appended so far, ctr[1] = keys below
+  uint16_t* poss = reinterpret_cast<uint16_t*>(ctr + 16);   // [cap]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int n = t.n, J = (n + T - 1) / T;
   SSTAMP(0);
@@ -193,91 +194,113 @@ __device__ __forceinline__ uint32_t part_sort_body(const PartTable& t, const int
     const int64_t id = t.ids[(j < J && i < n) ? i : 0];
     kj[j] = (j < J && i < n) ? ((id >= 0 && id < t.num_rows) ? (uint32_t)id : t.sentinel) : 0xffffffffu;   // past n: no range
   }
-  uint32_t below = 0u;
+  if (tid == 0) { ctr[0] = 0u; ctr[1] = 0u; }
+  __syncthreads();                                          // counters zeroed (the id loads above are still in flight)
+  // ---- group of every id; own-range masks (wave-uniform); the wave appends its own keys to the LDS list at a base drawn
+  // from one LDS counter - in NO particular order across waves: the usual group (<= 512 keys) is ranked by (key, position)
+  // below, which needs no order.  The per-(load, wave) counts are kept for the ordered path of a hot range. ----
+  uint64_t mm[JMAX];
+  uint32_t below = 0u, wave_mine = 0u;
+#pragma unroll
+  for (int j = 0; j < JMAX; ++j) {
+    mm[j] = 0ull;
+    if (j < J) {
+      const uint32_t b = bucket_of(kj[j], t);
+      mm[j] = __builtin_amdgcn_ballot_w64(b == (uint32_t)g);
+      below += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(b < (uint32_t)g));
+      const uint32_t c1 = (uint32_t)__popcll(mm[j]);
+      wave_mine += c1;
+      if (lane == 0) cjw[j * W + w] = c1;
+    }
+  }
+  uint32_t wbase = 0u;
+  if (lane == 0) {
+    wbel[w] = below;
+    wbase = atomicAdd(&ctr[0], wave_mine);
+    atomicAdd(&ctr[1], below);
+  }
+  wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+  base_key = (uint32_t)g * t.width;
 #pragma unroll
   for (int j = 0; j < JMAX; ++j) {
     if (j < J) {
-      const uint32_t b = bucket_of(kj[j], t);
-      const uint64_t mine = __builtin_amdgcn_ballot_w64(b == (uint32_t)g);
-      below += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(b < (uint32_t)g));
-      if (lane == 0) cjw[j * W + w] = (uint32_t)__popcll(mine);
+      if ((mm[j] >> lane) & 1ull) {
+        const uint32_t dst = wbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm[j], 0u));
+        keys[dst] = kj[j] - base_key;
+        poss[dst] = (uint16_t)(j * T + tid);
+      }
+      wbase += (uint32_t)__popcll(mm[j]);
     }
   }
-  if (lane == 0) wbel[w] = below;
   SSTAMP(1);
   __syncthreads();
   SSTAMP(2);
-  // exclusive scan of the (load, wave) counts in position order (j major, wave minor); m = keys of this range
-  uint32_t val = (tid < J * W) ? cjw[tid] : 0u, incl = val;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
-    if (lane >= o) incl += up;
-  }
-  if (lane == 63) wtot[w] = incl;
-  __syncthreads();
-  uint32_t pre = 0u, m = 0u;
-  offset = 0u;
-  for (int ww = 0; ww < W; ++ww) {
-    const uint32_t x = wtot[ww];
-    if (ww < w) pre += x;
-    m += x;
-    offset += wbel[ww];
-  }
-  __syncthreads();                                          // everyone has read cjw / wtot
-  if (tid < J * W) cjw[tid] = pre + incl - val;
-  __syncthreads();
-  SSTAMP(3);
-  // ---- compaction in position order: local key (range base removed) + position ----
-#pragma unroll
-  for (int j = 0; j < JMAX; ++j) {
-    if (j < J) {
-      const bool mine = bucket_of(kj[j], t) == (uint32_t)g;
-      const uint64_t mask = __builtin_amdgcn_ballot_w64(mine);
-      if (mine) {
-        const uint32_t dst = cjw[j * W + w] + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-        keys[dst] = kj[j] - (uint32_t)g * t.width;
-        poss[dst] = (uint16_t)(j * T + tid);
-      }
-    }
-  }
-  if (tid < 64) keys[m + (uint32_t)tid] = 0xffffffffu;          // padding for the 4-wide rank loop (LDS holds cap + 64 keys)
-  __syncthreads();
-  SSTAMP(4);
-  base_key = (uint32_t)g * t.width;
+  const uint32_t m = ctr[0];
+  offset = ctr[1];
   if (m == 0u) return 0u;
   if (m <= 512u) {
-    // ---- the usual case (n / groups ~ 128 keys): rank by counting, no further barrier.  P = 1024 / pow2(m) threads per
-    // element e, each compares a 1/P slice of the keys: rank = #(smaller keys) + #(equal keys at an earlier position);
-    // the compaction left the keys in position order, so "earlier position" is "smaller index": stable. ----
+    // ---- the usual case (n / groups ~ 64-128 keys): rank by counting.  P = 1024 / pow2(m) threads per element e, each
+    // compares a 1/P slice of the list: rank = #(smaller keys) + #(equal keys at a smaller batch position) = the stable
+    // rank, whatever order the list is in. ----
     uint32_t lp = 4;                                        // log2 P: 16 threads per element up to 64 keys ... 2 up to 512
     while ((T >> lp) < m) --lp;
     const uint32_t e = (uint32_t)tid >> lp, sub = (uint32_t)tid & ((1u << lp) - 1u), P = 1u << lp;
-    const uint32_t key = keys[e < m ? e : 0u];
+    const uint32_t ee = e < m ? e : 0u;
+    const uint32_t key = keys[ee], pos = poss[ee];
     uint32_t c = 0u;
-    // 4 keys per LDS read; the slots m .. m+63 were filled with 0xffffffff (larger than any local key) before the barrier
+    // 4 pairs per iteration (one ds_read_b128 + one ds_read_b64); slots past m (inside the LDS arrays) are masked out
     for (uint32_t j = 4u * sub; j < m; j += 4u * P) {
       const uint4 k4 = *reinterpret_cast<const uint4*>(keys + j);
-      c += (k4.x < key || (k4.x == key && j < e)) ? 1u : 0u;
-      c += (k4.y < key || (k4.y == key && j + 1u < e)) ? 1u : 0u;
-      c += (k4.z < key || (k4.z == key && j + 2u < e)) ? 1u : 0u;
-      c += (k4.w < key || (k4.w == key && j + 3u < e)) ? 1u : 0u;
+      const uint2 p2 = *reinterpret_cast<const uint2*>(poss + j);
+      const uint32_t p0 = p2.x & 0xffffu, p1 = p2.x >> 16, pq2 = p2.y & 0xffffu, p3 = p2.y >> 16;
+      c += (k4.x < key || (k4.x == key && p0 < pos)) ? 1u : 0u;
+      c += (j + 1u < m && (k4.y < key || (k4.y == key && p1 < pos))) ? 1u : 0u;
+      c += (j + 2u < m && (k4.z < key || (k4.z == key && pq2 < pos))) ? 1u : 0u;
+      c += (j + 3u < m && (k4.w < key || (k4.w == key && p3 < pos))) ? 1u : 0u;
     }
     for (uint32_t o = 1u; o < P; o <<= 1) c += (uint32_t)__shfl_xor((int)c, (int)o);
     if constexpr (TO_GLOBAL) {
       if (sub == 0u && e < m) {
         t.sorted_ids[offset + c] = (int64_t)(key + base_key);
-        t.order[offset + c] = (int32_t)poss[e];
+        t.order[offset + c] = (int32_t)pos;
       }
     } else {
-      const uint32_t pe = poss[e < m ? e : 0u];
-      __syncthreads();                                      // every thread has read its key / position
-      if (sub == 0u && e < m) { keys[c] = key; poss[c] = (uint16_t)pe; }
+      __syncthreads();                                      // every thread has read the pairs it compares with
+      if (sub == 0u && e < m) { keys[c] = key; poss[c] = (uint16_t)pos; }
       __syncthreads();
     }
     SSTAMP(5);
     return m;
   }
+  // ---- a hot key range (> 512 keys: skewed ids): the list is rebuilt IN POSITION ORDER (exclusive scan of the
+  // per-(load, wave) counts, j major / wave minor) - the LSD radix passes below are stable with respect to it ----
+  __syncthreads();                                          // everyone has read ctr; the unordered list may be overwritten
+  {
+    uint32_t val = (tid < J * W) ? cjw[tid] : 0u, incl = val;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+      if (lane >= o) incl += up;
+    }
+    if (lane == 63) wtot[w] = incl;
+    __syncthreads();
+    uint32_t pre = 0u;
+    for (int ww = 0; ww < w; ++ww) pre += wtot[ww];
+    __syncthreads();                                        // everyone has read cjw / wtot
+    if (tid < J * W) cjw[tid] = pre + incl - val;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+      if (j < J && ((mm[j] >> lane) & 1ull)) {
+        const uint32_t dst = cjw[j * W + w] + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm[j], 0u));
+        keys[dst] = kj[j] - base_key;
+        poss[dst] = (uint16_t)(j * T + tid);
+      }
+    }
+    if (tid < 64) keys[m + (uint32_t)tid] = 0xffffffffu;        // padding slots sort last in every radix pass
+    __syncthreads();
+  }
+  SSTAMP(4);
   // ---- a hot key range: LSD radix sort of the m compacted (local key, position) pairs; register arrays by rounds needed;
   // passes by the bits of this group's largest local key (the last group's is the sentinel's) ----
   const uint32_t local_max = g == t.groups - 1 ? t.sentinel - base_key : t.width - 1u;
