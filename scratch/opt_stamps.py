@@ -22,12 +22,12 @@ torch.cuda.synchronize()
 buf = np.zeros(1024 * 8, dtype=np.uint64)
 assert lib.tt_debug_opt_stamps(buf.ctypes.data, buf.size) == 0
 allw = buf.reshape(1024, 8)[:, :7].astype(np.int64)
-s = allw[:256]
+s = allw[36:256]
 s = s[s[:, 6] > s[:, 0]]
 t0 = s[:, 0].min()
 us = (s - t0) / 100.0
 print(len(s), "sorting WGs; mean stamp times (us):", us.mean(0).round(2).tolist(), "max end", us[:, 6].max(), "start spread", us[:, 0].max())
-d = allw[256:256 + 64]
+d = allw[:36]
 d = d[d[:, 6] > d[:, 0]]
 ud = (d - t0) / 100.0
 print(len(d), "dense blocks: start", ud[:, 0].round(2).tolist()[:40], "end", ud[:, 6].round(2).tolist()[:40])
