@@ -341,6 +341,9 @@ int tt_optimizer_step_ids_f32(int32_t opt, const tt_sparse_table_ids* tables, in
  * Outputs: lse [nq], per_row [nq], loss [1]; dq [nq,dim], dc [nc,dim].
  * Workspace: tt_retrieval_workspace_bytes(nq, nc, dim) bytes, 256-byte aligned.          */
 int64_t tt_retrieval_workspace_bytes(int64_t nq, int64_t nc, int32_t dim);
+/* the part of it the forward-only (tt_retrieval_fwd_f32) and separate-backward (tt_retrieval_bwd_f32) entries need: no
+ * [nq][nc] logit buffer (only the fused training entries keep the raw dot products between their two passes) */
+int64_t tt_retrieval_fwd_workspace_bytes(int64_t nq, int64_t nc, int32_t dim);
 /* What tt_retrieval_rank_f32 alone needs (no gradient slabs: those make the full workspace as large as the candidate
  * corpus once nc >= 65536).                                                                                   */
 int64_t tt_retrieval_rank_workspace_bytes(int64_t nq, int64_t nc, int32_t dim);

@@ -112,6 +112,7 @@ SIGNATURES = {
     "tt_optimizer_step_f32": (C.c_int, [_i32, C.POINTER(SparseTable), _i32, _i32, _i64, C.POINTER(DenseSeg), _i32, _f, _f, _p]),
     "tt_optimizer_step_ids_f32": (C.c_int, [_i32, C.POINTER(SparseTableIds), _i32, _i32, _i64, C.POINTER(DenseSeg), _i32, _f, _f, _p]),
     "tt_retrieval_workspace_bytes": (_i64, [_i64, _i64, _i32]),
+    "tt_retrieval_fwd_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "tt_retrieval_rank_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "tt_retrieval_fwd_f32": (C.c_int, [_p, _p, _i64, _i64, _i32, _i64, _f, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p]),
     "tt_retrieval_fwd_bwd_f32": (C.c_int, [_p, _p, _i64, _i64, _i32, _i64, _f, _p, _p, _p, _p, _f, _p, _i64, _p, _p, _p, _p, _p, _p]),

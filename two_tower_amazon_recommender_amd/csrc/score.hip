@@ -38,7 +38,9 @@ constexpr float kLog2e = 1.44269504088896340736f;
 constexpr float kLn2 = 0.69314718055994530942f;
 constexpr float kNegBig = -1.0e30f;   // log2-domain stand-in for -inf (tfrs uses finfo.min/100)
 
-enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2, MODE_RANK = 3 };
+// MODE_FUSED_S: MODE_FUSED that also writes the raw dot products X[q][c] to ScoreArgs::S; MODE_BWD_S: MODE_BWD that reads
+// them back instead of recomputing GEMM1 (the training entry's pass 2: half the matrix-pipe work)
+enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2, MODE_RANK = 3, MODE_FUSED_S = 4, MODE_BWD_S = 5 };
 #ifndef TT_BX3_ABL
 #define TT_BX3_ABL 0          // timing-only ablation hooks of the bf16x3 kernel (wrong results when non-zero; scratch/abl_bx3.sh)
 #endif
@@ -81,6 +83,8 @@ struct ScoreArgs {
   const float* h_c;         // optional [n_c]: hard-negative threshold per column (same domain as the masked value t)
   const int64_t* pos_idx;   // optional [n_r]: explicit positive column per row (else r + diag)
   int32_t* part_cnt;        // RANK [nsplit][n_r]: columns scoring strictly above the row's threshold a_r
+  float* S;                 // FUSED_S (out) / BWD_S (in): raw dot products, [queries][ldS] row-major (query x candidate)
+  int64_t ldS;              // >= number of candidates
 };
 
 // PREC = 0: exact f32 products (v_mfma_f32_32x32x2_f32).  PREC = 1: "bf16x3" — every f32 operand is split into three
@@ -119,12 +123,18 @@ __device__ __forceinline__ Bf3 split3(float x) {
 // reads (ds_read_b128, GEMM1's A operand) and for the transposing reads (ds_read_b64_tr_b16, GEMM2's A operand = K^T).
 __device__ __forceinline__ int img_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
 
+#ifndef TT_BWDS_WAVES
+#define TT_BWDS_WAVES 2       // min waves per SIMD of the BWD_S pass at D <= 128 (3 = 170 VGPRs)
+#endif
 template <int D, int MODE, bool HAS_IDS, bool HAS_HN, int WAVES, int PREC>
-__global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? 2 : 1))) void score_kernel(ScoreArgs p) {   // (min waves per SIMD)
+__global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? ((MODE == MODE_BWD_S && PREC == 0) ? TT_BWDS_WAVES : 2) : 1))) void score_kernel(ScoreArgs p) {   // (min waves per SIMD)
+  constexpr bool IS_FUSED = MODE == MODE_FUSED || MODE == MODE_FUSED_S;     // online softmax + dq
+  constexpr bool IS_BWD = MODE == MODE_BWD || MODE == MODE_BWD_S;            // gradient pass with given row statistics
+  constexpr bool FROM_S = MODE == MODE_BWD_S, TO_S = MODE == MODE_FUSED_S;
   using G_ = Geo<D, PREC>;
   constexpr int LS = G_::LS, NG = G_::NG, NB = G_::NB, TILE_F = G_::TILE_F, BUF_F = G_::BUF_F;
   constexpr int KS = G_::KS, HALF_B = G_::HALF_B, PIECE_B = G_::PIECE_B;
-  static_assert(PREC == 0 || (D % 128 == 0 && (MODE == MODE_BWD || MODE == MODE_FUSED)),
+  static_assert(PREC == 0 || (D % 128 == 0 && MODE != MODE_FWD && MODE != MODE_RANK),
                 "bf16x3: gradient passes at dim 128 / 256 only");
   constexpr int ROW4 = D / 4;                       // float4 per K row
   constexpr int THREADS = WAVES * 64;
@@ -153,12 +163,14 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? 2 : 1))) 
   // (bf16x3 with 8-wave workgroups: the lo piece — one product per k-step — lives in LDS, [ks][lane] x 16 B per wave,
   // written once: 32 VGPRs less, which is what keeps the gradient kernels free of scratch spills)
   constexpr bool RLO_LDS = PREC == 1 && WAVES == 8;
-  constexpr bool STAG = PREC == 1 && WAVES == 8 && TT_BX3_STAGGER;     // staggered wave halves + 3-buffer LDS ring (see the tile loop)
+  constexpr bool STAG = PREC == 1 && WAVES == 8 && TT_BX3_STAGGER && !FROM_S && !TO_S;     // staggered wave halves + 3-buffer LDS ring (see the tile loop)
   constexpr int NBUF = STAG ? 3 : 2;
   f32x4 rf[PREC == 0 ? NG : 1];
   bf16x8 rp[PREC == 0 ? 1 : (RLO_LDS ? 2 : 3)][PREC == 0 ? 1 : KS];
   bf16x8* rlo = reinterpret_cast<bf16x8*>(smem + NBUF * BUF_F) + (wave * KS) * 64 + lane;
-  if constexpr (PREC == 0) {
+  if constexpr (FROM_S) {
+    // pass 2 of the training entry: the dot products come back from HBM, no stationary fragment, no GEMM1
+  } else if constexpr (PREC == 0) {
     const f32x4* R4 = reinterpret_cast<const f32x4*>(p.R + (r_ok ? r : 0) * D) + h;
 #pragma unroll
     for (int g = 0; g < NG; ++g) rf[g] = r_ok ? R4[2 * g] : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -180,8 +192,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? 2 : 1))) 
       else rp[2][ks] = lo8;
     }
   }
-  const float ar = ((MODE == MODE_BWD || MODE == MODE_RANK) && p.a_r != nullptr && r_ok) ? p.a_r[r] : 0.f;
-  const float sr = (MODE == MODE_BWD && p.s_r != nullptr && r_ok) ? p.s_r[r] : 1.f;
+  const float ar = ((IS_BWD || MODE == MODE_RANK) && p.a_r != nullptr && r_ok) ? p.a_r[r] : 0.f;
+  const float sr = (IS_BWD && p.s_r != nullptr && r_ok) ? p.s_r[r] : 1.f;
   int64_t idr = 0;
   if constexpr (HAS_IDS) idr = r_ok ? p.id_r[r] : (int64_t)-1;
   const int64_t cpos = p.pos_idx != nullptr ? (r_ok ? p.pos_idx[r] : (int64_t)-1) : r + p.diag;   // positive column
@@ -257,12 +269,47 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? 2 : 1))) 
     }
   };
 
+  // ---- the raw dot products through HBM (training entry: pass 1 writes them, pass 2 reads them back) ----
+  // FUSED_S (R = q, K = c): lane = query row r, accumulator register reg = candidate c0 + acc_row(reg, h): registers
+  //   4g .. 4g+3 are 4 consecutive candidates -> one 16-byte store per g into S[r][c] (a wave fills whole 128-byte lines).
+  // BWD_S (R = c, K = q): lane = candidate r, register = query row q0 + acc_row(reg, h): for a fixed register the 32 lanes
+  //   of a half read 32 consecutive candidates of one query row -> coalesced 4-byte loads of S[q][r].
+  auto store_S = [&](int t, const f32x16& X) {
+    if (!r_ok) return;
+    const int64_t c0 = c_begin + 32 * (int64_t)t;
+    float* srow = p.S + r * p.ldS;
+    const bool vec = (p.ldS % 4) == 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int64_t c = c0 + 8 * g + 4 * h;
+      if (vec && c + 3 < c_end) {
+        *reinterpret_cast<f32x4*>(srow + c) = f32x4{X[4 * g], X[4 * g + 1], X[4 * g + 2], X[4 * g + 3]};
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (c + i < c_end) srow[c + i] = X[4 * g + i];
+      }
+    }
+  };
+  // (wave-uniform row pointer + one 32-bit per-lane offset that never changes: no vector address arithmetic per load)
+  const uint32_t s_lane_off = (uint32_t)(4 * h * p.ldS + (r_ok ? r : 0));
+  auto load_S = [&](int t, f32x16& X) {
+    const int64_t q0 = c_begin + 32 * (int64_t)t;
+    const int nq_left = (int)(c_end - q0);            // valid query rows of this tile (may exceed 32)
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const float* rowp = p.S + (q0 + tt::acc_row(reg, 0)) * p.ldS;          // uniform
+      const bool ok = r_ok && (tt::acc_row(reg, 0) + 4 * h) < nq_left;
+      X[reg] = ok ? rowp[s_lane_off] : 0.f;
+    }
+  };
+
   // ---- per-lane state ----
   float run_m = kNegBig, run_l = 0.f, pos = 0.f;
   int cnt = 0;
   bool have_pos = false;
   f32x16 G[NB];
-  if constexpr (MODE == MODE_BWD || MODE == MODE_FUSED) {
+  if constexpr (IS_BWD || IS_FUSED) {
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -338,7 +385,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? 2 : 1))) 
       const f32x4 va = *reinterpret_cast<const f32x4*>(T + TILE_F + 8 * q + 4 * h);
 #pragma unroll
       for (int i = 0; i < 4; ++i) ac[4 * q + i] = va[i];
-      if constexpr (MODE == MODE_BWD) {
+      if constexpr (IS_BWD) {
         const f32x4 vs = *reinterpret_cast<const f32x4*>(T + TILE_F + 32 + 8 * q + 4 * h);
 #pragma unroll
         for (int i = 0; i < 4; ++i) sc[4 * q + i] = vs[i];
@@ -405,7 +452,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? 2 : 1))) 
       run_l = run_l * __builtin_amdgcn_exp2f(run_m - m_new) + sum;
       run_m = m_new;
     } else {
-      if constexpr (MODE == MODE_BWD) {
+      if constexpr (IS_BWD) {
         // the fma and the add as packed f32 pairs (v_pk_fma_f32 / v_pk_add_f32: same roundings, half the VALU
         // issue slots — VALU cycles are not hidden behind f32 MFMAs)
         float tvs[16];
@@ -611,17 +658,24 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? 2 : 1))) 
     }
   } else {
     // ---- every wave runs GEMM1 -> epilogue -> GEMM2 per tile; 2 LDS buffers, one barrier per tile ----
+    f32x16 xs;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) xs[i] = 0.f;
+    if constexpr (FROM_S) { if (ntiles > 0) load_S(0, xs); }
     for (int t = 0; t < ntiles; ++t) {
       // FWD/RANK: prefetch the next tile at the top.  BWD/FUSED: registers are tight (rf + G + X + coef), so the
       // prefetch is issued just before GEMM2, whose 16*NB MFMAs (>= 1.7 us at D=128) cover its latency.
       // bf16x3: a tile is ~1 us of MFMAs, less than a global round trip under load: the prefetch goes to the top too
       if constexpr (MODE == MODE_FWD || MODE == MODE_RANK || PREC == 1) { if (t + 1 < ntiles) load_tile(t + 1); }
       const float* T = smem + (t & 1) * BUF_F;
-      const f32x16 X = gemm1(T);
+      f32x16 X;
+      if constexpr (FROM_S) X = xs; else X = gemm1(T);
+      if constexpr (TO_S) store_S(t, X);
       float coef[16];
       epilogue(T, t, X, coef);
-      if constexpr (MODE == MODE_BWD || MODE == MODE_FUSED) {
+      if constexpr (IS_BWD || IS_FUSED) {
         if constexpr (PREC == 0) { if (t + 1 < ntiles) load_tile(t + 1); }
+        if constexpr (FROM_S) { if (t + 1 < ntiles) load_S(t + 1, xs); }     // next tile's dot products, under GEMM2
         gemm2(T, coef);
       }
       if (t + 1 < ntiles) store_tile((t + 1) & 1);
@@ -630,7 +684,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? 2 : 1))) 
   }
 
   // ---- epilogue ----
-  if constexpr (MODE == MODE_FUSED) {
+  if constexpr (IS_FUSED) {
     const float L = run_l + __shfl_xor(run_l, 32);      // both halves share run_m
     if (r_ok) {
       if (h == 0) {
@@ -966,11 +1020,14 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const f32x4* __restri
 #ifndef TT_SCORE_WGS
 #define TT_SCORE_WGS 512      // workgroups a pass aims for (two 4-wave workgroups per CU)
 #endif
-int choose_nsplit(int64_t n_r, int64_t n_c) {
+#ifndef TT_BWDS_WGS
+#define TT_BWDS_WGS 512       // workgroups the BWD_S pass (dc from the stored dot products) aims for
+#endif
+int choose_nsplit(int64_t n_r, int64_t n_c, int target_wgs = TT_SCORE_WGS) {
   const int64_t nrb = (n_r + 32 * TT_SCORE_WAVES - 1) / (32 * TT_SCORE_WAVES);
   int ns = 1;
   // 512 workgroups = two per CU measured best at B = 8192 (256: 291 us, 512: 272 us, 1024: 283 us, 2048: 294 us per launch)
-  while (nrb * ns < TT_SCORE_WGS && (int64_t)ns * 2 * 64 <= n_c && ns < 64) ns *= 2;
+  while (nrb * ns < target_wgs && (int64_t)ns * 2 * 64 <= n_c && ns < 64) ns *= 2;
   return ns;
 }
 
@@ -978,13 +1035,15 @@ int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
 struct WsLayout {
   int ns_q, ns_c;           // splits for the passes whose stationary side is q / c
-  int64_t off_bias, off_aq, off_sq, off_hq, off_pm, off_pl, off_pos, off_slab, total;
+  int ns_cs;                // ... for the dc pass that reads the stored dot products (BWD_S)
+  int64_t off_bias, off_aq, off_sq, off_hq, off_pm, off_pl, off_pos, off_slab, off_S, total_no_S, total;
 };
 
 WsLayout ws_layout(int64_t nq, int64_t nc, int32_t dim) {
   WsLayout w{};
   w.ns_q = choose_nsplit(nq, nc);
   w.ns_c = choose_nsplit(nc, nq);
+  w.ns_cs = choose_nsplit(nc, nq, TT_BWDS_WGS);
   int64_t o = 0;
   w.off_bias = o; o = align_up(o + nc * 4, 256);
   w.off_aq = o;   o = align_up(o + nq * 4, 256);
@@ -994,8 +1053,13 @@ WsLayout ws_layout(int64_t nq, int64_t nc, int32_t dim) {
   w.off_pl = o;   o = align_up(o + (int64_t)w.ns_q * nq * 4, 256);
   w.off_pos = o;  o = align_up(o + nq * 4, 256);
   w.off_slab = o;
-  const int64_t slab_q = (int64_t)w.ns_q * nq * dim * 4, slab_c = (int64_t)w.ns_c * nc * dim * 4;
+  const int64_t slab_q = (int64_t)w.ns_q * nq * dim * 4, slab_c = (int64_t)(w.ns_c > w.ns_cs ? w.ns_c : w.ns_cs) * nc * dim * 4;
   o = align_up(o + (slab_q > slab_c ? slab_q : slab_c), 256);
+  w.total_no_S = o;
+  // the training entry keeps the raw dot products [nq][nc] between its two passes (pass 2 reads them back instead of
+  // recomputing them: half its matrix-pipe work for 8 bytes of hidden HBM traffic per logit)
+  w.off_S = o;
+  o = align_up(o + nq * nc * 4, 256);
   w.total = o;
   return w;
 }
@@ -1026,9 +1090,11 @@ int launch_score(const ScoreArgs& a_in, bool has_ids, hipStream_t stream) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return tt::fail(TT_ERR_LAUNCH, "hipFuncSetAttribute(LDS %d) failed", lds);
     }
-    tt::ProfScope prof(MODE == MODE_FWD ? "score_fwd" : (MODE == MODE_BWD ? "score_bwd" : (MODE == MODE_FUSED ? "score_fused" : "score_rank")), stream);
+    constexpr const char* tag = MODE == MODE_FWD ? "score_fwd" : ((MODE == MODE_BWD || MODE == MODE_BWD_S) ? "score_bwd"
+                                : ((MODE == MODE_FUSED || MODE == MODE_FUSED_S) ? "score_fused" : "score_rank"));
+    tt::ProfScope prof(tag, stream);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(W * 64), lds, stream, a);
-    return tt::check_launch(MODE == MODE_FWD ? "score_fwd" : (MODE == MODE_BWD ? "score_bwd" : "score_fused"));
+    return tt::check_launch(tag);
   };
   if (has_ids && has_hn) return go(score_kernel<D, MODE, true, true, W, PREC>);
   if (has_ids) return go(score_kernel<D, MODE, true, false, W, PREC>);
@@ -1058,16 +1124,17 @@ int dispatch_score(int32_t dim, const ScoreArgs& a, bool has_ids, hipStream_t st
 }
 
 int check_common(const char* fn, const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
-                 int64_t diag_offset, const void* ws, int64_t ws_bytes) {
+                 int64_t diag_offset, const void* ws, int64_t ws_bytes, bool need_S = false) {
   TT_REQUIRE(q && c && ws, "%s: null pointer", fn);
   TT_REQUIRE(nq > 0 && nc > 0, "%s: nq and nc must be positive", fn);
   TT_REQUIRE(diag_offset >= 0 && nq + diag_offset <= nc, "%s: need 0 <= diag_offset and nq + diag_offset <= nc", fn);
   TT_REQUIRE(dim == 32 || dim == 64 || dim == 128 || dim == 256, "%s: dim %d not in {32,64,128,256}", fn, dim);
   TT_REQUIRE(tt::aligned16(q) && tt::aligned16(c), "%s: q/c must be 16-byte aligned", fn);
   TT_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255u) == 0, "%s: workspace must be 256-byte aligned", fn);
-  if (ws_bytes < ws_layout(nq, nc, dim).total)
-    return tt::fail(TT_ERR_WORKSPACE, "%s: workspace %lld < %lld bytes", fn, (long long)ws_bytes,
-                    (long long)ws_layout(nq, nc, dim).total);
+  const WsLayout wl = ws_layout(nq, nc, dim);
+  const int64_t need = need_S ? wl.total : wl.total_no_S;
+  if (ws_bytes < need)
+    return tt::fail(TT_ERR_WORKSPACE, "%s: workspace %lld < %lld bytes", fn, (long long)ws_bytes, (long long)need);
   return TT_OK;
 }
 
@@ -1076,6 +1143,12 @@ int check_common(const char* fn, const float* q, const float* c, int64_t nq, int
 extern "C" int64_t tt_retrieval_workspace_bytes(int64_t nq, int64_t nc, int32_t dim) {
   if (nq <= 0 || nc <= 0 || dim <= 0) return 0;
   return ws_layout(nq, nc, dim).total;
+}
+
+// the forward-only (validation) and separate-backward entries need no logit buffer: everything in front of it
+extern "C" int64_t tt_retrieval_fwd_workspace_bytes(int64_t nq, int64_t nc, int32_t dim) {
+  if (nq <= 0 || nc <= 0 || dim <= 0) return 0;
+  return ws_layout(nq, nc, dim).total_no_S;
 }
 
 // the rank (metric) pass uses the regions in front of the gradient slabs only: bias, threshold, per-split counts
@@ -1207,7 +1280,7 @@ static int retrieval_fwd_bwd(int prec, const float* q, const float* c, int64_t n
                              const float* cand_prob, const int64_t* cand_ids, const float* hard_thr,
                              float grad_scale, void* workspace, int64_t workspace_bytes, float* lse,
                              float* per_row, float* loss, float* dq, float* dc, tt_stream_t stream_) {
-  int rc = check_common("tt_retrieval_fwd_bwd_f32", q, c, nq, nc, dim, diag_offset, workspace, workspace_bytes);
+  int rc = check_common("tt_retrieval_fwd_bwd_f32", q, c, nq, nc, dim, diag_offset, workspace, workspace_bytes, true);
   if (rc != TT_OK) return rc;
   TT_REQUIRE(lse && per_row && loss && dq && dc, "tt_retrieval_fwd_bwd_f32: null output pointer");
   TT_REQUIRE(tt::aligned16(dq) && tt::aligned16(dc), "tt_retrieval_fwd_bwd_f32: dq/dc must be 16-byte aligned");
@@ -1218,6 +1291,7 @@ static int retrieval_fwd_bwd(int prec, const float* q, const float* c, int64_t n
   float* aq = reinterpret_cast<float*>(ws + w.off_aq);
   float* sq = reinterpret_cast<float*>(ws + w.off_sq);
   float* slab = reinterpret_cast<float*>(ws + w.off_slab);
+  float* smat = reinterpret_cast<float*>(ws + w.off_S);       // [nq][nc] raw dot products, pass 1 -> pass 2
   if (cand_prob != nullptr) {
     hipLaunchKernelGGL(prob_bias_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, stream, cand_prob, bias, nc);
     if ((rc = tt::check_launch("prob_bias")) != TT_OK) return rc;
@@ -1229,6 +1303,7 @@ static int retrieval_fwd_bwd(int prec, const float* q, const float* c, int64_t n
     a.c1 = kLog2e * inv_temperature;
     a.a_c = biasp;
     a.h_r = hard_thr;
+    a.S = smat; a.ldS = nc;
     a.id_r = cand_ids != nullptr ? cand_ids + diag_offset : nullptr;
     a.id_c = cand_ids;
     a.nsplit = w.ns_q;
@@ -1237,8 +1312,10 @@ static int retrieval_fwd_bwd(int prec, const float* q, const float* c, int64_t n
     a.part_l = reinterpret_cast<float*>(ws + w.off_pl);
     a.pos2 = reinterpret_cast<float*>(ws + w.off_pos);
     a.slab = slab;
+    // bf16x3 recomputes GEMM1 in pass 2 (its 6 bf16 products cost less than moving the logits through HBM twice:
+    // measured 200 + 127 us with the buffer against 126 + 126 us without)
     rc = prec == 1 ? dispatch_score_bx3<MODE_FUSED>(dim, a, cand_ids != nullptr, stream)
-                   : dispatch_score<MODE_FUSED>(dim, a, cand_ids != nullptr, stream);
+                   : dispatch_score<MODE_FUSED_S>(dim, a, cand_ids != nullptr, stream);
     if (rc != TT_OK) return rc;
     {
       tt::ProfScope prof("score_aux", stream);
@@ -1264,11 +1341,12 @@ static int retrieval_fwd_bwd(int prec, const float* q, const float* c, int64_t n
     a.h_c = hq;
     a.id_r = cand_ids;
     a.id_c = cand_ids != nullptr ? cand_ids + diag_offset : nullptr;
-    a.nsplit = w.ns_c;
+    a.nsplit = prec == 1 ? w.ns_c : w.ns_cs;
     a.c_per_split = align_up((nq + a.nsplit - 1) / a.nsplit, 32);
     a.slab = slab;
+    a.S = smat; a.ldS = nc;
     rc = prec == 1 ? dispatch_score_bx3<MODE_BWD>(dim, a, cand_ids != nullptr, stream)
-                   : dispatch_score<MODE_BWD>(dim, a, cand_ids != nullptr, stream);
+                   : dispatch_score<MODE_BWD_S>(dim, a, cand_ids != nullptr, stream);
     if (rc != TT_OK) return rc;
     const int64_t n4 = nc * dim / 4;
     const int64_t blocks = (n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048;

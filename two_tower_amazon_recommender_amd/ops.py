@@ -475,7 +475,13 @@ def make_dense_seg(param, accum, grad_slabs, n_slabs: int, l2: float, grad_out=N
 
 # ----------------------------------------------------------------------------- a3+a4 retrieval
 def retrieval_workspace_bytes(nq: int, nc: int, dim: int) -> int:
+    """Workspace of the fused training entries (retrieval_fwd_bwd): includes the [nq, nc] f32 logit buffer pass 2 reads back."""
     return int(_lib.load().tt_retrieval_workspace_bytes(nq, nc, dim))
+
+
+def retrieval_fwd_workspace_bytes(nq: int, nc: int, dim: int) -> int:
+    """Workspace of the forward-only / separate-backward entries (no logit buffer)."""
+    return int(_lib.load().tt_retrieval_fwd_workspace_bytes(nq, nc, dim))
 
 
 def _chk_retrieval(q, c, sample_weight=None, cand_prob=None, cand_ids=None, hard_thr=None, lse=None, per_row=None,
