@@ -270,12 +270,15 @@ def main():
     sd = tower_dims[-1]
     b2d = float(batch) * batch * sd
     # The scorer+loss runs as two launches of one kernel template per step:
-    #   score_kernel<D,FUSED>: loss + dq  — algorithmic 4*B^2*D (fwd 2 + dq 2), executed 4*B^2*D
-    #   score_kernel<D,BWD>  : dc         — algorithmic 2*B^2*D (GEMM1 recompute not counted), executed 4*B^2*D
+    #   score_kernel<D,FUSED_S>: loss + dq — algorithmic 4*B^2*D (fwd 2 + dq 2), executed 4*B^2*D; also writes the raw
+    #                                        dot products [B][B] f32 to the workspace (4*B^2 bytes)
+    #   score_kernel<D,BWD_S>  : dc        — algorithmic = executed 2*B^2*D: reads the dot products back (4*B^2 bytes)
+    #                                        instead of recomputing them (r02: was 4*B^2*D executed)
     t_fused = mean(prof["score_fused"]) * 1e-3
     t_bwd = mean(prof["score_bwd"]) * 1e-3
 
-    def roof(name, alg_flops, t):
+    def roof(name, alg_flops, t, exec_flops=None):
+        exec_flops = alg_flops if exec_flops is None else exec_flops
         if t <= 0:
             return {"bound": "mfma", "kernel": name, "achieved": None, "note": "no hipEvent samples (graph replay)"}
         a = alg_flops / t / 1e12
@@ -283,10 +286,12 @@ def main():
                 "frac": a / MFMA_F32_PEAK_TFLOPS, "traffic": None,
                 "traffic_source": f"{PMC_FILE} (committed rocprofv3 --pmc passes of round r02; not re-measured in this run)",
                 "avg_launch_us": t * 1e6, "dtype": "f32-input MFMA",
-                "executed_tflops": 4.0 * b2d / t / 1e12, "executed_frac": 4.0 * b2d / t / 1e12 / MFMA_F32_PEAK_TFLOPS}
+                "executed_tflops": exec_flops / t / 1e12, "executed_frac": exec_flops / t / 1e12 / MFMA_F32_PEAK_TFLOPS}
 
-    r_fused = roof(f"score_kernel<{sd},FUSED> (loss + dq pass; 1 launch/step; algorithmic 4*B^2*D)", 4.0 * b2d, t_fused)
-    r_bwd = roof(f"score_kernel<{sd},BWD> (dc pass; 1 launch/step; algorithmic 2*B^2*D)", 2.0 * b2d, t_bwd)
+    r_fused = roof(f"score_kernel<{sd},FUSED_S> (loss + dq pass, keeps the [B][B] dot products for the dc pass; 1 launch/step; "
+                   f"algorithmic = executed 4*B^2*D)", 4.0 * b2d, t_fused)
+    r_bwd = roof(f"score_kernel<{sd},BWD_S> (dc pass from the stored dot products; 1 launch/step; algorithmic = executed "
+                 f"2*B^2*D, + 4*B^2 bytes of HBM reads)", 2.0 * b2d, t_bwd)
     if args.config == "cfg3" and args.optimizer == "sgd":          # the configuration the PMC passes were collected on
         r_fused["traffic"], r_bwd["traffic"] = pmc_traffic("score_fused"), pmc_traffic("score_bwd")
     dominant, other = (r_fused, r_bwd) if t_fused >= t_bwd else (r_bwd, r_fused)

@@ -274,6 +274,9 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? ((MODE ==
   //   4g .. 4g+3 are 4 consecutive candidates -> one 16-byte store per g into S[r][c] (a wave fills whole 128-byte lines).
   // BWD_S (R = c, K = q): lane = candidate r, register = query row q0 + acc_row(reg, h): for a fixed register the 32 lanes
   //   of a half read 32 consecutive candidates of one query row -> coalesced 4-byte loads of S[q][r].
+  // Measured alternatives (r02, cfg3, pass 1 / pass 2 us; this form 287 / 174): the transposed layout S^T[c][q] (full-line
+  // 4-byte stores in pass 1, 16-byte strided loads in pass 2) 290 / 170 - a wash; nontemporal stores 387 / 175 (the 32-byte
+  // pieces of a line are no longer merged in L2); nontemporal loads 287 / 175.
   auto store_S = [&](int t, const f32x16& X) {
     if (!r_ok) return;
     const int64_t c0 = c_begin + 32 * (int64_t)t;
