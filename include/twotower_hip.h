@@ -326,7 +326,8 @@ int tt_optimizer_step_ids_f32(int32_t opt, const tt_sparse_table_ids* tables, in
  * a3 + a4 — batched dot-product scorer fused with the in-batch sampled-softmax loss
  * (tfrs.tasks.Retrieval.call: matmul(q, c^T) / temperature, optional sampling-probability
  * correction and accidental-hit removal, CategoricalCrossentropy(from_logits=True,
- * reduction=SUM); configs/data_config.yaml:69-70).  The [nq,nc] logits never reach HBM.
+ * reduction=SUM); configs/data_config.yaml:69-70).  Softmax probabilities never reach HBM (see tt_retrieval_fwd_bwd_f32 for the
+ * raw dot products the exact-f32 training entry keeps between its passes).
  *
  *   s_ij   = <q_i, c_j> * inv_temperature  - log(clip(cand_prob_j, 1e-6, 1))
  *            (+ -inf where cand_ids_j == cand_ids_{i+diag_offset} and j != i+diag_offset)
@@ -363,7 +364,7 @@ int tt_retrieval_bwd_f32(const float* q, const float* c, int64_t nq, int64_t nc,
 /* tfrs.tasks.Retrieval(num_hard_negatives=k) / tfrs.layers.loss.HardNegativeMining: thr[i] separates the k
  * highest-scoring negatives of query i (after temperature, sampling-probability correction and accidental-hit
  * removal) from the rest (midpoint between the k-th and the next lower logit; ties at the k-th value are all kept;
- * fewer than k negatives: everything is kept).  scratch: nq*nc floats — the one place logits are materialised.    */
+ * fewer than k negatives: everything is kept).  scratch: nq*nc floats (a logit row block, materialised).             */
 int tt_retrieval_hard_negative_thresholds_f32(const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
                                               int64_t diag_offset, float inv_temperature,
                                               const float* cand_prob, const int64_t* cand_ids,
@@ -374,7 +375,11 @@ int tt_retrieval_hard_negative_thresholds_f32(const float* q, const float* c, in
 
 /* Fused training form: loss AND both gradients in two passes over the logits instead of three
  * (pass 1: online softmax with the candidate-weighted sum -> lse, per_row, loss, dq;  pass 2: dc).
- * Same semantics and outputs as tt_retrieval_fwd_f32 followed by tt_retrieval_bwd_f32.          */
+ * Same semantics and outputs as tt_retrieval_fwd_f32 followed by tt_retrieval_bwd_f32.
+ * The exact-f32 entry keeps the raw dot products [nq][nc] (f32) in the workspace between the passes — pass 2 reads them
+ * back instead of recomputing them (half its matrix-pipe work; 6*nq*nc*dim executed FLOPs in total instead of 8) —
+ * which is why tt_retrieval_workspace_bytes includes 4*nq*nc bytes; tt_retrieval_fwd_workspace_bytes is enough for the
+ * forward-only and separate-backward entries.                                                                        */
 int tt_retrieval_fwd_bwd_f32(const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
                              int64_t diag_offset, float inv_temperature,
                              const float* sample_weight, const float* cand_prob, const int64_t* cand_ids,

@@ -1,6 +1,7 @@
 // K4 / K5 — batched dot-product scorer fused with the in-batch sampled-softmax loss and its
 // gradient (SURVEY.md §2.2 K4/K5, §8a a3+a4; tfrs.tasks.Retrieval semantics, Appendix A).
-// The [nq, nc] logit matrix never reaches HBM.
+// Probabilities / coefficients never reach HBM.  The exact-f32 TRAINING entry keeps the raw dot products [nq][nc] in the
+// workspace between its two passes (MODE_FUSED_S writes, MODE_BWD_S reads: pass 2 skips GEMM1); every other entry keeps nothing.
 //
 // One kernel serves the forward statistics pass and both gradient passes.  It sees a STATIONARY
 // matrix R [n_r, D] (one 32-row fragment per wave, held in registers for the whole launch) and a

@@ -2,10 +2,11 @@
 ``tfrs.tasks.Retrieval`` (tensorflow-recommenders 0.7.x; the reference declares the dependency at
 ``/root/reference/pyproject.toml:24`` and the settings at ``configs/data_config.yaml:68-71`` but never
 calls it).  The scorer, the in-batch sampled-softmax loss and its gradient run in ONE family of fused
-HIP kernels (csrc/score.hip): the [num_queries, num_candidates] logits never reach HBM.
+HIP kernels (csrc/score.hip); softmax probabilities are never stored (the exact-f32 training entry keeps the raw
+[num_queries, num_candidates] dot products in its workspace between its two passes; the forward-only form keeps nothing).
 
 The task dispatches through the registered custom ops ``torch.ops.twotower.retrieval_loss`` (training: loss and
-both gradients in the fused two-pass form, 8*Bq*Bc*D executed FLOPs, gradients saved for autograd) and
+both gradients in the fused two-pass form, 6*Bq*Bc*D executed FLOPs, gradients saved for autograd) and
 ``torch.ops.twotower.retrieval_loss_value`` (no gradient needed: one statistics pass) — ``torch_ops.py``.
 
 Differences from TFRS, all loud:
@@ -37,7 +38,7 @@ class Retrieval:
                                       "from logits, SUM reduction) is implemented in the HIP path")
         if batch_metrics is not None:
             raise NotImplementedError("Retrieval(batch_metrics=...): metrics over the in-batch score matrix need the "
-                                      "[queries x candidates] logits, which the fused kernels never materialise")
+                                      "[queries x candidates] score matrix, which the fused kernels do not hand out")
         if metrics is not None:
             from .metrics import FactorizedTopK
             if not isinstance(metrics, FactorizedTopK) or metrics.candidates is None:

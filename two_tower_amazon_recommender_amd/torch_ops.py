@@ -49,7 +49,8 @@ def retrieval_loss(query_embeddings: Tensor, candidate_embeddings: Tensor, sampl
                    inv_temperature: float, diag_offset: int, num_hard_negatives: int,
                    precision: str = "f32") -> Tuple[Tensor, Tensor, Tensor, Tensor]:
     """In-batch sampled-softmax loss (SUM) of tfrs.tasks.Retrieval AND its gradients, in the fused two-pass form
-    (8*Bq*Bc*D executed FLOPs; the logits never reach HBM).  Returns (loss [], per-example loss [Bq], dLoss/dq, dLoss/dc);
+    (exact f32: 6*Bq*Bc*D executed FLOPs - pass 2 reads the raw dot products of pass 1 back from the workspace;
+    bf16x3: both passes compute them).  Returns (loss [], per-example loss [Bq], dLoss/dq, dLoss/dc);
     the autograd formula multiplies the saved gradients by the incoming scalar gradient.  ``candidate_ids`` given =
     accidental-hit removal; ``num_hard_negatives`` > 0 keeps the positive and the k hardest negatives per query;
     ``precision`` "f32" (exact f32 products) or "bf16x3" (f32-emulated split-bf16 products, dim 128 / 256)."""

@@ -344,7 +344,7 @@ class TwoTowerTrainer:
             q = ut.forward((cfg.dropout_rate, self.dropout_seed, 0, row0), lookup=lks[0])
             c = it.forward((cfg.dropout_rate, self.dropout_seed, 1, row0), lookup=lks[1])
         kw = dict(sample_weight=sample_weight, cand_prob=candidate_sampling_probability, cand_ids=candidate_ids)
-        # loss + dq + dc in two fused passes over the logits (never materialised)
+        # loss + dq + dc in two fused passes over the logits (probabilities never stored; f32: raw dot products kept in self.ws)
         ops.retrieval_fwd_bwd(q, c, 1.0 / cfg.temperature, self.ws, self.lse, self.per_row, self.loss,
                               ut.dz[-1], it.dz[-1], precision=cfg.scorer_precision, **kw)
         if cfg.symmetric:
