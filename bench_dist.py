@@ -183,7 +183,7 @@ def run_distributed(args, rank, world, dev):
             t = sum(fused) / len(fused) * 1e-3
             flops = 4.0 * batch * nc * sd                  # pass 1 on this GPU's slab: logits + dq (algorithmic = executed)
             a = flops / t / 1e12
-            roofline = {"bound": "mfma", "kernel": f"score_kernel<{sd},FUSED> on rank 0's slab [{batch} queries x {nc} candidates] "
+            roofline = {"bound": "mfma", "kernel": f"score_kernel<{sd},FUSED_S> on rank 0's slab [{batch} queries x {nc} candidates] "
                                                    "(loss + dq pass; algorithmic 4*Bq*Bc*D per launch)",
                         "achieved": a, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": a / MFMA_F32_PEAK_TFLOPS,
                         "traffic": None, "avg_launch_us": t * 1e6, "samples": len(fused), "dtype": "f32-input MFMA"}

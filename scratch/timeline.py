@@ -9,8 +9,9 @@ names = [r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::"
 g = [i for i, n in enumerate(names) if n.startswith("gemm_kernel<true, false, false, 1")]   # layer-0 forward (fused lookup) opens a step
 steps = [(g[k], g[k + 1]) for k in range(len(g) - 1)]
 # the timed region's steps only: the usual kernel count, exact-f32 scorer, fused optimizer launch
-steps = [(a, b) for a, b in steps if b - a <= 12 and any("score_kernel<128, 2, false, false, 4, 0>" in names[j] for j in range(a, b))
-         and any(names[j].startswith("optimizer_kernel") for j in range(a, b))]
+steps = [(a, b) for a, b in steps if b - a <= 12 and any("score_kernel<128, 4, false, false, 4, 0>" in names[j] or
+                                                          "score_kernel<128, 2, false, false, 4, 0>" in names[j] for j in range(a, b))
+         and any(names[j].startswith("optimizer_") for j in range(a, b))]
 mode = collections.Counter(b - a for a, b in steps).most_common(1)[0][0]
 steps = [(a, b) for a, b in steps if b - a == mode][-150:]
 agg, gaps, wall = collections.OrderedDict(), collections.OrderedDict(), 0
