@@ -127,6 +127,15 @@ __device__ __forceinline__ int img_off(int row, int ch) { return 256 * row + 16 
 #ifndef TT_BWDS_WAVES
 #define TT_BWDS_WAVES 2       // min waves per SIMD of the BWD_S pass at D <= 128 (3 = 170 VGPRs)
 #endif
+#ifndef TT_TILES_PER_BARRIER
+#define TT_TILES_PER_BARRIER 2
+#endif
+template <int D, int MODE, int PREC>
+constexpr int tiles_per_barrier() {
+  return (PREC == 0 && D <= 128 && (MODE == MODE_BWD || MODE == MODE_FUSED || MODE == MODE_FUSED_S || MODE == MODE_BWD_S))
+             ? TT_TILES_PER_BARRIER : 1;
+}
+
 template <int D, int MODE, bool HAS_IDS, bool HAS_HN, int WAVES, int PREC>
 __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? ((MODE == MODE_BWD_S && PREC == 0) ? TT_BWDS_WAVES : 2) : 1))) void score_kernel(ScoreArgs p) {   // (min waves per SIMD)
   constexpr bool IS_FUSED = MODE == MODE_FUSED || MODE == MODE_FUSED_S;     // online softmax + dq
@@ -165,7 +174,10 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? ((MODE ==
   // written once: 32 VGPRs less, which is what keeps the gradient kernels free of scratch spills)
   constexpr bool RLO_LDS = PREC == 1 && WAVES == 8;
   constexpr bool STAG = PREC == 1 && WAVES == 8 && TT_BX3_STAGGER && !FROM_S && !TO_S;     // staggered wave halves + 3-buffer LDS ring (see the tile loop)
-  constexpr int NBUF = STAG ? 3 : 2;
+  // exact-f32 gradient passes: TPB tiles between workgroup barriers (ring of 2*TPB LDS buffers, the prefetch runs TPB tiles
+  // ahead); everything else: one tile per barrier, two buffers
+  constexpr int TPB = tiles_per_barrier<D, MODE, PREC>();
+  constexpr int NBUF = STAG ? 3 : 2 * TPB;
   f32x4 rf[PREC == 0 ? NG : 1];
   bf16x8 rp[PREC == 0 ? 1 : (RLO_LDS ? 2 : 3)][PREC == 0 ? 1 : KS];
   bf16x8* rlo = reinterpret_cast<bf16x8*>(smem + NBUF * BUF_F) + (wave * KS) * 64 + lane;
@@ -320,10 +332,16 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? ((MODE ==
       for (int i = 0; i < 16; ++i) G[b][i] = 0.f;
   }
 
-  if (ntiles > 0) {
-    load_tile(0);
-    store_tile(0);
-  }
+  // (r02: starting the second workgroup of every CU 1-4 us late, so that the two waves of a SIMD run half a tile apart, only
+  // added the delay: 174.9 -> 175.5 .. 177.7 us for the dc pass.  Ablation of that pass: GEMM2 alone 112 us = the matrix pipe's
+  // time; everything else - tile staging 25, dot-product loads 6-19, epilogue 9, loop skeleton 23 - adds to it instead of
+  // hiding under it, with or without a phase shift between the waves.)
+#pragma unroll
+  for (int t0 = 0; t0 < TPB; ++t0)
+    if (t0 < ntiles) {
+      load_tile(t0);
+      store_tile(t0);
+    }
   __syncthreads();
   // ---- GEMM1: X[c][r] = sum_d K[c][d] R[r][d] ----
   auto gemm1 = [&](const float* T) -> f32x16 {
@@ -671,19 +689,19 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? ((MODE ==
       // prefetch is issued just before GEMM2, whose 16*NB MFMAs (>= 1.7 us at D=128) cover its latency.
       // bf16x3: a tile is ~1 us of MFMAs, less than a global round trip under load: the prefetch goes to the top too
       if constexpr (MODE == MODE_FWD || MODE == MODE_RANK || PREC == 1) { if (t + 1 < ntiles) load_tile(t + 1); }
-      const float* T = smem + (t & 1) * BUF_F;
+      const float* T = smem + (t % NBUF) * BUF_F;
       f32x16 X;
       if constexpr (FROM_S) X = xs; else X = gemm1(T);
       if constexpr (TO_S) store_S(t, X);
       float coef[16];
       epilogue(T, t, X, coef);
       if constexpr (IS_BWD || IS_FUSED) {
-        if constexpr (PREC == 0) { if (t + 1 < ntiles) load_tile(t + 1); }
+        if constexpr (PREC == 0) { if (t + TPB < ntiles) load_tile(t + TPB); }
         if constexpr (FROM_S) { if (t + 1 < ntiles) load_S(t + 1, xs); }     // next tile's dot products, under GEMM2
         gemm2(T, coef);
       }
-      if (t + 1 < ntiles) store_tile((t + 1) & 1);
-      __syncthreads();
+      if (t + TPB < ntiles) store_tile((t + TPB) % NBUF);
+      if ((t % TPB) == TPB - 1) __syncthreads();       // (uniform) tiles of the next group are complete, this group's buffers free
     }
   }
 
@@ -1085,7 +1103,7 @@ int launch_score(const ScoreArgs& a_in, bool has_ids, hipStream_t stream) {
   const int64_t nrb = (a_in.n_r + W * 32 - 1) / (W * 32);
   const int64_t blocks = nrb * a_in.nsplit;
   // bf16x3 with 8 waves: a third tile buffer (staggered wave halves) + the R_lo fragments of the 8 waves
-  const int lds = Geo<D, PREC>::LDS_BYTES +
+  const int lds = Geo<D, PREC>::LDS_BYTES * tiles_per_barrier<D, MODE, PREC>() +
                   ((PREC == 1 && W == 8) ? (TT_BX3_STAGGER ? Geo<D, PREC>::BUF_F * 4 : 0) + W * Geo<D, PREC>::KS * 64 * 16 : 0);
   const bool has_hn = (a_in.h_r != nullptr) || (a_in.h_c != nullptr);
   const ScoreArgs& a = a_in;
