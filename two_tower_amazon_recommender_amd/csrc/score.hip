@@ -84,8 +84,8 @@ struct ScoreArgs {
   const float* h_c;         // optional [n_c]: hard-negative threshold per column (same domain as the masked value t)
   const int64_t* pos_idx;   // optional [n_r]: explicit positive column per row (else r + diag)
   int32_t* part_cnt;        // RANK [nsplit][n_r]: columns scoring strictly above the row's threshold a_r
-  float* S;                 // FUSED_S (out) / BWD_S (in): raw dot products, [queries][ldS] row-major (query x candidate)
-  int64_t ldS;              // >= number of candidates
+  float* S;                 // FUSED_S (out) / BWD_S (in): raw dot products in 32 x 32 blocks (see store_S)
+  int64_t ldS;              // number of query tiles = ceil(nq / 32)
 };
 
 // PREC = 0: exact f32 products (v_mfma_f32_32x32x2_f32).  PREC = 1: "bf16x3" — every f32 operand is split into three
@@ -283,40 +283,31 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? ((MODE ==
   };
 
   // ---- the raw dot products through HBM (training entry: pass 1 writes them, pass 2 reads them back) ----
-  // FUSED_S (R = q, K = c): lane = query row r, accumulator register reg = candidate c0 + acc_row(reg, h): registers
-  //   4g .. 4g+3 are 4 consecutive candidates -> one 16-byte store per g into S[r][c] (a wave fills whole 128-byte lines).
-  // BWD_S (R = c, K = q): lane = candidate r, register = query row q0 + acc_row(reg, h): for a fixed register the 32 lanes
-  //   of a half read 32 consecutive candidates of one query row -> coalesced 4-byte loads of S[q][r].
-  // Measured alternatives (r02, cfg3, pass 1 / pass 2 us; this form 287 / 174): the transposed layout S^T[c][q] (full-line
-  // 4-byte stores in pass 1, 16-byte strided loads in pass 2) 290 / 170 - a wash; nontemporal stores 387 / 175 (the 32-byte
-  // pieces of a line are no longer merged in L2); nontemporal loads 287 / 175.
+  // Stored as 32 x 32 BLOCKS of 4 KB, block (candidate tile, query tile) at [ctile * ldS + qtile] (ldS = query tiles), inside a
+  // block [query][candidate]: the block one wave produces in pass 1 is the block one wave consumes in pass 2, and both
+  // move it as one contiguous 4 KB burst (row-major [nq][nc] made every 128-byte line of a tile a separate DRAM page).
+  // FUSED_S (R = q, K = c): lane = query row, accumulator register reg = candidate acc_row(reg, h): registers 4g .. 4g+3
+  //   are 4 consecutive candidates -> one 16-byte store per g.
+  // BWD_S (R = c, K = q): lane = candidate, register = query row: for a fixed register the 32 lanes of a half read 32
+  //   consecutive candidates of one query row -> coalesced 4-byte loads.
+  // (r02 alternatives, cfg3, pass 1 / pass 2 us against 287 / 174 for row-major: transposed row-major 290 / 170;
+  // nontemporal stores 387 / 175 - the pieces of a line are no longer merged in L2; nontemporal loads 287 / 175.)
   auto store_S = [&](int t, const f32x16& X) {
     if (!r_ok) return;
-    const int64_t c0 = c_begin + 32 * (int64_t)t;
-    float* srow = p.S + r * p.ldS;
-    const bool vec = (p.ldS % 4) == 0;
+    const int64_t ctile = (c_begin >> 5) + t;
+    float* blk = p.S + (ctile * p.ldS + (r0w >> 5)) * 1024 + ln * 32 + 4 * h;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int64_t c = c0 + 8 * g + 4 * h;
-      if (vec && c + 3 < c_end) {
-        *reinterpret_cast<f32x4*>(srow + c) = f32x4{X[4 * g], X[4 * g + 1], X[4 * g + 2], X[4 * g + 3]};
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (c + i < c_end) srow[c + i] = X[4 * g + i];
-      }
-    }
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<f32x4*>(blk + 8 * g) = f32x4{X[4 * g], X[4 * g + 1], X[4 * g + 2], X[4 * g + 3]};
   };
-  // (wave-uniform row pointer + one 32-bit per-lane offset that never changes: no vector address arithmetic per load)
-  const uint32_t s_lane_off = (uint32_t)(4 * h * p.ldS + (r_ok ? r : 0));
   auto load_S = [&](int t, f32x16& X) {
     const int64_t q0 = c_begin + 32 * (int64_t)t;
     const int nq_left = (int)(c_end - q0);            // valid query rows of this tile (may exceed 32)
+    const float* blk = p.S + ((r0w >> 5) * p.ldS + (q0 >> 5)) * 1024 + 4 * h * 32 + ln;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
-      const float* rowp = p.S + (q0 + tt::acc_row(reg, 0)) * p.ldS;          // uniform
       const bool ok = r_ok && (tt::acc_row(reg, 0) + 4 * h) < nq_left;
-      X[reg] = ok ? rowp[s_lane_off] : 0.f;
+      X[reg] = ok ? blk[tt::acc_row(reg, 0) * 32] : 0.f;
     }
   };
 
@@ -1081,7 +1072,7 @@ WsLayout ws_layout(int64_t nq, int64_t nc, int32_t dim) {
   // the training entry keeps the raw dot products [nq][nc] between its two passes (pass 2 reads them back instead of
   // recomputing them: half its matrix-pipe work for 8 bytes of hidden HBM traffic per logit)
   w.off_S = o;
-  o = align_up(o + nq * nc * 4, 256);
+  o = align_up(o + ((nq + 31) / 32) * ((nc + 31) / 32) * 4096, 256);
   w.total = o;
   return w;
 }
@@ -1325,7 +1316,7 @@ static int retrieval_fwd_bwd(int prec, const float* q, const float* c, int64_t n
     a.c1 = kLog2e * inv_temperature;
     a.a_c = biasp;
     a.h_r = hard_thr;
-    a.S = smat; a.ldS = nc;
+    a.S = smat; a.ldS = (nq + 31) / 32;
     a.id_r = cand_ids != nullptr ? cand_ids + diag_offset : nullptr;
     a.id_c = cand_ids;
     a.nsplit = w.ns_q;
@@ -1366,7 +1357,7 @@ static int retrieval_fwd_bwd(int prec, const float* q, const float* c, int64_t n
     a.nsplit = prec == 1 ? w.ns_c : w.ns_cs;
     a.c_per_split = align_up((nq + a.nsplit - 1) / a.nsplit, 32);
     a.slab = slab;
-    a.S = smat; a.ldS = nc;
+    a.S = smat; a.ldS = (nq + 31) / 32;
     rc = prec == 1 ? dispatch_score_bx3<MODE_BWD>(dim, a, cand_ids != nullptr, stream)
                    : dispatch_score<MODE_BWD_S>(dim, a, cand_ids != nullptr, stream);
     if (rc != TT_OK) return rc;
