@@ -25,6 +25,7 @@
 // XCD's L2 keeps re-serving the same K range); partial results go to per-split slabs that a small
 // kernel sums in split order (bitwise reproducible; no float atomics).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -1325,9 +1326,9 @@ static int retrieval_fwd_bwd(int prec, const float* q, const float* c, int64_t n
     a.part_l = reinterpret_cast<float*>(ws + w.off_pl);
     a.pos2 = reinterpret_cast<float*>(ws + w.off_pos);
     a.slab = slab;
-    // bf16x3 recomputes GEMM1 in pass 2 (its 6 bf16 products cost less than moving the logits through HBM twice:
-    // measured 200 + 127 us with the buffer against 126 + 126 us without)
-    rc = prec == 1 ? dispatch_score_bx3<MODE_FUSED>(dim, a, cand_ids != nullptr, stream)
+    // (bf16x3 too keeps the dot products: 134 + 96 us against 123 + 124 us recomputing - with the row-major buffer it had
+    // been 200 + 127 us, the blocked layout is what makes it pay)
+    rc = prec == 1 ? dispatch_score_bx3<MODE_FUSED_S>(dim, a, cand_ids != nullptr, stream)
                    : dispatch_score<MODE_FUSED_S>(dim, a, cand_ids != nullptr, stream);
     if (rc != TT_OK) return rc;
     {
@@ -1354,11 +1355,11 @@ static int retrieval_fwd_bwd(int prec, const float* q, const float* c, int64_t n
     a.h_c = hq;
     a.id_r = cand_ids;
     a.id_c = cand_ids != nullptr ? cand_ids + diag_offset : nullptr;
-    a.nsplit = prec == 1 ? w.ns_c : w.ns_cs;
+    a.nsplit = w.ns_cs;
     a.c_per_split = align_up((nq + a.nsplit - 1) / a.nsplit, 32);
     a.slab = slab;
     a.S = smat; a.ldS = (nq + 31) / 32;
-    rc = prec == 1 ? dispatch_score_bx3<MODE_BWD>(dim, a, cand_ids != nullptr, stream)
+    rc = prec == 1 ? dispatch_score_bx3<MODE_BWD_S>(dim, a, cand_ids != nullptr, stream)
                    : dispatch_score<MODE_BWD_S>(dim, a, cand_ids != nullptr, stream);
     if (rc != TT_OK) return rc;
     const int64_t n4 = nc * dim / 4;
