@@ -699,6 +699,10 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? ((MODE ==
     }
   } else {
     // ---- every wave runs GEMM1 -> epilogue -> GEMM2 per tile; 2 LDS buffers, one barrier per tile ----
+    // (Keep this loop as a plain loop.  Wrapping its body in a lambda called from an unrolled k-loop - the form the BWD_S
+    // branch above uses - compiled, for score_kernel<256, FWD>, to a loop whose exit test is a vector compare and whose
+    // results were wrong in about half the rows, differently from run to run (r02; same instructions otherwise; an
+    // extra barrier per iteration did not help).  tests: test_retrieval_baseline_configs[1024-256] catches it.)
     f32x16 xs;
 #pragma unroll
     for (int i = 0; i < 16; ++i) xs[i] = 0.f;
