@@ -7,10 +7,10 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(base + "/*/pmc_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         agg[r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
-KEYS = {"score_fused": "score_kernel<128, 2, false, false, 4, 0>", "score_bwd": "score_kernel<128, 1, false, false, 4, 0>",
-        "score_fused_bf16x3": "score_kernel<128, 2, false, false, 8, 1>", "score_bwd_bf16x3": "score_kernel<128, 1, false, false, 8, 1>",
+KEYS = {"score_fused": "score_kernel<128, 4, false, false, 4, 0>", "score_bwd": "score_kernel<128, 5, false, false, 4, 0>",
+        "score_fused_bf16x3": "score_kernel<128, 4, false, false, 8, 1>", "score_bwd_bf16x3": "score_kernel<128, 5, false, false, 8, 1>",
         "gather": "gather_kernel<4", "sparse_apply": "sparse_apply_kernel<0>", "sparse_plan": "part_sort_kernel<",
-        "optimizer": "optimizer_kernel<0>",
+        "optimizer": "optimizer_ids_kernel<0",
         "dense_fwd_lookup": "gemm_kernel<true, false, false, 1", "dense_fwd": "gemm_kernel<true, false, false, 0",
         "dense_bwd_lookup": "gemm_bwd_kernel<256>", "dense_bwd": "gemm_bwd_kernel<0>",
         "fused_combine": "fused_combine_kernel", "reduce_slabs": "reduce_slabs_kernel", "dense_update": "dense_update_kernel<0>"}

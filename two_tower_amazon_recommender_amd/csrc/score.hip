@@ -1357,9 +1357,12 @@ static int retrieval_fwd_bwd(int prec, const float* q, const float* c, int64_t n
     a.part_l = reinterpret_cast<float*>(ws + w.off_pl);
     a.pos2 = reinterpret_cast<float*>(ws + w.off_pos);
     a.slab = slab;
-    // (bf16x3 too keeps the dot products: 134 + 96 us against 123 + 124 us recomputing - with the row-major buffer it had
-    // been 200 + 127 us, the blocked layout is what makes it pay)
-    rc = prec == 1 ? dispatch_score_bx3<MODE_FUSED_S>(dim, a, cand_ids != nullptr, stream)
+    // (bf16x3 at dim 128 too keeps the dot products: 134 + 89 us against 123 + 124 us recomputing - with the row-major buffer
+    // it had been 200 + 127 us, the blocked layout is what makes it pay.  Not at dim 256: its 4-wave kernels are at the
+    // register limit and the buffer path measured 17.7 ms against 12.4 ms per cfg5 step.)
+    const bool bx3_keep = prec == 1 && dim == 128;
+    rc = prec == 1 ? (bx3_keep ? dispatch_score_bx3<MODE_FUSED_S>(dim, a, cand_ids != nullptr, stream)
+                               : dispatch_score_bx3<MODE_FUSED>(dim, a, cand_ids != nullptr, stream))
                    : dispatch_score<MODE_FUSED_S>(dim, a, cand_ids != nullptr, stream);
     if (rc != TT_OK) return rc;
     {
@@ -1386,11 +1389,12 @@ static int retrieval_fwd_bwd(int prec, const float* q, const float* c, int64_t n
     a.h_c = hq;
     a.id_r = cand_ids;
     a.id_c = cand_ids != nullptr ? cand_ids + diag_offset : nullptr;
-    a.nsplit = w.ns_cs;
+    a.nsplit = (prec == 1 && dim != 128) ? w.ns_c : w.ns_cs;
     a.c_per_split = align_up((nq + a.nsplit - 1) / a.nsplit, 32);
     a.slab = slab;
     a.S = smat; a.ldS = (nq + 31) / 32;
-    rc = prec == 1 ? dispatch_score_bx3<MODE_BWD_S>(dim, a, cand_ids != nullptr, stream)
+    rc = prec == 1 ? (dim == 128 ? dispatch_score_bx3<MODE_BWD_S>(dim, a, cand_ids != nullptr, stream)
+                                 : dispatch_score_bx3<MODE_BWD>(dim, a, cand_ids != nullptr, stream))
                    : dispatch_score<MODE_BWD_S>(dim, a, cand_ids != nullptr, stream);
     if (rc != TT_OK) return rc;
     const int64_t n4 = nc * dim / 4;
