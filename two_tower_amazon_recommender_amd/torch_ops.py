@@ -25,8 +25,10 @@ from . import ops
 NS = "twotower"
 
 
-def _ws(nq: int, nc: int, d: int, device) -> Tensor:
-    return torch.empty(ops.retrieval_workspace_bytes(nq, nc, d), dtype=torch.uint8, device=device)
+def _ws(nq: int, nc: int, d: int, device, forward_only: bool = False) -> Tensor:
+    """Scorer workspace; the training entry's includes the [nq, nc] f32 dot-product buffer its second pass reads back."""
+    n = ops.retrieval_fwd_workspace_bytes(nq, nc, d) if forward_only else ops.retrieval_workspace_bytes(nq, nc, d)
+    return torch.empty(n, dtype=torch.uint8, device=device)
 
 
 # --------------------------------------------------------------------------------------------- a1 lookup
@@ -98,7 +100,7 @@ def retrieval_loss_value(query_embeddings: Tensor, candidate_embeddings: Tensor,
     """Forward only (validation): (loss [], per-example loss [Bq]) in one statistics pass."""
     q, c = query_embeddings.contiguous(), candidate_embeddings.contiguous()
     nq, nc, d = q.shape[0], c.shape[0], q.shape[1]
-    ws = _ws(nq, nc, d, q.device)
+    ws = _ws(nq, nc, d, q.device, forward_only=True)
     lse, per_row = q.new_empty(nq), q.new_empty(nq)
     loss = q.new_empty(1)
     thr = None
