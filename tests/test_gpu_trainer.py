@@ -311,6 +311,44 @@ def test_loss_decreases_over_steps(dev):
     assert last < first
 
 
+@pytest.mark.parametrize("opt,variant,buckets", [("sgd", "U", 0), ("adagrad", "Z", 30)])
+def test_fused_launches_equal_the_separate_ones_bit_for_bit(dev, opt, variant, buckets):
+    """The train step's fusions change launches, not arithmetic: lookup inside the layer-0 GEMM loaders, ReLU sign bits as
+    the dx mask, sort + sparse apply + dense update in ONE optimizer launch from the raw ids — against gather launch,
+    plan launch, sparse launch(es) and dense launch.  Loss, tables, accumulators and dense weights after several steps
+    must be identical bit for bit (uniform / Zipf ids, with and without the hashed category table)."""
+    cfg = TwoTowerConfig(n_users=5000, n_items=3000, embedding_dim=64, tower_dims=[128, 64], temperature=0.1,
+                         l2_regularization=1e-6, learning_rate=0.001, optimizer=opt, batch_size=2048,
+                         n_category_buckets=buckets)
+    a = TwoTowerTrainer(cfg, dev, seed=37)
+    b = TwoTowerTrainer(TwoTowerConfig(**cfg.__dict__), dev, seed=37)
+    b.fuse_sort = False
+    b.fuse_optimizer = False
+    b.fuse_lookup = False
+    assert a.fuse_sort and a.fuse_optimizer and a.fuse_lookup
+    for step in range(4):
+        u, i = a.synthetic_batch(37, step, variant)
+        extra = {"category_ids": a.synthetic_categories(37, step)} if buckets else {}
+        la = a.step(u, i, **extra).clone()
+        lb = b.step(u, i, **extra).clone()
+        assert torch.equal(la, lb), step
+    a.check_ids(); b.check_ids()
+    assert torch.equal(a.user_table, b.user_table) and torch.equal(a.item_table, b.item_table)
+    assert torch.equal(a.dense_flat, b.dense_flat)
+    if buckets:
+        assert torch.equal(a.cat_table, b.cat_table)
+    if opt == "adagrad":
+        assert torch.equal(a.user_accum, b.user_accum) and torch.equal(a.item_accum, b.item_accum)
+    # the middle form too: one optimizer launch, but behind a separate plan launch
+    c = TwoTowerTrainer(TwoTowerConfig(**cfg.__dict__), dev, seed=37)
+    c.fuse_sort = False
+    for step in range(4):
+        u, i = c.synthetic_batch(37, step, variant)
+        extra = {"category_ids": c.synthetic_categories(37, step)} if buckets else {}
+        c.step(u, i, **extra)
+    assert torch.equal(a.user_table, c.user_table) and torch.equal(a.item_table, c.item_table) and torch.equal(a.dense_flat, c.dense_flat)
+
+
 @pytest.mark.parametrize("opt,variant", [("sgd", "U"), ("adagrad", "Z")])
 def test_sharded_trainer_world1_is_bit_identical_to_single_gpu_trainer(dev, opt, variant):
     """The row-sharded step (route / de-dup / exchange buffers / owner update) with one rank must reproduce the
