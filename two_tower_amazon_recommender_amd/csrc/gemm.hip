@@ -23,7 +23,16 @@ using tt::f32x4;
 using tt::f32x16;
 
 constexpr int BM = 64, BN = 64, BK = 32;
-constexpr int PF_MAX = 4;                // k-tiles of global loads kept in flight per thread (register ring); the mixed-orientation
+// k-tiles of global loads in flight per thread.  r02 sweep of the four cfg3 tower launches (us): 1: 96.3, 2: 95.3, 3: 98.8,
+// 4 (3 for the forward orientation, the r01 setting): 98.2 - with four resident workgroups per CU the other waves cover a
+// tile's latency; the smaller ring leaves registers.
+#ifndef TT_GEMM_PF
+#define TT_GEMM_PF 2
+#endif
+#ifndef TT_GEMM_PF_FWD
+#define TT_GEMM_PF_FWD 2
+#endif
+constexpr int PF_MAX = TT_GEMM_PF;       // k-tiles of global loads kept in flight per thread (register ring); the mixed-orientation
                                          // forward kernel runs with 3 (it spills 22-48 VGPRs at 4 under the 4-waves/SIMD bound)
 constexpr int NST = BM * BK / 4 / 256;   // staged float4 per thread and operand (= 2)
 constexpr int LS_KC = BK + 4;            // [row][k] stride
@@ -192,7 +201,7 @@ struct GemmBatch {
 template <bool A_KC, bool B_KC, bool COLSUM, int GK, bool DROP = false>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int zsplit, const int bx, const int by, float* smem,
                                           int32_t* gids) {
-  constexpr int PF = (A_KC && !B_KC) ? 3 : PF_MAX;
+  constexpr int PF = (A_KC && !B_KC) ? TT_GEMM_PF_FWD : PF_MAX;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, ln = lane & 31;
