@@ -1118,7 +1118,18 @@ WsLayout ws_layout(int64_t nq, int64_t nc, int32_t dim) {
 // MFMA runs at the f32 vector rate; a 25 % cut of the epilogue's VALU instructions changed nothing measurable, so the
 // cost is in the GEMM1 -> epilogue -> GEMM2 dependency hand-offs rather than in VALU throughput).
 template <int D, int MODE, int PREC = 0>
-constexpr int waves_for() { return (PREC == 1 && D == 128) ? 8 : (PREC == 1 ? 4 : TT_SCORE_WAVES); }     // bf16x3 at dim 128: 256-row workgroups, one per CU
+// waves per workgroup of the exact-f32 training passes at D <= 128 (r02 A/B at cfg3: the dc pass with 8 waves = 256 stationary
+// rows per workgroup, one workgroup per CU, half the tile staging per MFMA: 169.0 -> 165.8 us; pass 1 with 8: 276.8 -> 277.6)
+#ifndef TT_BWDS_WG_WAVES
+#define TT_BWDS_WG_WAVES 8
+#endif
+#ifndef TT_FUSEDS_WG_WAVES
+#define TT_FUSEDS_WG_WAVES 4
+#endif
+constexpr int waves_for() {
+  return (PREC == 1 && D == 128) ? 8 : (PREC == 1 ? 4 : ((MODE == MODE_BWD_S && D <= 128) ? TT_BWDS_WG_WAVES
+                                                         : ((MODE == MODE_FUSED_S && D <= 128) ? TT_FUSEDS_WG_WAVES : TT_SCORE_WAVES)));
+}     // bf16x3 at dim 128: 256-row workgroups, one per CU
 
 template <int D, int MODE, int PREC = 0>
 int launch_score(const ScoreArgs& a_in, bool has_ids, hipStream_t stream) {
