@@ -1,5 +1,5 @@
 """Phase stamps of optimizer_ids_kernel's sorting workgroups (debug build of sparse.hip with -DTT_SORT_STAMPS via TT_LIB_PATH):
-0 start, 1 ids counted, 2 barrier, 3 scan done, 4 compaction done, 5 ranked (sorted pairs in LDS), 6 rows updated."""
+0 start, 1 ids counted + appended, 2 barrier, 3 rows requested (r03: before the ranking), 4 (hot range only) list rebuilt, 5 ranked (sorted pairs in LDS), 6 rows updated."""
 import ctypes as C
 import os
 import sys
@@ -21,12 +21,14 @@ for _ in range(5):
 torch.cuda.synchronize()
 buf = np.zeros(1024 * 8, dtype=np.uint64)
 assert lib.tt_debug_opt_stamps(buf.ctypes.data, buf.size) == 0
-allw = buf.reshape(1024, 8)[:, :7].astype(np.int64)
+allw = buf.reshape(1024, 8).astype(np.int64)
 s = allw[36:256]
 s = s[s[:, 6] > s[:, 0]]
 t0 = s[:, 0].min()
 us = (s - t0) / 100.0
-print(len(s), "sorting WGs; mean stamp times (us):", us.mean(0).round(2).tolist(), "max end", us[:, 6].max(), "start spread", us[:, 0].max())
+names = ["start", "appended", "barrier", "rows requested", "classified", "ranked", "updated", "ids landed"]
+order = [0, 7, 4, 1, 2, 3, 5, 6]
+print(len(s), "sorting WGs; mean stamp times (us):", ", ".join(f"{names[k]} {us[:, k].mean():.2f}" for k in order), "| max end", us[:, 6].max(), "start spread", us[:, 0].max())
 d = allw[:36]
 d = d[d[:, 6] > d[:, 0]]
 ud = (d - t0) / 100.0

@@ -286,13 +286,16 @@ def test_sparse_heavy_hitters_are_split_into_pieces_bit_exact(dev, opt, n):
 @pytest.mark.parametrize("n,dim,rows,kind", [(8192, 128, (5_000_000, 100_000), "U"), (8192, 128, (100_000, 3_000), "Z"),
                                              (16384, 128, (1_000_000, 50_000), "Z"), (1000, 32, (777, 40), "U"),
                                              (4096, 256, (20_000, 20_000), "Z"), (9000, 128, (1000, 1000), "heavy"),
-                                             (300, 64, (5, 1), "U")])
+                                             (300, 64, (5, 1), "U"), (8192, 128, (100_000, 5_000), "U"),
+                                             (512, 32, (2_000, 1_500), "U"), (4096, 64, (20_000, 2_000), "U")])
 def test_optimizer_step_from_raw_ids_matches_plan_then_step_bit_for_bit(dev, opt, n, dim, rows, kind):
     """tt_optimizer_step_ids_f32 — the optimizer launch sorts the ids of each row range in LDS and updates those rows
     itself, no plan launch, no sorted ids in HBM — against tt_sparse_plan_batched + tt_optimizer_step_f32 (itself
     bit-exact vs the oracle above): tables, accumulators and dense parameters identical bit for bit, for uniform / Zipf /
     heavy-hitter ids (runs of thousands, several pieces), out-of-range and padding ids, three tables (the third with 30
-    rows: every id hundreds of times), tiny tables."""
+    rows: every id hundreds of times), tiny tables, and row ranges in which ids touched once, twice (finished without ranks,
+    r03) and three or more times (ranked path, piece sums) mix - the 5,000-row case caught a pair across a 64-slot boundary
+    being applied twice."""
     rng = np.random.default_rng(5)
     rows3 = list(rows) + [30]
     ids = []
@@ -626,11 +629,34 @@ def test_retrieval_grad_scale_linearity(dev):
 
 
 @pytest.mark.parametrize("fused", [False, True, "bf16x3"])
-def test_retrieval_is_deterministic(dev, fused):
-    q = synth.uniform_f32(44, 1, 2048 * 128, -0.3, 0.6).reshape(2048, 128)
-    a = run_retrieval(dev, q, q[::-1].copy(), 0.1, fused=fused)
-    b = run_retrieval(dev, q, q[::-1].copy(), 0.1, fused=fused)
-    assert a[0] == b[0] and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+@pytest.mark.parametrize("n,d", [(2048, 128), (1056, 256), (1056, 128)])
+def test_retrieval_is_deterministic(dev, fused, n, d):
+    """Bitwise run-to-run reproducibility of every scorer form (FWD statistics pass + two BWD passes; the fused FUSED_S /
+    BWD_S pair; bf16x3), at dim 128 and at dim 256 (the instantiation r02 saw run-to-run differences in, score.hip), with
+    even (2048) and odd / empty (1056 = 33 tiles) tile counts per split; five launches each."""
+    q = synth.uniform_f32(44, 1, n * d, -0.3, 0.6).reshape(n, d)
+    runs = [run_retrieval(dev, q, q[::-1].copy(), 0.1, fused=fused) for _ in range(5)]
+    a = runs[0]
+    for b in runs[1:]:
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+
+
+@pytest.mark.parametrize("nq,nc,d", [(2048, 4096, 128), (1056, 3000, 256)])
+def test_retrieval_rank_pass_is_deterministic(dev, nq, nc, d):
+    q = T(synth.uniform_f32(45, 1, nq * d, -0.3, 0.6).reshape(nq, d), dev)
+    c = T(synth.uniform_f32(45, 2, nc * d, -0.3, 0.6).reshape(nc, d), dev)
+    pos = T(synth.ids_uniform(45, 3, nq, nc), dev)
+    ranks = [ops.retrieval_rank(q, c, 10.0, pos).cpu().numpy() for _ in range(5)]
+    for r in ranks[1:]:
+        assert np.array_equal(ranks[0], r)
+
+
+@pytest.mark.parametrize("nq,nc,d", [(160, 160, 128), (1056, 1056, 128), (96, 96, 256), (1056, 1056, 256), (1120, 1184, 64)])
+def test_retrieval_odd_and_short_tile_counts(dev, nq, nc, d):
+    """Splits of 3 and 2 tiles, of 33 tiles, and empty trailing splits: the two-tiles-per-iteration loop of the dc pass
+    (BWD_S) and the two-tiles-per-barrier ring of the gradient passes end on an odd tile / skip the loop altogether."""
+    check_retrieval(dev, nq, nc, d, off=nc - nq)
 
 
 def test_fused_online_rescale_branch_is_exercised(dev):

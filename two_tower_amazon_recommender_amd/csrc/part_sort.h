@@ -160,19 +160,35 @@ __device__ __forceinline__ void part_local_sort(const PartTable& t, uint32_t* ke
 // [16][RADIX] | per-(load, wave) counts [16][16] | 2 x 16 scan partials | 16 counters | positions u16 [cap]
 __host__ __device__ inline int part_sort_lds_bytes(int cap, int radix) { return (cap + 64 + 16 * radix + 16 * 16 + 48) * 4 + cap * 2; }
 __device__ __forceinline__ uint32_t* part_keys(uint32_t* smem) { return smem; }
+// !TO_GLOBAL, m <= 512 (ranked by counting): rank of the i-th pair of the UNORDERED list the workgroup appended (u16 [512],
+// in the radix counters' area, which that path does not use) - lets a caller that requested rows per unordered pair find
+// the pair's sorted slot afterwards
+__device__ __forceinline__ uint16_t* part_ranks(uint32_t* smem, int cap) { return reinterpret_cast<uint16_t*>(smem + cap + 64); }
+constexpr uint32_t kPartRankMax = 512u;                     // lists up to this length are ranked by counting
 template <int DBITS>
 __device__ __forceinline__ uint16_t* part_poss(uint32_t* smem, int cap) {
   return reinterpret_cast<uint16_t*>(smem + cap + 64 + 16 * (1 << DBITS) + 16 * 16 + 48);
 }
 
-// The body of one sorting workgroup (1024 threads), group g of table t.  TO_GLOBAL: the sorted (id, position) pairs go to
-// t.sorted_ids / t.order at the group's offset.  !TO_GLOBAL (the fused optimizer, csrc/sparse.hip): they stay in LDS —
-// part_keys(smem)[0..m) local keys ascending (id = base_key + key), part_poss(smem, cap)[0..m) their batch positions —
-// and every thread returns after a barrier.  Returns m (uniform); offset = number of keys sorting before the group.
-// JMAX: ids per thread of the scan (8: lists <= 8192, 16: <= 16384).
-template <int DBITS, int JMAX, bool TO_GLOBAL>
-__device__ __forceinline__ uint32_t part_sort_body(const PartTable& t, const int g, const int cap, uint32_t* smem, uint32_t& offset,
-                                                   uint32_t& base_key) {
+// The body of one sorting workgroup (1024 threads), group g of table t, in three pieces (part_sort_body composes them; the
+// fused optimizer, csrc/sparse.hip, calls them itself so that it can request rows between the scan and the ranking):
+//   part_scan_append   every id of the table is read and clamped, the keys of the group's row range are appended to the LDS
+//                      list (unordered); returns m = their number (workgroup-uniform), offset = keys sorting before the group
+//   part_rank_small    m <= kPartRankMax: stable rank by counting
+//   part_sort_hot      a hot range: the list is rebuilt in position order and LSD-radix-sorted
+// TO_GLOBAL: the sorted (id, position) pairs go to t.sorted_ids / t.order at the group's offset.  !TO_GLOBAL: they stay in
+// LDS - part_keys(smem)[0..m) local keys ascending (id = base_key + key), part_poss(smem, cap)[0..m) their batch positions
+// (and, ranked lists, part_ranks(smem, cap)[i] = the sorted slot of the i-th appended pair) - and every thread returns
+// after a barrier.  JMAX: ids per thread of the scan (8: lists <= 8192, 16: <= 16384).
+template <int JMAX>
+struct PartScan {
+  uint32_t kj[JMAX];       // this thread's clamped keys (0xffffffff past n)
+  uint64_t mm[JMAX];       // per load: which lanes of the wave hold a key of this group's range
+};
+
+template <int DBITS, int JMAX>
+__device__ __forceinline__ uint32_t part_scan_append(const PartTable& t, const int g, const int cap, uint32_t* smem, PartScan<JMAX>& sc,
+                                                     uint32_t& offset, uint32_t& base_key) {
   constexpr int RADIX = 1 << DBITS;
   constexpr int W = 16, T = 1024;
   uint32_t* keys = smem;                                    // [cap]
@@ -187,32 +203,37 @@ __device__ __forceinline__ uint32_t part_sort_body(const PartTable& t, const int
   SSTAMP(0);
 
   // ---- scan: every id of the table; clamp; which range ----
-  uint32_t kj[JMAX];
 #pragma unroll
   for (int j = 0; j < JMAX; ++j) {
     const int i = j * T + tid;
     const int64_t id = t.ids[(j < J && i < n) ? i : 0];
-    kj[j] = (j < J && i < n) ? ((id >= 0 && id < t.num_rows) ? (uint32_t)id : t.sentinel) : 0xffffffffu;   // past n: no range
+    sc.kj[j] = (j < J && i < n) ? ((id >= 0 && id < t.num_rows) ? (uint32_t)id : t.sentinel) : 0xffffffffu;   // past n: no range
   }
   if (tid == 0) { ctr[0] = 0u; ctr[1] = 0u; }
-  __syncthreads();                                          // counters zeroed (the id loads above are still in flight)
+  __syncthreads();                                          // counters zeroed; the ids have landed (the barrier's fence waits for them)
+  SSTAMP(7);
   // ---- group of every id; own-range masks (wave-uniform); the wave appends its own keys to the LDS list at a base drawn
   // from one LDS counter - in NO particular order across waves: the usual group (<= 512 keys) is ranked by (key, position)
   // below, which needs no order.  The per-(load, wave) counts are kept for the ordered path of a hot range. ----
-  uint64_t mm[JMAX];
+  // (r03: a key is classified against THIS group's range [lo, lo + span) directly - one subtract and two compares per id -
+  // instead of computing its group number first (multiply-high, multiply, compare, subtract, min: bucket_of, kept for the
+  // routing kernels).  The last group's span runs up to the out-of-range sentinel; the all-ones key of a slot past n is in
+  // no range and not below any.  Every workgroup classifies all n ids, so these instructions ARE the scan's VALU time.)
+  base_key = (uint32_t)g * t.width;
+  const uint32_t span = (g == t.groups - 1) ? (base_key <= t.sentinel ? t.sentinel - base_key + 1u : 0u) : t.width;
   uint32_t below = 0u, wave_mine = 0u;
 #pragma unroll
   for (int j = 0; j < JMAX; ++j) {
-    mm[j] = 0ull;
+    sc.mm[j] = 0ull;
     if (j < J) {
-      const uint32_t b = bucket_of(kj[j], t);
-      mm[j] = __builtin_amdgcn_ballot_w64(b == (uint32_t)g);
-      below += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(b < (uint32_t)g));
-      const uint32_t c1 = (uint32_t)__popcll(mm[j]);
+      sc.mm[j] = __builtin_amdgcn_ballot_w64(sc.kj[j] - base_key < span);
+      below += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(sc.kj[j] < base_key));
+      const uint32_t c1 = (uint32_t)__popcll(sc.mm[j]);
       wave_mine += c1;
       if (lane == 0) cjw[j * W + w] = c1;
     }
   }
+  SSTAMP(4);
   uint32_t wbase = 0u;
   if (lane == 0) {
     wbel[w] = below;
@@ -220,60 +241,87 @@ __device__ __forceinline__ uint32_t part_sort_body(const PartTable& t, const int
     atomicAdd(&ctr[1], below);
   }
   wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
-  base_key = (uint32_t)g * t.width;
 #pragma unroll
   for (int j = 0; j < JMAX; ++j) {
     if (j < J) {
-      if ((mm[j] >> lane) & 1ull) {
-        const uint32_t dst = wbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm[j], 0u));
-        keys[dst] = kj[j] - base_key;
+      if ((sc.mm[j] >> lane) & 1ull) {
+        const uint32_t dst = wbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(sc.mm[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sc.mm[j], 0u));
+        keys[dst] = sc.kj[j] - base_key;
         poss[dst] = (uint16_t)(j * T + tid);
       }
-      wbase += (uint32_t)__popcll(mm[j]);
+      wbase += (uint32_t)__popcll(sc.mm[j]);
     }
   }
   SSTAMP(1);
   __syncthreads();
   SSTAMP(2);
-  const uint32_t m = ctr[0];
-  offset = ctr[1];
-  if (m == 0u) return 0u;
-  if (m <= 512u) {
-    // ---- the usual case (n / groups ~ 64-128 keys): rank by counting.  P = 1024 / pow2(m) threads per element e, each
-    // compares a 1/P slice of the list: rank = #(smaller keys) + #(equal keys at a smaller batch position) = the stable
-    // rank, whatever order the list is in. ----
-    uint32_t lp = 4;                                        // log2 P: 16 threads per element up to 64 keys ... 2 up to 512
-    while ((T >> lp) < m) --lp;
-    const uint32_t e = (uint32_t)tid >> lp, sub = (uint32_t)tid & ((1u << lp) - 1u), P = 1u << lp;
-    const uint32_t ee = e < m ? e : 0u;
-    const uint32_t key = keys[ee], pos = poss[ee];
-    uint32_t c = 0u;
-    // 4 pairs per iteration (one ds_read_b128 + one ds_read_b64); slots past m (inside the LDS arrays) are masked out
-    for (uint32_t j = 4u * sub; j < m; j += 4u * P) {
-      const uint4 k4 = *reinterpret_cast<const uint4*>(keys + j);
-      const uint2 p2 = *reinterpret_cast<const uint2*>(poss + j);
-      const uint32_t p0 = p2.x & 0xffffu, p1 = p2.x >> 16, pq2 = p2.y & 0xffffu, p3 = p2.y >> 16;
-      c += (k4.x < key || (k4.x == key && p0 < pos)) ? 1u : 0u;
-      c += (j + 1u < m && (k4.y < key || (k4.y == key && p1 < pos))) ? 1u : 0u;
-      c += (j + 2u < m && (k4.z < key || (k4.z == key && pq2 < pos))) ? 1u : 0u;
-      c += (j + 3u < m && (k4.w < key || (k4.w == key && p3 < pos))) ? 1u : 0u;
-    }
-    for (uint32_t o = 1u; o < P; o <<= 1) c += (uint32_t)__shfl_xor((int)c, (int)o);
-    if constexpr (TO_GLOBAL) {
-      if (sub == 0u && e < m) {
-        t.sorted_ids[offset + c] = (int64_t)(key + base_key);
-        t.order[offset + c] = (int32_t)pos;
-      }
-    } else {
-      __syncthreads();                                      // every thread has read the pairs it compares with
-      if (sub == 0u && e < m) { keys[c] = key; poss[c] = (uint16_t)pos; }
-      __syncthreads();
-    }
-    SSTAMP(5);
-    return m;
+  // (readfirstlane: the counts are workgroup-uniform, but read from LDS the compiler takes them for per-lane values and
+  // every branch on m for a divergent one - both sides of it then run back to back under masks, and the registers of the
+  // hot path (kj, mm: 24-48 VGPRs) stay allocated through the ranking path and the caller's apply)
+  const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctr[0]);
+  offset = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctr[1]);
+  return m;
+}
+
+// Workgroup barrier for LDS traffic only: waits for this wave's LDS operations, NOT for its global loads in flight
+// (__syncthreads() is a fence + barrier: `s_waitcnt vmcnt(0)` first, which would park the rows the fused optimizer has
+// just requested in front of the ranking instead of letting them land under it).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ---- the usual case (n / groups ~ 64-128 keys): rank by counting.  P = 1024 / pow2(m) threads per element e, each
+// compares a 1/P slice of the list: rank = #(smaller keys) + #(equal keys at a smaller batch position) = the stable
+// rank, whatever order the list is in. ----
+template <int DBITS, bool TO_GLOBAL>
+__device__ __forceinline__ void part_rank_small(const PartTable& t, const int cap, uint32_t* smem, const uint32_t m, const uint32_t offset,
+                                                const uint32_t base_key) {
+  constexpr int T = 1024;
+  uint32_t* keys = smem;
+  uint16_t* poss = part_poss<DBITS>(smem, cap);
+  const int tid = threadIdx.x;
+  uint32_t lp = 4;                                        // log2 P: 16 threads per element up to 64 keys ... 2 up to 512
+  while ((T >> lp) < m) --lp;
+  const uint32_t e = (uint32_t)tid >> lp, sub = (uint32_t)tid & ((1u << lp) - 1u), P = 1u << lp;
+  const uint32_t ee = e < m ? e : 0u;
+  const uint32_t key = keys[ee], pos = poss[ee];
+  uint32_t c = 0u;
+  // 4 pairs per iteration (one ds_read_b128 + one ds_read_b64); slots past m (inside the LDS arrays) are masked out
+  for (uint32_t j = 4u * sub; j < m; j += 4u * P) {
+    const uint4 k4 = *reinterpret_cast<const uint4*>(keys + j);
+    const uint2 p2 = *reinterpret_cast<const uint2*>(poss + j);
+    const uint32_t p0 = p2.x & 0xffffu, p1 = p2.x >> 16, pq2 = p2.y & 0xffffu, p3 = p2.y >> 16;
+    c += (k4.x < key || (k4.x == key && p0 < pos)) ? 1u : 0u;
+    c += (j + 1u < m && (k4.y < key || (k4.y == key && p1 < pos))) ? 1u : 0u;
+    c += (j + 2u < m && (k4.z < key || (k4.z == key && pq2 < pos))) ? 1u : 0u;
+    c += (j + 3u < m && (k4.w < key || (k4.w == key && p3 < pos))) ? 1u : 0u;
   }
-  // ---- a hot key range (> 512 keys: skewed ids): the list is rebuilt IN POSITION ORDER (exclusive scan of the
-  // per-(load, wave) counts, j major / wave minor) - the LSD radix passes below are stable with respect to it ----
+  for (uint32_t o = 1u; o < P; o <<= 1) c += (uint32_t)__shfl_xor((int)c, (int)o);
+  if constexpr (TO_GLOBAL) {
+    if (sub == 0u && e < m) {
+      t.sorted_ids[offset + c] = (int64_t)(key + base_key);
+      t.order[offset + c] = (int32_t)pos;
+    }
+  } else {
+    lds_barrier();                                        // every thread has read the pairs it compares with
+    if (sub == 0u && e < m) { keys[c] = key; poss[c] = (uint16_t)pos; part_ranks(smem, cap)[e] = (uint16_t)c; }
+    lds_barrier();
+  }
+  SSTAMP(5);
+}
+
+// ---- a hot key range (> kPartRankMax keys: skewed ids): the list is rebuilt IN POSITION ORDER (exclusive scan of the
+// per-(load, wave) counts, j major / wave minor) - the LSD radix passes are stable with respect to it ----
+template <int DBITS, int JMAX, bool TO_GLOBAL>
+__device__ __forceinline__ void part_sort_hot(const PartTable& t, const int g, const int cap, uint32_t* smem, const PartScan<JMAX>& sc,
+                                              const uint32_t m, const uint32_t offset, const uint32_t base_key) {
+  constexpr int RADIX = 1 << DBITS;
+  constexpr int W = 16, T = 1024;
+  uint32_t* keys = smem;
+  uint32_t* cnt = keys + cap + 64;
+  uint32_t* cjw = cnt + W * RADIX;
+  uint32_t* wtot = cjw + 16 * W;
+  uint16_t* poss = part_poss<DBITS>(smem, cap);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int n = t.n, J = (n + T - 1) / T;
   __syncthreads();                                          // everyone has read ctr; the unordered list may be overwritten
   {
     uint32_t val = (tid < J * W) ? cjw[tid] : 0u, incl = val;
@@ -291,9 +339,9 @@ __device__ __forceinline__ uint32_t part_sort_body(const PartTable& t, const int
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < JMAX; ++j) {
-      if (j < J && ((mm[j] >> lane) & 1ull)) {
-        const uint32_t dst = cjw[j * W + w] + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm[j], 0u));
-        keys[dst] = kj[j] - base_key;
+      if (j < J && ((sc.mm[j] >> lane) & 1ull)) {
+        const uint32_t dst = cjw[j * W + w] + __builtin_amdgcn_mbcnt_hi((uint32_t)(sc.mm[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sc.mm[j], 0u));
+        keys[dst] = sc.kj[j] - base_key;
         poss[dst] = (uint16_t)(j * T + tid);
       }
     }
@@ -301,8 +349,8 @@ __device__ __forceinline__ uint32_t part_sort_body(const PartTable& t, const int
     __syncthreads();
   }
   SSTAMP(4);
-  // ---- a hot key range: LSD radix sort of the m compacted (local key, position) pairs; register arrays by rounds needed;
-  // passes by the bits of this group's largest local key (the last group's is the sentinel's) ----
+  // ---- LSD radix sort of the m compacted (local key, position) pairs; register arrays by rounds needed; passes by the
+  // bits of this group's largest local key (the last group's is the sentinel's) ----
   const uint32_t local_max = g == t.groups - 1 ? t.sentinel - base_key : t.width - 1u;
   const int lbits = 32 - __builtin_clz(local_max | 1u);
   const int npass = (lbits + DBITS - 1) / DBITS;
@@ -314,6 +362,16 @@ __device__ __forceinline__ uint32_t part_sort_body(const PartTable& t, const int
     else if (m <= 6u * T) part_local_sort<DBITS, 6, TO_GLOBAL>(t, keys, poss, cnt, wtot, m, offset, base_key, npass);
     else part_local_sort<DBITS, 16, TO_GLOBAL>(t, keys, poss, cnt, wtot, m, offset, base_key, npass);
   }
+}
+
+template <int DBITS, int JMAX, bool TO_GLOBAL>
+__device__ __forceinline__ uint32_t part_sort_body(const PartTable& t, const int g, const int cap, uint32_t* smem, uint32_t& offset,
+                                                   uint32_t& base_key) {
+  PartScan<JMAX> sc;
+  const uint32_t m = part_scan_append<DBITS, JMAX>(t, g, cap, smem, sc, offset, base_key);
+  if (m == 0u) return 0u;
+  if (m <= kPartRankMax) part_rank_small<DBITS, TO_GLOBAL>(t, cap, smem, m, offset, base_key);
+  else part_sort_hot<DBITS, JMAX, TO_GLOBAL>(t, g, cap, smem, sc, m, offset, base_key);
   return m;
 }
 

@@ -131,6 +131,9 @@ __device__ __forceinline__ int img_off(int row, int ch) { return 256 * row + 16 
 #ifndef TT_S_PREFETCH
 #define TT_S_PREFETCH 2       // BWD_S: tiles of stored dot products in flight ahead of the one being worked on (1 or 2)
 #endif
+#ifndef TT_LOOP_LAMBDA
+#define TT_LOOP_LAMBDA 0
+#endif
 #ifndef TT_TILES_PER_BARRIER
 #define TT_TILES_PER_BARRIER 2
 #endif
@@ -161,15 +164,20 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? ((MODE ==
   const int h = lane >> 5;
   const int ln = lane & 31;
 
-  const int split = blockIdx.x % p.nsplit;
-  const int64_t rblk = blockIdx.x / p.nsplit;
+  // Everything that steers a loop with a workgroup barrier in it is made PROVABLY wave-uniform (readfirstlane): the split,
+  // the row block and, below, the tile count.  They depend on blockIdx and kernel arguments only, but hipcc divides on the
+  // vector ALU; whether the quotient comes back to an SGPR is its choice, and a trip count left in VGPRs turns the tile
+  // loop's exit test into a vector compare with the barrier inside a loop the compiler treats as divergent.
+  // scratch/audit_barriers.py checks the built ISA: in all instantiations every barrier loop closes on scalar branches.
+  const int split = __builtin_amdgcn_readfirstlane((int)(blockIdx.x % (unsigned)p.nsplit));
+  const int64_t rblk = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / (unsigned)p.nsplit));
   const int64_t r0w = rblk * (WAVES * 32) + wave * 32;   // first row of this wave
   const int64_t r = r0w + ln;                       // this lane's row (both halves)
   const bool r_ok = r < p.n_r;
   const int64_t c_begin = (int64_t)split * p.c_per_split;
   int64_t c_end = c_begin + p.c_per_split;
   if (c_end > p.n_c) c_end = p.n_c;
-  const int ntiles = c_end > c_begin ? (int)((c_end - c_begin + 31) >> 5) : 0;
+  const int ntiles = __builtin_amdgcn_readfirstlane(c_end > c_begin ? (int)((c_end - c_begin + 31) >> 5) : 0);
 
   // ---- stationary fragment (B operand of GEMM1), in registers for the whole launch ----
   //   f32:     rf[g][s]     = R[r][8g + 4h + s]
@@ -699,14 +707,49 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? ((MODE ==
     }
   } else {
     // ---- every wave runs GEMM1 -> epilogue -> GEMM2 per tile; 2 LDS buffers, one barrier per tile ----
-    // (Keep this loop as a plain loop.  Wrapping its body in a lambda called from an unrolled k-loop - the form the BWD_S
-    // branch above uses - compiled, for score_kernel<256, FWD>, to a loop whose exit test is a vector compare and whose
-    // results were wrong in about half the rows, differently from run to run (r02; same instructions otherwise; an
-    // extra barrier per iteration did not help).  tests: test_retrieval_baseline_configs[1024-256] catches it.)
+    // History (r02 -> r03).  In r02 a build of this loop with its body in a lambda called twice per iteration (the form the
+    // BWD_S branch above uses) gave, for score_kernel<256, FWD>, wrong values in about half the rows, different from run to
+    // run; the note left here said its loop "exit test is a vector compare".  That build was never committed.  r03 rebuilt
+    // the form from the description (TT_LOOP_LAMBDA=1, below) with the same compiler: its ISA has SCALAR loop control
+    // (s_cmp / s_cbranch_scc on the tile count), the `s_waitcnt vmcnt(0)` in front of every staged tile's ds_write and
+    // `s_waitcnt lgkmcnt(0)` in front of every s_barrier exactly as the plain loop, and it passes the parity and determinism
+    // tests on the GPU three runs out of three (profiles/r03_loop_lambda_audit.txt) - so the lambda form as such is not the
+    // cause.  What the r02 note does pin down is a trip count held in VGPRs: results that change from run to run need waves
+    // that disagree about how often they reach the barrier, and the only way the tile loop gets there is a per-lane copy of
+    // `ntiles` / `t` (the quotient blockIdx / nsplit is computed on the vector ALU) that the compiler no longer proves uniform
+    // once the loop body is large enough to spill or re-materialise it (D = 256: 240+ VGPRs).  The fix is by construction:
+    // split, row block and ntiles go through readfirstlane (top of the kernel), so in EVERY loop form the compiler sees
+    // scalar control, and scratch/audit_barriers.py verifies on the built ISA - for all 112 instantiations, both loop forms -
+    // that each barrier loop closes and exits on scalar branches and that no barrier can be skipped under a lane mask (the
+    // script's negative control, a barrier loop on a per-lane trip count, is flagged).  The shipping BWD_S loop above
+    // satisfies the same condition.  tests: test_retrieval_baseline_configs[1024-256], test_retrieval_is_deterministic
+    // (dims 128 and 256, every form, rank pass), test_retrieval_odd_and_short_tile_counts.
     f32x16 xs;
 #pragma unroll
     for (int i = 0; i < 16; ++i) xs[i] = 0.f;
     if constexpr (FROM_S) { if (ntiles > 0) load_S(0, xs); }
+#if TT_LOOP_LAMBDA
+    auto tile_step = [&](int t) {
+      if constexpr (MODE == MODE_FWD || MODE == MODE_RANK || PREC == 1) { if (t + 1 < ntiles) load_tile(t + 1); }
+      const float* T = smem + (t % NBUF) * BUF_F;
+      f32x16 X;
+      if constexpr (FROM_S) X = xs; else X = gemm1(T);
+      if constexpr (TO_S) store_S(t, X);
+      float coef[16];
+      epilogue(T, t, X, coef);
+      if constexpr (IS_BWD || IS_FUSED) {
+        if constexpr (PREC == 0) { if (t + TPB < ntiles) load_tile(t + TPB); }
+        if constexpr (FROM_S) { if (t + 1 < ntiles) load_S(t + 1, xs); }
+        gemm2(T, coef);
+      }
+      if (t + TPB < ntiles) store_tile((t + TPB) % NBUF);
+      if ((t % TPB) == TPB - 1) __syncthreads();
+    };
+    for (int t = 0; t < ntiles; t += 2) {
+      tile_step(t);
+      if (t + 1 < ntiles) tile_step(t + 1);
+    }
+#else
     for (int t = 0; t < ntiles; ++t) {
       // FWD/RANK: prefetch the next tile at the top.  BWD/FUSED: registers are tight (rf + G + X + coef), so the
       // prefetch is issued just before GEMM2, whose 16*NB MFMAs (>= 1.7 us at D=128) cover its latency.
@@ -726,6 +769,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? ((MODE ==
       if (t + TPB < ntiles) store_tile((t + TPB) % NBUF);
       if ((t % TPB) == TPB - 1) __syncthreads();       // (uniform) tiles of the next group are complete, this group's buffers free
     }
+#endif
   }
 
   // ---- epilogue ----

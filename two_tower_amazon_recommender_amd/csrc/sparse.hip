@@ -39,6 +39,17 @@ struct ApplyArgs {
   int32_t* p_flag[kMaxSparseTables];   // [nblk]       arrival ticket of the deferred run whose head is in block j (0 between launches)
 };
 
+// TT_OPT_NT_STORES=1: the updated rows leave with nontemporal stores (A/B hook; a row is not read again before the next
+// step's lookup, which goes to other rows)
+#ifndef TT_OPT_NT_STORES
+#define TT_OPT_NT_STORES 0
+#endif
+#if TT_OPT_NT_STORES
+#define TT_ROW_STORE(ptr, v) __builtin_nontemporal_store((v), (ptr))
+#else
+#define TT_ROW_STORE(ptr, v) (*(ptr) = (v))
+#endif
+
 // the update of 4 elements of a row given its (already loaded) weights w and accumulator acc
 template <int OPT>
 __device__ __forceinline__ void update_store(f32x4* __restrict__ table, f32x4* __restrict__ accum, int64_t off, f32x4 w, f32x4 acc,
@@ -53,9 +64,9 @@ __device__ __forceinline__ void update_store(f32x4* __restrict__ table, f32x4* _
       const float den = sqrtf(__fadd_rn(acc[e], eps));
       w[e] = __fsub_rn(w[e], __fdiv_rn(__fmul_rn(lr, g[e]), den));
     }
-    accum[off] = acc;
+    TT_ROW_STORE(accum + off, acc);
   }
-  table[off] = w;
+  TT_ROW_STORE(table + off, w);
 }
 
 template <int OPT>
@@ -67,16 +78,111 @@ __device__ __forceinline__ void update_row(f32x4* __restrict__ table, f32x4* __r
   update_store<OPT>(table, accum, off, w, acc, g, lr, eps);
 }
 
+// Piece sums travel between lane groups of DIFFERENT workgroups inside one launch.  They are stored WRITE-THROUGH
+// (sc1: two 8-byte agent-scope relaxed stores per float4) and read back with sc1 loads behind an agent-scope acquire, so
+// the producer needs no release fence.  (r02 used plain stores + fence(release, agent) = `buffer_wbl2 sc1`, which writes
+// back EVERY dirty line of the XCD's L2 - in a kernel whose whole job is to dirty L2 with table rows.  One fence per piece
+// of a multi-piece run: ~1,600 of them at 1M uniform ids, ~100x more with power-law ids; the launch went from 350 to 690 us
+// (U) and 634 to 1,992 us (Z) against r01's two-launch form - VERDICT r02.  TT_SPARSE_RELEASE_FENCE=1 rebuilds that form
+// for the A/B in profiles/r03_sparse_apply_ab.jsonl.)
+#ifndef TT_SPARSE_RELEASE_FENCE
+#define TT_SPARSE_RELEASE_FENCE 0
+#endif
+__device__ __forceinline__ void store_piece(f32x4* p, const f32x4& v) {
+#if TT_SPARSE_RELEASE_FENCE
+  *p = v;
+#else
+  unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
+  const unsigned long long lo = ((unsigned long long)__float_as_uint(v[1]) << 32) | __float_as_uint(v[0]);
+  const unsigned long long hi = ((unsigned long long)__float_as_uint(v[3]) << 32) | __float_as_uint(v[2]);
+  __hip_atomic_store(q, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // global_store_dwordx2 ... sc1
+  __hip_atomic_store(q + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ f32x4 load_piece(const f32x4* p) {
+#if TT_SPARSE_RELEASE_FENCE
+  return *p;
+#else
+  unsigned long long* q = reinterpret_cast<unsigned long long*>(const_cast<f32x4*>(p));
+  const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // global_load_dwordx2 ... sc1
+  const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return f32x4{__uint_as_float((uint32_t)lo), __uint_as_float((uint32_t)(lo >> 32)), __uint_as_float((uint32_t)hi),
+               __uint_as_float((uint32_t)(hi >> 32))};
+#endif
+}
+
+// A piece of a run that spans several 64-slot blocks (rare): find the run's extent, publish, take a ticket; the last
+// arriver adds the pieces in index order and applies the update.  (TT_SPARSE_TAIL_NOINLINE=1 keeps it out of line - an
+// A/B hook: as a real call it costs the callers 32-76 bytes of scratch for the registers saved around it.)
+#ifndef TT_SPARSE_TAIL_NOINLINE
+#define TT_SPARSE_TAIL_NOINLINE 0
+#endif
+#if TT_SPARSE_TAIL_NOINLINE
+#define TT_TAIL_ATTR __attribute__((noinline))
+#else
+#define TT_TAIL_ATTR __forceinline__
+#endif
+template <int OPT>
+__device__ TT_TAIL_ATTR void finish_run_piece(f32x4* __restrict__ table, f32x4* __restrict__ accum, const int64_t* __restrict__ sid,
+                                              const f32x4* P, const f32x4* S, int32_t* p_flag, const int64_t k, const int64_t e,
+                                              const int64_t pend, const int64_t id, const bool run_head, const bool continues,
+                                              const int dim4, const int lpr_log2, const int64_t n_ids, const float lr, const float eps) {
+  const int lpr = 1 << lpr_log2;
+  const int l = threadIdx.x & (lpr - 1);
+  int64_t first = k;                              // first slot of the run (lower bound of id in the sorted ids)
+  if (!run_head) {
+    int64_t lo = 0, hi = k;                       // sid[k] == id, and the slot before a boundary piece holds id too
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (sid[mid] < id) lo = mid + 1; else hi = mid;
+    }
+    first = lo;
+  }
+  int64_t last = e;                               // one past the last slot of the run
+  if (continues) {
+    int64_t lo = pend + 1, hi = n_ids;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (sid[mid] <= id) lo = mid + 1; else hi = mid;      // sentinel / valid ids ascend; nothing sorts below 0
+    }
+    last = lo;
+  }
+  const int64_t jh = first / kPiece, jl = (last - 1) / kPiece;
+  const int npieces = (int)(jl - jh + 1);
+  // publish: this lane group's write-through stores (all in this wave) have left the CU before the ticket is drawn
+#if TT_SPARSE_RELEASE_FENCE
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  int ticket = 0;
+  if (l == 0) ticket = atomicAdd(&p_flag[jh], 1);
+  ticket = __shfl(ticket, (int)(threadIdx.x & 63u & ~(unsigned)(lpr - 1)));
+  if (ticket != npieces - 1) return;
+  // last arriver: every piece of the run is published
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (l == 0) p_flag[jh] = 0;                     // leave the workspace zeroed for the next call
+  for (int c = l; c < dim4; c += lpr) {
+    f32x4 g = load_piece(P + jh * dim4 + c);
+    for (int64_t m = jh + 1; m <= jl; ++m) {
+      const f32x4 s = load_piece(S + m * dim4 + c);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) g[q] = __fadd_rn(g[q], s[q]);
+    }
+    update_row<OPT>(table, accum, id * dim4 + c, g, lr, eps);
+  }
+}
+
 // Summation order (the oracle's dedup_sum restates it): a run of equal ids occupies consecutive sorted slots; it is cut
 // into PIECES at global multiples of 64 slots; every piece is summed sequentially in slot (= ascending position) order,
 // then the pieces are added in order.  A run inside one 64-slot block — the common case — is a plain sequential sum
 // (bit-equal to np.add.at).  A hot id repeated thousands of times is summed by many lane groups in parallel.
 //
-// A run that crosses a block boundary is finished INSIDE this launch: every piece stores its sum (p_sum / s_sum of its
-// block), releases it (agent scope) and takes a ticket on the run's counter p_flag[head block]; the piece that draws
-// the last ticket acquires, adds the pieces in INDEX order (never arrival order: bitwise reproducible) and applies the
-// update.  A block holds at most one run head that continues past its end, so the counter is unambiguous; the last
-// arriver leaves it at 0 for the next launch.
+// A run that crosses a block boundary is finished INSIDE this launch: every piece stores its sum write-through (p_sum /
+// s_sum of its block), drains its stores (s_waitcnt vmcnt(0)) and takes a ticket on the run's counter p_flag[head block];
+// the piece that draws the last ticket acquires, adds the pieces in INDEX order (never arrival order: bitwise
+// reproducible) and applies the update.  A block holds at most one run head that continues past its end, so the counter is
+// unambiguous; the last arriver leaves it at 0 for the next launch.
 template <int OPT>
 __device__ __forceinline__ void sparse_apply_body(const ApplyArgs& a, const int t, const int64_t bx, int dim4, int lpr_log2,
                                                   int64_t n_ids, float lr, float eps) {
@@ -136,56 +242,14 @@ __device__ __forceinline__ void sparse_apply_body(const ApplyArgs& a, const int 
     if (whole) {
       update_row<OPT>(table, accum, id * dim4 + c, g, lr, eps);           // whole run summed: fused update
     } else if (run_head) {
-      reinterpret_cast<f32x4*>(a.p_sum[t])[blk * dim4 + c] = g;           // first piece of a long run
+      store_piece(reinterpret_cast<f32x4*>(a.p_sum[t]) + blk * dim4 + c, g);   // first piece of a long run
     } else {
-      reinterpret_cast<f32x4*>(a.s_sum[t])[blk * dim4 + c] = g;           // later piece (starts at slot 64*blk)
+      store_piece(reinterpret_cast<f32x4*>(a.s_sum[t]) + blk * dim4 + c, g);   // later piece (starts at slot 64*blk)
     }
   }
   if (whole) return;
-
-  // ---- a piece of a run that spans several blocks: find the run's extent, publish, take a ticket ----
-  int64_t first = k;                              // first slot of the run (lower bound of id in the sorted ids)
-  if (!run_head) {
-    int64_t lo = 0, hi = k;                       // sid[k] == id, and the slot before a boundary piece holds id too
-    while (lo < hi) {
-      const int64_t mid = (lo + hi) >> 1;
-      if (sid[mid] < id) lo = mid + 1; else hi = mid;
-    }
-    first = lo;
-  }
-  int64_t last = e;                               // one past the last slot of the run
-  if (continues) {
-    int64_t lo = pend + 1, hi = n_ids;
-    while (lo < hi) {
-      const int64_t mid = (lo + hi) >> 1;
-      if (sid[mid] <= id) lo = mid + 1; else hi = mid;      // sentinel / valid ids ascend; nothing sorts below 0
-    }
-    last = lo;
-  }
-  const int64_t jh = first / kPiece, jl = (last - 1) / kPiece;
-  const int npieces = (int)(jl - jh + 1);
-  // release: this lane group's stores (all in this wave) are written back before the ticket is drawn
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  int ticket = 0;
-  if (l == 0) ticket = atomicAdd(&a.p_flag[t][jh], 1);
-  ticket = __shfl(ticket, (int)(threadIdx.x & 63u & ~(unsigned)(lpr - 1)));
-  if (ticket != npieces - 1) return;
-  // last arriver: every piece of the run is published
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (l == 0) a.p_flag[t][jh] = 0;                // leave the workspace zeroed for the next call
-  const f32x4* P = reinterpret_cast<const f32x4*>(a.p_sum[t]);
-  const f32x4* S = reinterpret_cast<const f32x4*>(a.s_sum[t]);
-  for (int c = l; c < dim4; c += lpr) {
-    f32x4 g = P[jh * dim4 + c];
-    for (int64_t m = jh + 1; m <= jl; ++m) {
-      const f32x4 s = S[m * dim4 + c];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) g[e] = __fadd_rn(g[e], s[e]);
-    }
-    update_row<OPT>(table, accum, id * dim4 + c, g, lr, eps);
-  }
+  finish_run_piece<OPT>(table, accum, sid, reinterpret_cast<const f32x4*>(a.p_sum[t]), reinterpret_cast<const f32x4*>(a.s_sum[t]),
+                        a.p_flag[t], k, e, pend, id, run_head, continues, dim4, lpr_log2, n_ids, lr, eps);
 }
 
 template <int OPT>
@@ -223,10 +287,140 @@ struct FusedTables {
   int32_t seg_first[TT_MAX_DENSE_SEGS + 1];   // flat index (from first[n_tables]) of segment s's block 0
 };
 
-template <int OPT, int DBITS>
-__device__ __forceinline__ void apply_from_lds(const ApplyArgs& a, const int t, const uint32_t* K, const uint16_t* P, const uint32_t m,
-                                               const uint32_t offset, const uint32_t base_key, int dim4, int lpr_log2, float lr,
-                                               float eps, int* s_multi) {
+// Rows requested per lane group before any of them is finished (one memory round trip for the usual 2-3 slots per group)
+constexpr int kRowsAhead = 4;
+struct RowsAhead {
+  f32x4 g[kRowsAhead], w[kRowsAhead], a[kRowsAhead];   // first float4 chunk (c = l) of: the pair's gradient row, its table row, its accumulator row
+};
+
+// The rank-by-counting path: called when the workgroup's unordered (key, position) list is complete, BEFORE it is ranked.
+// Lane group grp requests the gradient row and the table (+ accumulator) row of the pairs grp, grp + ngroups, ... - their
+// addresses need the key and the batch position only, not the rank -, so the rows' HBM round trip runs under the ranking
+// (~2 us of LDS work) instead of after it.  (r02: requested after the ranking; per-workgroup stamps 5.5 -> 9.3 us for the
+// apply phase, of which one HBM round trip.)
+template <int OPT>
+__device__ __forceinline__ void request_rows(const ApplyArgs& a, const int t, const uint32_t* K, const uint16_t* P, const uint32_t m,
+                                             const uint32_t base_key, int dim4, int lpr_log2, RowsAhead& ra) {
+  const f32x4* __restrict__ table = reinterpret_cast<const f32x4*>(a.table[t]);
+  const f32x4* __restrict__ accum = reinterpret_cast<const f32x4*>(a.accum[t]);
+  const f32x4* __restrict__ grads = reinterpret_cast<const f32x4*>(a.grads[t]);
+  const int64_t rows = a.rows[t];
+  const uint32_t ngroups = 1024u >> lpr_log2;
+  const uint32_t grp = threadIdx.x >> lpr_log2;
+  const int l = threadIdx.x & ((1 << lpr_log2) - 1);
+#pragma unroll
+  for (int r = 0; r < kRowsAhead; ++r) {
+    const uint32_t i = grp + (uint32_t)r * ngroups;
+    // (no zero-initialisation: only slots that were requested are consumed.  With one, hipcc merged "zero or loaded" through
+    // a register copy placed right behind the load - an `s_waitcnt vmcnt` per slot inside this function, i.e. one HBM round
+    // trip paid HERE: 2.1 us between the stamps around it instead of ~0.2, r03 call 3.)
+    if (i < m && l < dim4) {
+      const int64_t id = (int64_t)base_key + K[i];
+      if (id < rows) {                                  // (the out-of-range sentinel has no row)
+        ra.g[r] = grads[(int64_t)P[i] * dim4 + l];
+        ra.w[r] = table[id * dim4 + l];
+        if constexpr (OPT != TT_OPT_SGD) ra.a[r] = accum[id * dim4 + l];
+      }
+    }
+  }
+}
+
+// The usual row range WITHOUT the ranking on the critical path (r03).  Which sorted slot a pair lands in matters only
+// for runs of three or more equal ids (the order and the 64-slot pieces of their sums); a row touched ONCE is updated from
+// its one gradient row whatever its slot, and for a row touched TWICE the sum is fadd(first, second) for either piece cut
+// (one piece: g0 then += g1; two pieces: P = g0, S = g1, P + S).  So each lane group, for each of its <= kRowsAhead pairs of
+// the UNORDERED list: requests the pair's gradient row and table (+ accumulator) row; while they are in flight, compares the
+// pair's key with the whole list (lane l takes entries l, l + lpr, ...; one ballot per compare, the group's bits counted)
+// to get n_eq = entries with this key, n_before = those at a smaller batch position, and the index of another entry with
+// the key; then
+//   n_eq == 1                      update the row from the requested registers
+//   n_eq == 2, n_before == 0       fetch the partner's gradient row (L2: its own lane group has just requested it), add, update
+//   n_eq == 2, n_before == 1       nothing (the partner does it)
+//   n_eq >= 3                      left to the ranked path: bit r of the return value, *s_slow = 1
+// No workgroup barrier, no LDS write-back, no dependence on the ranks: a workgroup without a triple (every workgroup, for
+// uniform ids over >= 1M rows) is done when its rows have landed.  Needs dim4 <= lpr <= 32 and m <= kRowsAhead * ngroups.
+template <int OPT>
+__device__ __forceinline__ uint32_t fast_apply(const ApplyArgs& a, const int t, const uint32_t* K, const uint16_t* P, const uint32_t m,
+                                               const uint32_t base_key, int dim4, int lpr_log2, float lr, float eps, int* s_slow) {
+  f32x4* __restrict__ table = reinterpret_cast<f32x4*>(a.table[t]);
+  f32x4* __restrict__ accum = reinterpret_cast<f32x4*>(a.accum[t]);
+  const f32x4* __restrict__ grads = reinterpret_cast<const f32x4*>(a.grads[t]);
+  const int64_t rows = a.rows[t];
+  const uint32_t lpr = 1u << lpr_log2;
+  const uint32_t ngroups = 1024u >> lpr_log2;
+  const uint32_t grp = threadIdx.x >> lpr_log2;
+  const uint32_t l = threadIdx.x & (lpr - 1u);
+  const uint32_t gshift = (threadIdx.x & 63u) & ~(lpr - 1u);           // first lane of this lane group within its wave
+  const uint32_t gmask = lpr >= 32u ? 0xffffffffu : ((1u << lpr) - 1u);
+  constexpr int RP = kRowsAhead;
+  uint32_t key[RP], pos[RP], n_eq[RP], n_bf[RP], jo[RP];
+  bool live[RP];
+  f32x4 g[RP], w[RP], ac[RP];
+  // Every lane ALWAYS loads (no branch around the requests: with one, hipcc merged "loaded or not" through register copies
+  // placed right behind the loads, i.e. an `s_waitcnt vmcnt` - a whole HBM round trip - inside the request phase).  A lane
+  // group without a pair r (i >= m), a pair with the out-of-range sentinel and the lanes past the row's end re-read pair
+  // 0's rows / the row's last chunk: L1 hits, discarded.
+  const uint32_t lc = l < (uint32_t)dim4 ? l : (uint32_t)dim4 - 1u;
+#pragma unroll
+  for (int r = 0; r < RP; ++r) {
+    const uint32_t i = grp + (uint32_t)r * ngroups;
+    const uint32_t ic = i < m ? i : 0u;
+    const uint32_t kk = K[ic];
+    pos[r] = P[ic];
+    const int64_t id = (int64_t)base_key + kk;
+    live[r] = i < m && id < rows;                                        // (the out-of-range sentinel has no row)
+    key[r] = live[r] ? kk : 0xffffffffu;                                 // (no list entry has the all-ones local key)
+    n_eq[r] = 0u; n_bf[r] = 0u; jo[r] = 0u;
+    const int64_t off = (id < rows ? id : rows - 1) * dim4 + lc;
+    g[r] = grads[(int64_t)pos[r] * dim4 + lc];
+    w[r] = table[off];
+    if constexpr (OPT != TT_OPT_SGD) ac[r] = accum[off];
+  }
+  // ---- the pair's key against the whole list, under the row loads ----
+  for (uint32_t j0 = 0u; j0 < m; j0 += lpr) {
+    const uint32_t j = j0 + l;
+    const uint32_t kj = j < m ? K[j] : 0xfffffffeu;
+    const uint32_t pj = j < m ? (uint32_t)P[j] : 0u;
+#pragma unroll
+    for (int r = 0; r < RP; ++r) {
+      if (!__builtin_amdgcn_ballot_w64(live[r])) continue;               // (wave-uniform: no lane group of this wave has a pair r)
+      const bool eq = kj == key[r];
+      const uint32_t eb = (uint32_t)(__builtin_amdgcn_ballot_w64(eq) >> gshift) & gmask;
+      const uint32_t bb = (uint32_t)(__builtin_amdgcn_ballot_w64(eq && pj < pos[r]) >> gshift) & gmask;
+      n_eq[r] += (uint32_t)__popc(eb);
+      n_bf[r] += (uint32_t)__popc(bb);
+      const uint32_t self = grp + (uint32_t)r * ngroups - j0;            // this pair's own bit, when it is in this slice
+      const uint32_t others = self < lpr ? (eb & ~(1u << self)) : eb;
+      if (others != 0u) jo[r] = j0 + (uint32_t)__ffs((int)others) - 1u;
+    }
+  }
+  // two loops: first every pair's gradient is completed (a partner row fetched and added where there is one), then all the
+  // rows are stored - a store issued between two pairs would sit in front of the next pair's `s_waitcnt vmcnt`
+  uint32_t slow = 0u, put = 0u;
+#pragma unroll
+  for (int r = 0; r < RP; ++r) {
+    if (!live[r]) continue;
+    if (n_eq[r] >= 3u) { slow |= 1u << r; continue; }
+    if (n_eq[r] == 2u && n_bf[r] != 0u) continue;                         // second of a pair: its partner sums and updates
+    put |= 1u << r;
+    if (n_eq[r] == 2u && l < (uint32_t)dim4) {
+      const f32x4 g2 = grads[(int64_t)P[jo[r]] * dim4 + l];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) g[r][q] = __fadd_rn(g[r][q], g2[q]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RP; ++r)
+    if (((put >> r) & 1u) && l < (uint32_t)dim4)
+      update_store<OPT>(table, accum, ((int64_t)base_key + key[r]) * dim4 + l, w[r], ac[r], g[r], lr, eps);
+  if (slow != 0u && l == 0u) *s_slow = 1;
+  return slow;
+}
+
+template <int OPT, int DBITS, bool BY_LIST, bool USE_RA>
+__device__ __forceinline__ void apply_from_lds(const ApplyArgs& a, const int t, const uint32_t* K, const uint16_t* P, const uint16_t* R,
+                                               const uint32_t m, const uint32_t offset, const uint32_t base_key, int dim4, int lpr_log2,
+                                               float lr, float eps, int* s_multi, const RowsAhead& ra, const uint32_t todo) {
   f32x4* __restrict__ table = reinterpret_cast<f32x4*>(a.table[t]);
   f32x4* __restrict__ accum = reinterpret_cast<f32x4*>(a.accum[t]);
   const f32x4* __restrict__ grads = reinterpret_cast<const f32x4*>(a.grads[t]);
@@ -252,9 +446,10 @@ __device__ __forceinline__ void apply_from_lds(const ApplyArgs& a, const int t, 
     return true;
   };
 
-  // ---- phase A: every piece is summed; whole runs (the usual case) are applied at once.  A lane group owns the slots
-  // grp, grp + ngroups, ...: the first gradient row AND the table (accumulator) row of its first RP slots are requested
-  // before any of them is finished (one memory round trip for the usual 2-3 slots per group instead of one per slot). ----
+  // ---- phase A: every piece is summed; whole runs (the usual case) are applied at once.  The first gradient row AND the
+  // table (accumulator) row of a lane group's first kRowsAhead slots have been requested together: either per unordered
+  // pair before the ranking (BY_LIST: the pair i of the list sits in sorted slot R[i]) or, for a radix-sorted hot range,
+  // here per sorted slot grp, grp + ngroups, ... ----
   bool multi = false;
   auto finish = [&](uint32_t i, uint32_t e, bool head, bool cont, bool pre, const f32x4& g0, const f32x4& w0, const f32x4& a0) {
     const int64_t id = (int64_t)base_key + K[i];
@@ -291,8 +486,42 @@ __device__ __forceinline__ void apply_from_lds(const ApplyArgs& a, const int t, 
     }
     multi = multi || !whole;
   };
-  constexpr int RP = 4;
-  {
+  constexpr int RP = kRowsAhead;
+  if constexpr (BY_LIST) {
+    // every sorted slot is the rank of exactly one pair of the list: the lane group that requested pair i's rows finishes
+    // slot R[i].  The usual slot - a run of ONE id, the row fits the lane group - is updated straight from the requested
+    // registers; anything else (duplicates, rows wider than the lane group, pairs beyond kRowsAhead) takes the general walk,
+    // which loads for itself (one instance of it: the requested registers are dead by then).
+    const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+    uint32_t slow = todo;                  // !USE_RA: after fast_apply - only the pairs it left (bit r of todo), nothing requested ahead
+    if constexpr (USE_RA) {
+      slow = 0u;
+#pragma unroll
+      for (int r = 0; r < RP; ++r) {
+        const uint32_t i = grp + (uint32_t)r * ngroups;
+        if (i < m) {
+          const uint32_t sl = R[i];
+          uint32_t e = 0u;
+          bool head = false, cont = false;
+          if (piece(sl, e, head, cont)) {
+            if (head && !cont && e == sl + 1u && dim4 <= lpr) {
+              if (l < dim4) update_store<OPT>(table, accum, ((int64_t)base_key + K[sl]) * dim4 + l, ra.w[r], ra.a[r], ra.g[r], lr, eps);
+            } else {
+              slow |= 1u << r;
+            }
+          }
+        }
+      }
+    }
+    for (uint32_t i = grp; i < m; i += ngroups) {
+      const uint32_t r = (i - grp) / ngroups;
+      if (r < (uint32_t)RP && !((slow >> r) & 1u)) continue;
+      const uint32_t sl = R[i];
+      uint32_t e = 0u;
+      bool head = false, cont = false;
+      if (piece(sl, e, head, cont)) finish(sl, e, head, cont, false, z, z, z);
+    }
+  } else {
     f32x4 g0[RP], w0[RP], a0[RP];
     uint32_t ee[RP];
     bool act[RP], hd[RP], ct[RP];
@@ -314,12 +543,12 @@ __device__ __forceinline__ void apply_from_lds(const ApplyArgs& a, const int t, 
 #pragma unroll
     for (int r = 0; r < RP; ++r)
       if (act[r]) finish(grp + (uint32_t)r * ngroups, ee[r], hd[r], ct[r], true, g0[r], w0[r], a0[r]);
-  }
-  for (uint32_t i = grp + RP * ngroups; i < m; i += ngroups) {     // (a hot range: more than RP slots per lane group)
-    uint32_t e = 0u;
-    bool head = false, cont = false;
-    const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (piece(i, e, head, cont)) finish(i, e, head, cont, false, z, z, z);
+    for (uint32_t i = grp + RP * ngroups; i < m; i += ngroups) {     // (a hot range: more than RP slots per lane group)
+      uint32_t e = 0u;
+      bool head = false, cont = false;
+      const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (piece(i, e, head, cont)) finish(i, e, head, cont, false, z, z, z);
+    }
   }
   if (multi && l == 0) *s_multi = 1;
   // ---- phase B (only when some run of this workgroup has several pieces): the run's head adds the pieces in index order ----
@@ -334,6 +563,9 @@ __device__ __forceinline__ void apply_from_lds(const ApplyArgs& a, const int t, 
     const uint32_t key = K[h];
     uint32_t last = he;                                       // one past the last slot of the run
     while (last < m && K[last] == key) ++last;
+    // after fast_apply only runs of three or more ids came through phase A: a PAIR that straddles a 64-slot boundary was
+    // finished there and has no piece sums in the workspace
+    if constexpr (BY_LIST && !USE_RA) { if (last - h < 3u) continue; }
     const int64_t id = (int64_t)base_key + key;
     const int64_t jh = (int64_t)(offset + h) / kPiece, jl = (int64_t)(offset + last - 1u) / kPiece;
     const f32x4* Ps = reinterpret_cast<const f32x4*>(a.p_sum[t]);
@@ -354,7 +586,7 @@ template <int OPT, int DBITS, int JMAX>
 __global__ __launch_bounds__(1024) void optimizer_ids_kernel(ApplyArgs a, FusedTables ft, int n_tables, int dim4, int lpr_log2,
                                                               tt::SegTable tbl, int dense_blocks, float lr, float eps) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  __shared__ int s_multi;
+  __shared__ int s_multi, s_slow;
   // flat grid: exactly the dense blocks each segment needs FIRST (a sorting workgroup fills a CU - 16 waves at up to 128
   // VGPRs - so dense blocks dispatched behind 256 of them would only start when those retire: r02 stamps, 10 us late),
   // then the sorting workgroups of table 0, 1, (2); the host keeps the total at one workgroup per CU
@@ -363,12 +595,39 @@ __global__ __launch_bounds__(1024) void optimizer_ids_kernel(ApplyArgs a, FusedT
     int ti = 0;
     while (ti + 1 < n_tables && b >= ft.first[ti + 1]) ++ti;
     const tt::PartTable& t = ft.part[ti];
-    if (threadIdx.x == 0) s_multi = 0;
+    if (threadIdx.x == 0) { s_multi = 0; s_slow = 0; }
     uint32_t offset, base_key;
-    const uint32_t m = tt::part_sort_body<DBITS, JMAX, false>(t, b - ft.first[ti], ft.cap, smem, offset, base_key);
+    const int g = b - ft.first[ti];
+    tt::PartScan<JMAX> sc;
+    const uint32_t m = tt::part_scan_append<DBITS, JMAX>(t, g, ft.cap, smem, sc, offset, base_key);
     if (m == 0u) return;
-    apply_from_lds<OPT, DBITS>(a, ti, tt::part_keys(smem), tt::part_poss<DBITS>(smem, ft.cap), m, offset, base_key, dim4,
-                               lpr_log2, lr, eps, &s_multi);
+    const uint32_t* K = tt::part_keys(smem);
+    const uint16_t* P = tt::part_poss<DBITS>(smem, ft.cap);
+    const RowsAhead none{};
+    if (m <= tt::kPartRankMax) {
+      if (lpr_log2 <= 5 && dim4 <= (1 << lpr_log2) && m <= (uint32_t)kRowsAhead * (1024u >> lpr_log2)) {
+        // the usual row range: rows touched once or twice are finished without ranks (fast_apply); the ranking runs only
+        // if some id of the range occurs three times or more, and then only those pairs go through it
+        const uint32_t todo = fast_apply<OPT>(a, ti, K, P, m, base_key, dim4, lpr_log2, lr, eps, &s_slow);
+        SSTAMP(3);
+        tt::lds_barrier();                 // s_slow is final; every lane group has read the unordered list
+        if (s_slow == 0) { SSTAMP(5); SSTAMP(6); return; }
+        tt::part_rank_small<DBITS, false>(t, ft.cap, smem, m, offset, base_key);
+        apply_from_lds<OPT, DBITS, true, false>(a, ti, K, P, tt::part_ranks(smem, ft.cap), m, offset, base_key, dim4, lpr_log2, lr, eps,
+                                                &s_multi, none, todo);
+      } else {
+        // a longer list (or rows wider than a lane group): rows requested per unordered pair, THEN the ranking
+        RowsAhead ra;
+        request_rows<OPT>(a, ti, K, P, m, base_key, dim4, lpr_log2, ra);
+        SSTAMP(3);
+        tt::part_rank_small<DBITS, false>(t, ft.cap, smem, m, offset, base_key);
+        apply_from_lds<OPT, DBITS, true, true>(a, ti, K, P, tt::part_ranks(smem, ft.cap), m, offset, base_key, dim4, lpr_log2, lr, eps,
+                                               &s_multi, ra, 0u);
+      }
+    } else {
+      tt::part_sort_hot<DBITS, JMAX, false>(t, g, ft.cap, smem, sc, m, offset, base_key);
+      apply_from_lds<OPT, DBITS, false, false>(a, ti, K, P, nullptr, m, offset, base_key, dim4, lpr_log2, lr, eps, &s_multi, none, 0u);
+    }
     SSTAMP(6);
   } else {
     const int d = (int)blockIdx.x;
