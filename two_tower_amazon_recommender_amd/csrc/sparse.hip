@@ -39,8 +39,9 @@ struct ApplyArgs {
   int32_t* p_flag[kMaxSparseTables];   // [nblk]       arrival ticket of the deferred run whose head is in block j (0 between launches)
 };
 
-// TT_OPT_NT_STORES=1: the updated rows leave with nontemporal stores (A/B hook; a row is not read again before the next
-// step's lookup, which goes to other rows)
+// TT_OPT_NT_STORES=1: the updated rows leave with nontemporal stores (A/B hook).  Measured on one box: the cfg3 optimizer
+// launch 15.1 -> 14.8 us, but the large-list kernel over 1M ids 351 -> 370 us (SGD/U), 512 -> 544 us (Adagrad/U), 535 -> 546
+// and 642 -> 661 us (Z): off.
 #ifndef TT_OPT_NT_STORES
 #define TT_OPT_NT_STORES 0
 #endif
@@ -394,17 +395,29 @@ __device__ __forceinline__ uint32_t fast_apply(const ApplyArgs& a, const int t, 
       if (others != 0u) jo[r] = j0 + (uint32_t)__ffs((int)others) - 1u;
     }
   }
-  // two loops: first every pair's gradient is completed (a partner row fetched and added where there is one), then all the
-  // rows are stored - a store issued between two pairs would sit in front of the next pair's `s_waitcnt vmcnt`
+  // What each pair needs is known now, before any row has landed: the verdict on the ranked path (s_slow) is published and
+  // the workgroup barrier taken HERE, after the evenly long compare loop - not behind the rows' HBM latency, where the
+  // barrier would also cost the spread between the first and the last wave's data (1.3 us between the stamps, r03 call 7).
+  // After it a wave only waits for its own rows, stores and - unless some id of the range occurs three times - leaves.
   uint32_t slow = 0u, put = 0u;
+  uint32_t ppos[RP];                                                      // batch position of a pair's partner
 #pragma unroll
   for (int r = 0; r < RP; ++r) {
+    ppos[r] = 0u;
     if (!live[r]) continue;
     if (n_eq[r] >= 3u) { slow |= 1u << r; continue; }
     if (n_eq[r] == 2u && n_bf[r] != 0u) continue;                         // second of a pair: its partner sums and updates
     put |= 1u << r;
-    if (n_eq[r] == 2u && l < (uint32_t)dim4) {
-      const f32x4 g2 = grads[(int64_t)P[jo[r]] * dim4 + l];
+    if (n_eq[r] == 2u) ppos[r] = P[jo[r]];                                // (the list is read for the last time)
+  }
+  if (slow != 0u && l == 0u) *s_slow = 1;
+  tt::lds_barrier();
+  // two loops: first every pair's gradient is completed (a partner row fetched and added where there is one), then all the
+  // rows are stored - a store issued between two pairs would sit in front of the next pair's `s_waitcnt vmcnt`
+#pragma unroll
+  for (int r = 0; r < RP; ++r) {
+    if (((put >> r) & 1u) && n_eq[r] == 2u && l < (uint32_t)dim4) {
+      const f32x4 g2 = grads[(int64_t)ppos[r] * dim4 + l];
 #pragma unroll
       for (int q = 0; q < 4; ++q) g[r][q] = __fadd_rn(g[r][q], g2[q]);
     }
@@ -413,7 +426,6 @@ __device__ __forceinline__ uint32_t fast_apply(const ApplyArgs& a, const int t, 
   for (int r = 0; r < RP; ++r)
     if (((put >> r) & 1u) && l < (uint32_t)dim4)
       update_store<OPT>(table, accum, ((int64_t)base_key + key[r]) * dim4 + l, w[r], ac[r], g[r], lr, eps);
-  if (slow != 0u && l == 0u) *s_slow = 1;
   return slow;
 }
 
@@ -609,8 +621,7 @@ __global__ __launch_bounds__(1024) void optimizer_ids_kernel(ApplyArgs a, FusedT
         // the usual row range: rows touched once or twice are finished without ranks (fast_apply); the ranking runs only
         // if some id of the range occurs three times or more, and then only those pairs go through it
         const uint32_t todo = fast_apply<OPT>(a, ti, K, P, m, base_key, dim4, lpr_log2, lr, eps, &s_slow);
-        SSTAMP(3);
-        tt::lds_barrier();                 // s_slow is final; every lane group has read the unordered list
+        SSTAMP(3);                         // (fast_apply holds the workgroup barrier: s_slow is final, the unordered list read)
         if (s_slow == 0) { SSTAMP(5); SSTAMP(6); return; }
         tt::part_rank_small<DBITS, false>(t, ft.cap, smem, m, offset, base_key);
         apply_from_lds<OPT, DBITS, true, false>(a, ti, K, P, tt::part_ranks(smem, ft.cap), m, offset, base_key, dim4, lpr_log2, lr, eps,
