@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TT_ABI_VERSION 7
+#define TT_ABI_VERSION 8
 
 enum {
   TT_OK = 0,
@@ -323,6 +323,46 @@ int tt_optimizer_step_ids_f32(int32_t opt, const tt_sparse_table_ids* tables, in
                               const tt_dense_seg* segs, int32_t n_segs, float lr, float eps, tt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * The WHOLE train step as one call (ABI v8): what `train-model` (pyproject.toml:67, src/training/train.py - declared,
+ * never written) would run per batch.  A HOST struct of pointers describes the step once - every buffer is caller-owned
+ * and fixed from step to step; per step the caller only rewrites the id pointers, the dropout row counter and the optional
+ * per-pair inputs - and tt_train_step_f32 enqueues, on `stream`, exactly the launches the separate entry points would:
+ *   for each layer l:            tt_dense_fwd_batched_f32(fwd[l], 2, ...)       (layer 0 reads the embedding rows itself)
+ *   scorer + loss + dq, dc:      tt_retrieval_fwd_bwd_f32 / _bf16x3_f32         (q, c = fwd[n_layers-1][*].y; dq, dc = bwd[n_layers-1][*].dz)
+ *   for each layer l, last first: tt_dense_bwd_batched_f32(bwd[l], 2, ...)
+ *   optimizer:                   tt_optimizer_step_ids_f32(tables, segs)       (sort + duplicate sums + sparse update + dense update)
+ * Nine launches for two 2-layer towers; no other work, no allocation, no synchronisation.  It exists for the HOST side: a
+ * caller that reaches the library through an FFI (ctypes: ~7 us per call) pays that once per step instead of once per
+ * launch - cfg1 (B 256) is 9 launches of ~2 us of GPU work each.  Results are identical to the separate calls, bit for bit.
+ * Both towers must have the same layer shapes (the batched launches); batch <= 16384 (tt_optimizer_step_ids_f32) and
+ * <= 32768 with a fused lookup.                                                                                       */
+#define TT_MAX_TOWER_LAYERS 8
+typedef struct tt_train_step {
+  int64_t batch;                                   /* pairs per step = rows of every activation                    */
+  int32_t n_layers;                                /* Dense layers per tower                                       */
+  int32_t dims[TT_MAX_TOWER_LAYERS + 1];           /* embedding_dim, then the width of every layer                 */
+  tt_dense_fwd_args fwd[TT_MAX_TOWER_LAYERS][2];   /* [layer][0 = user tower, 1 = item tower]; hidden layers: ReLU */
+  tt_dense_bwd_args bwd[TT_MAX_TOWER_LAYERS][2];
+  float dropout_rate;                              /* configs/data_config.yaml:58; 0 = none                        */
+  uint64_t dropout_seed;
+  uint64_t dropout_row0;                           /* first global batch row of this step: layer l's counter offset = row0 * dims[l+1] */
+  int32_t scorer_precision;                        /* 0 = exact f32 products, 1 = bf16x3                           */
+  float inv_temperature;                           /* 1 / retrieval.temperature (configs/data_config.yaml:70)      */
+  const float* sample_weight;                      /* [batch] or NULL                                              */
+  const float* cand_prob;                          /* [batch] or NULL (candidate_sampling_probability)             */
+  const int64_t* cand_ids;                         /* [batch] or NULL (remove_accidental_hits)                     */
+  void* retrieval_ws; int64_t retrieval_ws_bytes;  /* tt_retrieval_workspace_bytes(batch, batch, dims[n_layers])   */
+  float* lse; float* per_row; float* loss;         /* [batch], [batch], [1]                                        */
+  int32_t opt;                                     /* TT_OPT_SGD / TT_OPT_ADAGRAD                                  */
+  int32_t n_tables;                                /* 2, or 3 with the hashed category table                       */
+  tt_sparse_table_ids tables[3];
+  int32_t n_segs;
+  tt_dense_seg segs[TT_MAX_DENSE_SEGS];
+  float lr, eps;
+} tt_train_step;
+int tt_train_step_f32(const tt_train_step* step, tt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * a3 + a4 — batched dot-product scorer fused with the in-batch sampled-softmax loss
  * (tfrs.tasks.Retrieval.call: matmul(q, c^T) / temperature, optional sampling-probability
  * correction and accidental-hit removal, CategoricalCrossentropy(from_logits=True,
@@ -340,7 +380,10 @@ int tt_optimizer_step_ids_f32(int32_t opt, const tt_sparse_table_ids* tables, in
  * hard_thr [nq] (may be NULL): per-query thresholds from tt_retrieval_hard_negative_thresholds_f32 — only the
  * positive and the negatives scoring at or above the threshold take part (tfrs num_hard_negatives).
  * Outputs: lse [nq], per_row [nq], loss [1]; dq [nq,dim], dc [nc,dim].
- * Workspace: tt_retrieval_workspace_bytes(nq, nc, dim) bytes, 256-byte aligned.          */
+ * Workspace: tt_retrieval_workspace_bytes(nq, nc, dim) bytes, 256-byte aligned.  For the fused training entries this
+ * INCLUDES the raw dot products of pass 1, ceil(nq/32) * ceil(nc/32) blocks of 4 KB = 4*nq*nc bytes (268 MB at 8192 x
+ * 8192, 4.3 GB at 32768 x 32768; ABI v5 and later - a workspace sized by an older library is refused with
+ * TT_ERR_WORKSPACE).  The bf16x3 entry at dim 256 recomputes instead and accepts tt_retrieval_fwd_workspace_bytes.    */
 int64_t tt_retrieval_workspace_bytes(int64_t nq, int64_t nc, int32_t dim);
 /* the part of it the forward-only (tt_retrieval_fwd_f32) and separate-backward (tt_retrieval_bwd_f32) entries need: no
  * [nq][nc] logit buffer (only the fused training entries keep the raw dot products between their two passes) */

@@ -349,6 +349,40 @@ def test_fused_launches_equal_the_separate_ones_bit_for_bit(dev, opt, variant, b
     assert torch.equal(a.user_table, c.user_table) and torch.equal(a.item_table, c.item_table) and torch.equal(a.dense_flat, c.dense_flat)
 
 
+@pytest.mark.parametrize("opt,buckets,precision", [("sgd", 0, "f32"), ("adagrad", 30, "f32"), ("sgd", 0, "bf16x3")])
+def test_composite_step_entry_equals_the_python_sequence_bit_for_bit(dev, opt, buckets, precision):
+    """tt_train_step_f32 (one C call per step: the nine launches enqueued in C) against the same launches issued one by one
+    from Python, with everything the step takes: dropout (the per-step counter), sample weights, sampling-probability
+    correction, accidental-hit ids, the hashed category table, Adagrad, the bf16x3 scorer."""
+    cfg = TwoTowerConfig(n_users=5000, n_items=3000, embedding_dim=64, tower_dims=[128, 128], temperature=0.1,
+                         l2_regularization=1e-6, learning_rate=0.01, optimizer=opt, batch_size=1024, dropout_rate=0.1,
+                         n_category_buckets=buckets, scorer_precision=precision)
+    a = TwoTowerTrainer(cfg, dev, seed=41)
+    b = TwoTowerTrainer(TwoTowerConfig(**cfg.__dict__), dev, seed=41)
+    b.use_composite = False
+    assert a.use_composite
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for step in range(4):
+        u, i = a.synthetic_batch(41, step, "Z")
+        extra = {"category_ids": a.synthetic_categories(41, step)} if buckets else {}
+        if step >= 1:
+            extra["sample_weight"] = (0.5 + torch.rand(1024, generator=g)).to(dev)
+        if step >= 2:
+            extra["candidate_sampling_probability"] = (0.001 + 0.3 * torch.rand(1024, generator=g)).to(dev)
+            extra["candidate_ids"] = i
+        la = a.step(u, i, **extra).clone()
+        lb = b.step(u, i, **extra).clone()
+        assert torch.equal(la, lb), step
+    assert a._cstep is not None and b._cstep is None
+    a.check_ids(); b.check_ids()
+    assert torch.equal(a.user_table, b.user_table) and torch.equal(a.item_table, b.item_table)
+    assert torch.equal(a.dense_flat, b.dense_flat) and torch.equal(a.per_row, b.per_row)
+    if buckets:
+        assert torch.equal(a.cat_table, b.cat_table)
+    if opt == "adagrad":
+        assert torch.equal(a.user_accum, b.user_accum) and torch.equal(a.dense_accum, b.dense_accum)
+
+
 @pytest.mark.parametrize("opt,variant", [("sgd", "U"), ("adagrad", "Z")])
 def test_sharded_trainer_world1_is_bit_identical_to_single_gpu_trainer(dev, opt, variant):
     """The row-sharded step (route / de-dup / exchange buffers / owner update) with one rank must reproduce the

@@ -15,12 +15,13 @@ import threading
 _PKG = pathlib.Path(__file__).resolve().parent
 # TT_LIB_PATH: load another build of the same C ABI (kernel A/B experiments); the product default is the in-tree library
 LIB_PATH = pathlib.Path(os.environ["TT_LIB_PATH"]) if os.environ.get("TT_LIB_PATH") else _PKG / "libtwotower_hip.so"
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 TT_OK, TT_ERR_INVALID_ARG, TT_ERR_LAUNCH, TT_ERR_UNSUPPORTED, TT_ERR_WORKSPACE = range(5)
 TT_OPT_SGD, TT_OPT_ADAGRAD = 0, 1
 TT_IDS_UNIFORM, TT_IDS_POWERLAW = 0, 1
 TT_MAX_DENSE_SEGS = 16
+TT_MAX_TOWER_LAYERS = 8
 
 
 class DenseLookup(C.Structure):
@@ -72,6 +73,21 @@ class DenseSeg(C.Structure):
     ]
 
 
+class TrainStep(C.Structure):
+    """Mirror of ``tt_train_step``: the whole train step behind one C call (``tt_train_step_f32``)."""
+    _fields_ = [
+        ("batch", C.c_int64), ("n_layers", C.c_int32), ("dims", C.c_int32 * (TT_MAX_TOWER_LAYERS + 1)),
+        ("fwd", (DenseFwdArgs * 2) * TT_MAX_TOWER_LAYERS), ("bwd", (DenseBwdArgs * 2) * TT_MAX_TOWER_LAYERS),
+        ("dropout_rate", C.c_float), ("dropout_seed", C.c_uint64), ("dropout_row0", C.c_uint64),
+        ("scorer_precision", C.c_int32), ("inv_temperature", C.c_float),
+        ("sample_weight", C.c_void_p), ("cand_prob", C.c_void_p), ("cand_ids", C.c_void_p),
+        ("retrieval_ws", C.c_void_p), ("retrieval_ws_bytes", C.c_int64),
+        ("lse", C.c_void_p), ("per_row", C.c_void_p), ("loss", C.c_void_p),
+        ("opt", C.c_int32), ("n_tables", C.c_int32), ("tables", SparseTableIds * 3),
+        ("n_segs", C.c_int32), ("segs", DenseSeg * TT_MAX_DENSE_SEGS), ("lr", C.c_float), ("eps", C.c_float),
+    ]
+
+
 _p, _i64, _i32, _u64, _f = C.c_void_p, C.c_int64, C.c_int32, C.c_uint64, C.c_float
 
 # name -> (restype, argtypes); exactly the declarations of include/twotower_hip.h
@@ -111,6 +127,7 @@ SIGNATURES = {
     "tt_dense_update_f32": (C.c_int, [C.POINTER(DenseSeg), _i32, _i32, _i32, _f, _f, _p]),
     "tt_optimizer_step_f32": (C.c_int, [_i32, C.POINTER(SparseTable), _i32, _i32, _i64, C.POINTER(DenseSeg), _i32, _f, _f, _p]),
     "tt_optimizer_step_ids_f32": (C.c_int, [_i32, C.POINTER(SparseTableIds), _i32, _i32, _i64, C.POINTER(DenseSeg), _i32, _f, _f, _p]),
+    "tt_train_step_f32": (C.c_int, [C.POINTER(TrainStep), _p]),
     "tt_retrieval_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "tt_retrieval_fwd_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "tt_retrieval_rank_workspace_bytes": (_i64, [_i64, _i64, _i32]),

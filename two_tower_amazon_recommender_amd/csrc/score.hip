@@ -1380,7 +1380,8 @@ static int retrieval_fwd_bwd(int prec, const float* q, const float* c, int64_t n
                              const float* cand_prob, const int64_t* cand_ids, const float* hard_thr,
                              float grad_scale, void* workspace, int64_t workspace_bytes, float* lse,
                              float* per_row, float* loss, float* dq, float* dc, tt_stream_t stream_) {
-  int rc = check_common("tt_retrieval_fwd_bwd_f32", q, c, nq, nc, dim, diag_offset, workspace, workspace_bytes, true);
+  // the dot-product buffer is part of the workspace only for the forms that use it: exact f32, and bf16x3 at dim 128
+  int rc = check_common("tt_retrieval_fwd_bwd_f32", q, c, nq, nc, dim, diag_offset, workspace, workspace_bytes, prec == 0 || dim == 128);
   if (rc != TT_OK) return rc;
   TT_REQUIRE(lse && per_row && loss && dq && dc, "tt_retrieval_fwd_bwd_f32: null output pointer");
   TT_REQUIRE(tt::aligned16(dq) && tt::aligned16(dc), "tt_retrieval_fwd_bwd_f32: dq/dc must be 16-byte aligned");

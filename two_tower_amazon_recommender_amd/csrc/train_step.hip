@@ -1,0 +1,40 @@
+// tt_train_step_f32 - the whole train step behind ONE C entry (include/twotower_hip.h, ABI v8).  Host code only: it calls the
+// library's own entry points in the order a caller would, so the arithmetic and the launches are theirs, bit for bit.
+#include "common.h"
+
+extern "C" int tt_train_step_f32(const tt_train_step* s, tt_stream_t stream) {
+  TT_REQUIRE(s != nullptr, "tt_train_step_f32: null step");
+  TT_REQUIRE(s->n_layers >= 1 && s->n_layers <= TT_MAX_TOWER_LAYERS, "tt_train_step_f32: 1..%d layers per tower", TT_MAX_TOWER_LAYERS);
+  TT_REQUIRE(s->batch > 0, "tt_train_step_f32: batch must be positive");
+  TT_REQUIRE(s->dropout_rate >= 0.f && s->dropout_rate < 1.f, "tt_train_step_f32: dropout_rate must be in [0, 1)");
+  TT_REQUIRE(s->scorer_precision == 0 || s->scorer_precision == 1, "tt_train_step_f32: scorer_precision must be 0 (f32) or 1 (bf16x3)");
+  TT_REQUIRE(s->n_tables >= 2 && s->n_tables <= 3, "tt_train_step_f32: 2 or 3 embedding tables");
+  TT_REQUIRE(s->n_segs >= 1 && s->n_segs <= TT_MAX_DENSE_SEGS, "tt_train_step_f32: 1..%d dense segments", TT_MAX_DENSE_SEGS);
+  const int L = s->n_layers;
+  int rc;
+  for (int l = 0; l < L; ++l) {
+    const bool hidden = l < L - 1;
+    const bool drop = hidden && s->dropout_rate > 0.f;
+    rc = tt_dense_fwd_batched_f32(s->fwd[l], 2, s->batch, s->dims[l], s->dims[l + 1], hidden ? 1 : 0, drop ? s->dropout_rate : 0.f,
+                                  s->dropout_seed, drop ? s->dropout_row0 * (uint64_t)s->dims[l + 1] : 0ull, stream);
+    if (rc != TT_OK) return rc;
+  }
+  const float* q = s->fwd[L - 1][0].y;
+  const float* c = s->fwd[L - 1][1].y;
+  float* dq = const_cast<float*>(s->bwd[L - 1][0].dz);
+  float* dc = const_cast<float*>(s->bwd[L - 1][1].dz);
+  if (s->scorer_precision == 0)
+    rc = tt_retrieval_fwd_bwd_f32(q, c, s->batch, s->batch, s->dims[L], 0, s->inv_temperature, s->sample_weight, s->cand_prob,
+                                  s->cand_ids, nullptr, 1.0f, s->retrieval_ws, s->retrieval_ws_bytes, s->lse, s->per_row, s->loss, dq, dc, stream);
+  else
+    rc = tt_retrieval_fwd_bwd_bf16x3_f32(q, c, s->batch, s->batch, s->dims[L], 0, s->inv_temperature, s->sample_weight, s->cand_prob,
+                                         s->cand_ids, nullptr, 1.0f, s->retrieval_ws, s->retrieval_ws_bytes, s->lse, s->per_row, s->loss, dq, dc, stream);
+  if (rc != TT_OK) return rc;
+  // the same f32 arithmetic as the forward launcher's keep scale: 1.0f / (1.0f - rate)
+  const float dx_scale = s->dropout_rate > 0.f ? 1.0f / (1.0f - s->dropout_rate) : 1.0f;
+  for (int l = L - 1; l >= 0; --l) {
+    rc = tt_dense_bwd_batched_f32(s->bwd[l], 2, l > 0 ? dx_scale : 1.0f, s->batch, s->dims[l], s->dims[l + 1], stream);
+    if (rc != TT_OK) return rc;
+  }
+  return tt_optimizer_step_ids_f32(s->opt, s->tables, s->n_tables, s->dims[0], s->batch, s->segs, s->n_segs, s->lr, s->eps, stream);
+}

@@ -25,10 +25,23 @@ from . import ops
 NS = "twotower"
 
 
+_WS_CACHE: dict = {}
+
+
 def _ws(nq: int, nc: int, d: int, device, forward_only: bool = False) -> Tensor:
-    """Scorer workspace; the training entry's includes the [nq, nc] f32 dot-product buffer its second pass reads back."""
+    """Scorer workspace; the training entry's includes the [nq, nc] f32 dot-product buffer its second pass reads back
+    (4*nq*nc bytes: 268 MB at 8192 x 8192, 4.3 GB at 32768 x 32768).  Kept per (shape, device, stream) instead of being
+    allocated on every call: the kernels of one stream run in order, so successive calls can share it; only the most
+    recent shape of each kind is held."""
+    key = (bool(forward_only), str(device), torch.cuda.current_stream(device).cuda_stream)
+    hit = _WS_CACHE.get(key)
+    if hit is not None and hit[0] == (nq, nc, d):
+        return hit[1]
     n = ops.retrieval_fwd_workspace_bytes(nq, nc, d) if forward_only else ops.retrieval_workspace_bytes(nq, nc, d)
-    return torch.empty(n, dtype=torch.uint8, device=device)
+    _WS_CACHE.pop(key, None)
+    buf = torch.empty(n, dtype=torch.uint8, device=device)
+    _WS_CACHE[key] = ((nq, nc, d), buf)
+    return buf
 
 
 # --------------------------------------------------------------------------------------------- a1 lookup
@@ -80,7 +93,10 @@ def _(q, c, sample_weight, candidate_sampling_probability, candidate_ids, inv_te
 
 
 def _retrieval_setup(ctx, inputs, output):
-    _, _, dq, dc = output
+    _, per_example, dq, dc = output
+    # only the scalar loss carries a gradient: the per-example losses and the two gradient tensors are results, not
+    # differentiable functions here (a loss built from per_example would otherwise train on silent zeros)
+    ctx.mark_non_differentiable(per_example, dq, dc)
     ctx.save_for_backward(dq, dc)
 
 

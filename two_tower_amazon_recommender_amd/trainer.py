@@ -22,7 +22,7 @@ from dataclasses import dataclass, field
 
 import torch
 
-from . import ops
+from . import _lib, ops
 
 # tensor-id convention of the synthetic initialiser (must match oracle/synth.py, which restates it
 # for the tests; the product does not import the oracle)
@@ -251,6 +251,10 @@ class TwoTowerTrainer:
         self.fuse_lookup = True                  # K1 inside the first tower layer's GEMMs (False: gather2 launch + acts[0])
         self.fuse_sort = os.environ.get("TT_FUSE_SORT", "1") != "0"   # the optimizer launch sorts the ids itself (no plan launch)
         self.fuse_optimizer = True               # sparse + dense optimizer in one launch (False: dense_update, sparse_update2 [, cat])
+        # the whole step behind ONE C call (tt_train_step_f32: the same nine launches, enqueued in C - one FFI crossing per step
+        # instead of nine; cfg1 is host-bound).  TT_COMPOSITE_STEP=0: the Python sequence of the separate entry points.
+        self.use_composite = os.environ.get("TT_COMPOSITE_STEP", "1") != "0"
+        self._cstep = None
         self.flag_poll_every = 50                # steps between asynchronous polls of the out-of-range flag (0 = never)
         self._oob_host = self._oob_event = None
         self._oob_step = -1
@@ -387,7 +391,8 @@ class TwoTowerTrainer:
         """One train step; returns the (device, unsynchronised) retrieval loss (SUM over the batch)."""
         self._check_batch(user_ids, item_ids, loss_kw.get("category_ids"), loss_kw.get("sample_weight"),
                           loss_kw.get("candidate_sampling_probability"), loss_kw.get("candidate_ids"))
-        if self.flag_poll_every and self.step_index % self.flag_poll_every == 0:
+        # (never inside a graph capture: the poll queries an event recorded outside it and would bake a D2H copy into every replay)
+        if self.flag_poll_every and self.step_index % self.flag_poll_every == 0 and not torch.cuda.is_current_stream_capturing():
             self.poll_ids()
         # the sort plans depend on the ids only: one launch for all tables, in front of the forward pass (or beside it)
         main = torch.cuda.current_stream()
@@ -399,6 +404,9 @@ class TwoTowerTrainer:
         fused_sort = (self.fuse_sort and self.fuse_optimizer and user_ids.numel() <= ops.sparse_plan_max_lds_ids()
                       and (self.cat_table is None) == (len(ids) == 2))
         if fused_sort:
+            if (self.use_composite and self.fuse_lookup and self.cfg.symmetric
+                    and self.cfg.batch_size <= ops.MAX_FUSED_LOOKUP_ROWS):
+                return self._step_composite(ids, **loss_kw)
             loss = self.forward_backward(user_ids, item_ids, **loss_kw)
             self.apply_gradients(step_ids=ids)
             return loss
@@ -413,6 +421,91 @@ class TwoTowerTrainer:
             main.wait_stream(self._side)
         self.apply_gradients()
         return loss
+
+    def _build_composite(self):
+        """The step's description for tt_train_step_f32 (include/twotower_hip.h): every buffer of the step is allocated once,
+        so the struct is filled once; step() rewrites the id pointers, the dropout row counter and the optional inputs."""
+        cfg, ut, it = self.cfg, self.user_tower, self.item_tower
+        st = _lib.TrainStep()
+        st.batch, st.n_layers = cfg.batch_size, ut.n_layers
+        if ut.n_layers > _lib.TT_MAX_TOWER_LAYERS or len(self._segs) > _lib.TT_MAX_DENSE_SEGS:
+            return None
+        for l, d in enumerate(ut.dims):
+            st.dims[l] = d
+        p = ops._p
+        for l in range(ut.n_layers):
+            for i, tw in enumerate((ut, it)):
+                f, b = st.fwd[l][i], st.bwd[l][i]
+                f.x = None if l == 0 else p(tw.acts[l])
+                f.w, f.b, f.y = p(tw.w[l]), p(tw.b[l]), p(tw.acts[l + 1])
+                f.dropout_tensor_id = TID_DROPOUT_BASE + 2 * l + i
+                f.relu_bits = p(tw.bits[l + 1])
+                b.x = None if l == 0 else p(tw.acts[l])
+                b.w, b.dz = p(tw.w[l]), p(tw.dz[l])
+                b.dx = p(tw.dz[l - 1] if l > 0 else tw.demb)
+                b.dx_relu_bits = p(tw.bits[l]) if l > 0 else None
+                b.dx_relu_src = p(tw.acts[l]) if (l > 0 and tw.bits[l] is None) else None
+                b.dw_slabs, b.db_slabs = p(tw.dw_slabs[l]), p(tw.db_slabs[l])
+        for i, (table, rows2) in enumerate(((self.user_table, None), (self.item_table, self.cat_table))):
+            for lk in (st.fwd[0][i].lookup, st.bwd[0][i].lookup):
+                lk.table, lk.table_rows, lk.oob_flag = p(table), table.shape[0], p(self.oob)
+                if rows2 is not None:
+                    lk.table2, lk.table2_rows = p(rows2), rows2.shape[0]
+        st.dropout_rate, st.dropout_seed = cfg.dropout_rate, self.dropout_seed
+        st.scorer_precision = ops.SCORER_PRECISIONS.index(cfg.scorer_precision)
+        st.inv_temperature = 1.0 / cfg.temperature
+        st.retrieval_ws, st.retrieval_ws_bytes = p(self.ws), self.ws.numel()
+        st.lse, st.per_row, st.loss = p(self.lse), p(self.per_row), p(self.loss)
+        st.opt = ops._OPT[cfg.optimizer]
+        tabs = [(self.user_table, self.user_accum, ut.demb, self.user_plan), (self.item_table, self.item_accum, it.demb, self.item_plan)]
+        if self.cat_table is not None:          # the category row's gradient is the item-tower input gradient itself
+            tabs.append((self.cat_table, self.cat_accum, it.demb, self.cat_plan))
+        st.n_tables = len(tabs)
+        for i, (table, accum, grads, plan) in enumerate(tabs):
+            t = st.tables[i]
+            t.table, t.accum, t.rows, t.grads = p(table), p(accum), table.shape[0], p(grads)
+            t.apply_ws = p(plan.apply_ws(cfg.embedding_dim))
+        st.n_segs = len(self._segs)
+        for i, seg in enumerate(self._segs):
+            st.segs[i] = seg
+        st.lr, st.eps = cfg.learning_rate, cfg.adagrad_epsilon
+        return st
+
+    def _step_composite(self, ids, sample_weight=None, candidate_sampling_probability=None, candidate_ids=None,
+                        category_ids=None) -> torch.Tensor:
+        """forward_backward + apply_gradients as ONE call into the library (same launches, same order, same results)."""
+        self._check_categories(category_ids)
+        if self._cstep is None:
+            self._cstep = self._build_composite()
+            if self._cstep is None:                  # more layers / segments than the struct holds: the Python sequence
+                self.use_composite = False
+                loss = self.forward_backward(ids[0], ids[1], sample_weight=sample_weight, category_ids=category_ids,
+                                             candidate_sampling_probability=candidate_sampling_probability, candidate_ids=candidate_ids)
+                self.apply_gradients(step_ids=ids)
+                return loss
+        st = self._cstep
+        for t in ids:
+            ops._chk(t, torch.int64, "ids", 1)
+        for t, name in ((sample_weight, "sample_weight"), (candidate_sampling_probability, "candidate_sampling_probability")):
+            if t is not None:
+                ops._chk(t, torch.float32, name, 1)
+        if candidate_ids is not None:
+            ops._chk(candidate_ids, torch.int64, "candidate_ids", 1)
+        p = ops._p
+        for i in range(2):
+            for lk in (st.fwd[0][i].lookup, st.bwd[0][i].lookup):
+                lk.ids = p(ids[i])
+                if i == 1:
+                    lk.ids2 = p(category_ids)
+            st.tables[i].ids = p(ids[i])
+        if st.n_tables == 3:
+            st.tables[2].ids = p(ids[2])
+        st.dropout_seed = self.dropout_seed
+        st.dropout_row0 = self.step_index * self.cfg.batch_size
+        st.sample_weight, st.cand_prob, st.cand_ids = p(sample_weight), p(candidate_sampling_probability), p(candidate_ids)
+        _lib.check(_lib.load().tt_train_step_f32(st, ops._stream()), "tt_train_step_f32")
+        self.step_index += 1
+        return self.loss
 
     def evaluate(self, user_ids: torch.Tensor, item_ids: torch.Tensor, **loss_kw) -> torch.Tensor:
         """Forward only (validation loss, SUM over the batch); device tensor, unsynchronised."""
@@ -532,12 +625,17 @@ class TwoTowerTrainer:
         if category_ids is not None:
             self._g_kw["category_ids"].copy_(category_ids, non_blocking=True)
         self._graph.replay()
+        self._replays = getattr(self, "_replays", 0) + 1
+        if self.flag_poll_every and self._replays % self.flag_poll_every == 0:     # host side, outside the graph
+            self.poll_ids()
         return self.loss
 
     def poll_ids(self):
         """Asynchronous check of the out-of-range flag: looks at the copy the PREVIOUS poll started (if it has landed —
         never waits for the GPU) and starts a new 4-byte device-to-pinned-host copy.  step() calls it every
-        ``flag_poll_every`` steps, so a bad id is reported within one interval, with the step it was seen at."""
+        ``flag_poll_every`` steps; the copy a poll starts is looked at by the NEXT poll, so a bad id is reported within two
+        intervals, with the step range it was seen in.  A bad id in the last interval of a run is only seen by check_ids()
+        (train.py calls it at the end of every epoch)."""
         if self._oob_event is not None and self._oob_event.query():
             bad, self._oob_event = int(self._oob_host.item()), None
             if bad:
