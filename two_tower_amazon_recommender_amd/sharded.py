@@ -81,6 +81,22 @@ class HipRowBackend:
             plan.run(ids, num_rows)
         self._pending[key] = plan
 
+    @property
+    def max_fused_ids(self) -> int:
+        """Longest owner-side id list the one-launch optimizer (sort + duplicate sums + update) takes."""
+        return self.ops.sparse_plan_max_lds_ids()
+
+    def apply_ids(self, opt, table, accum, ids, grads, dense_segs, lr, eps, key=None):
+        """Owner side in ONE launch, straight from the received ids (tt_optimizer_step_ids_f32): the workgroups sort the
+        ids of their row range in LDS, sum the duplicate gradient rows - inside one rank's batch and across ranks, in
+        (source rank, position) order - and apply the update; the dense segments are updated beside them.  No plan launch,
+        no side stream.  Bit-identical to plan() + apply() + dense_update_."""
+        n = ids.numel()
+        ws = self._plans.get((key, n, "ws"))
+        if ws is None:
+            ws = self._plans[(key, n, "ws")] = self.ops.SparsePlan(n, ids.device)      # (lends its apply workspace)
+        self.ops.optimizer_step_ids_(opt, [(table, accum, grads, ids, ws)], dense_segs, lr, eps)
+
     def apply(self, opt, table, accum, ids, grads, lr, eps, key=None):
         plan = self._pending.pop(key)
         torch.cuda.current_stream().wait_stream(self._side)
@@ -137,6 +153,12 @@ class ShardedTables:
         self.rows_out = torch.empty(n, dim, device=device)        # owner side: gathered rows / received grads
         # requester side: received rows / grads to send (one rank without collectives: the exchange is the identity)
         self.rows_in = torch.empty(n, dim, device=device) if self.collectives else self.rows_out
+        # gradient rows travel in buffers of their own: the received embedding rows stay valid through the backward pass (the
+        # towers' first layer reads them in place - forward GEMM and dW GEMM - through pos_flat: no expanded [batch, dim] copy)
+        self.grad_send = torch.empty(n, dim, device=device)
+        self.grad_recv = torch.empty(n, dim, device=device) if self.collectives else self.grad_send
+        # owner side in one launch from the received ids (no sort plan) when the backend offers it and the list fits
+        self.fused_apply = hasattr(self.backend, "apply_ids") and n <= getattr(self.backend, "max_fused_ids", 0)
         # id buffers exist twice: lookup_prefetch() routes and exchanges the NEXT step's ids while this step computes
         self._idbufs = [self._make_idbufs(), None]
         self._cur = 0
@@ -225,13 +247,21 @@ class ShardedTables:
         """owner side: sort plan (side stream), K1 gather, C2 (rows back to the requesters)."""
         self._wait(self._w)
         be = self.backend
-        be.plan(self.recv_ids, self.table.shape[0], key=id(self))
+        if not self.fused_apply:
+            be.plan(self.recv_ids, self.table.shape[0], key=id(self))
         be.gather(self.table, self.recv_ids, self.rows_out, self.flags[0:1])       # K1
         self._w = self._a2a(self.rows_in, self.rows_out, overlap=False)            # C2
+
+    def lookup_wait(self):
+        """The received rows are in ``rows_in`` (row of position p of table t at slot pos_flats[t][p], -1 = none): a consumer
+        that indexes them itself - the towers' first layer, tt_dense_lookup - needs no expanded copy."""
+        self._wait(self._w)
+        self._w = None
 
     def lookup_finish(self, out: torch.Tensor):
         """K1': out[t*batch + p, :] = row of position p of table t."""
         self._wait(self._w)
+        self._w = None
         self.backend.gather(self.rows_in, self.pos_flat, out, None)
         return out
 
@@ -243,13 +273,20 @@ class ShardedTables:
     # ---------------------------------------------------------------- backward, in two phases
     def grads_start(self, grads: torch.Tensor):
         """K2' + C3: per-position gradient rows [n_tables*batch, dim] to the owners (padding slots are never read)."""
-        self.backend.scatter_rows(grads, self.pos_flat, self.rows_in)
-        self._w = self._a2a(self.rows_out, self.rows_in)                           # C3
+        self.backend.scatter_rows(grads, self.pos_flat, self.grad_send)
+        self._w = self._a2a(self.grad_recv, self.grad_send)                        # C3
 
-    def grads_finish(self, opt: str, lr: float, eps: float = 1e-7):
-        """K2: fused sparse update on the owner (duplicates summed first, in (source rank, position) order)."""
+    def grads_finish(self, opt: str, lr: float, eps: float = 1e-7, dense_segs=None):
+        """K2: fused sparse update on the owner (duplicates summed first, in (source rank, position) order).
+        dense_segs (only with ``fused_apply``): dense segments updated in the same launch; returns True if they were."""
         self._wait(self._w)
-        self.backend.apply(opt, self.table, self.accum, self.recv_ids, self.rows_out, lr, eps, key=id(self))
+        if self.fused_apply and dense_segs:
+            self.backend.apply_ids(opt, self.table, self.accum, self.recv_ids, self.grad_recv, dense_segs, lr, eps, key=id(self))
+            return True
+        if self.fused_apply:       # (no dense work to ride along: the sort plan was skipped, so run it now)
+            self.backend.plan(self.recv_ids, self.table.shape[0], key=id(self))
+        self.backend.apply(opt, self.table, self.accum, self.recv_ids, self.grad_recv, lr, eps, key=id(self))
+        return False
 
     def apply_gradients(self, grads: torch.Tensor, opt: str, lr: float, eps: float = 1e-7):
         """grads[t*batch + p, :] = dLoss/d(out[t*batch + p, :]) of the last lookup (K2', C3, K2)."""
@@ -396,6 +433,7 @@ class ShardedTwoTowerTrainer:
             self.c_all = torch.empty(nc, sd, device=dev)
             self.dc_all = torch.empty(nc, sd, device=dev)
         self.step_index = 0
+        self.fuse_lookup = True       # the towers' first layer reads the received rows in place (False: expand gather + emb_in)
         self.flag_poll_every = 50     # steps between asynchronous [out-of-range, overflow] flag polls (0 = never)
         self.dropout_seed = 0 if seed is None else seed
         if seed is not None:
@@ -506,17 +544,27 @@ class ShardedTwoTowerTrainer:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 self.cat_plan.run(category_ids, cfg.n_category_buckets)
-        em.lookup_finish(self.emb_in)
-        if category_ids is not None:
-            ops.embedding_gather_add_(it.acts[0], self.cat_table, category_ids, em.flags[0:1])
+        # K1' fused into the towers' first layer (r03): the forward GEMM and the dW GEMM read the received rows in place
+        # through pos_flat (tt_dense_lookup with table = rows_in; the category row is its table2) - no expand gather, no
+        # [2*batch, dim] emb_in, no gather-add launch.  (Longer batches than the fused lookup takes: the old three launches.)
+        fused_in = self.fuse_lookup and b <= ops.MAX_FUSED_LOOKUP_ROWS
+        lks = None
+        if fused_in:
+            em.lookup_wait()
+            lks = (ops.make_lookup(em.rows_in, em.pos_flats[0], oob_flag=em.flags[0:1]),
+                   ops.make_lookup(em.rows_in, em.pos_flats[1], self.cat_table, category_ids, em.flags[0:1]))
+        else:
+            em.lookup_finish(self.emb_in)
+            if category_ids is not None:
+                ops.embedding_gather_add_(it.acts[0], self.cat_table, category_ids, em.flags[0:1])
         if next_ids is not None:
             em.lookup_prefetch(next_ids, prefetch_exchange)
         row0 = (self.step_index * w + self.rank) * b          # first global batch row of this rank
         if cfg.symmetric:
-            q, c = towers_forward(ut, it, (cfg.dropout_rate, self.dropout_seed, row0))
+            q, c = towers_forward(ut, it, (cfg.dropout_rate, self.dropout_seed, row0), lookups=lks)
         else:
-            q = ut.forward((cfg.dropout_rate, self.dropout_seed, 0, row0))
-            c = it.forward((cfg.dropout_rate, self.dropout_seed, 1, row0))
+            q = ut.forward((cfg.dropout_rate, self.dropout_seed, 0, row0), lookup=lks[0] if lks else None)
+            c = it.forward((cfg.dropout_rate, self.dropout_seed, 1, row0), lookup=lks[1] if lks else None)
         inv_t = 1.0 / cfg.temperature
         cp = self._cand_prob(candidate_sampling_probability)
         ci = self._cand_ids(candidate_ids)
@@ -539,18 +587,23 @@ class ShardedTwoTowerTrainer:
                 torch.cuda.current_stream().wait_stream(em.backend._side)
                 self.cat_grad.zero_()
                 ops.sparse_sgd_(self.cat_grad, it.demb, self.cat_plan, -1.0)
-        if cfg.symmetric:
-            towers_backward(ut, it, cfg.dropout_rate, on_embedding_grads=send)
+        if cfg.symmetric and not self.collectives:
+            # nothing to overlap the dw GEMMs with: the fused dx + dw launches of the plain trainer, then the scatter
+            towers_backward(ut, it, cfg.dropout_rate, lookups=lks)
+            send()
+        elif cfg.symmetric:
+            towers_backward(ut, it, cfg.dropout_rate, on_embedding_grads=send, lookups=lks)
         else:
             ut.backward(cfg.dropout_rate, dx=True, dw=False)
             it.backward(cfg.dropout_rate, dx=True, dw=False)
             send()
-            ut.backward(cfg.dropout_rate, dx=False, dw=True)
-            it.backward(cfg.dropout_rate, dx=False, dw=True)
+            ut.backward(cfg.dropout_rate, dx=False, dw=True, lookup=lks[0] if lks else None)
+            it.backward(cfg.dropout_rate, dx=False, dw=True, lookup=lks[1] if lks else None)
         self.step_index += 1
         if not self.collectives:
-            ops.dense_update_(self._segs_reduce, cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon, apply=True)
-            em.grads_finish(cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon)
+            # one rank, no collectives: owner sort + duplicate sums + sparse update + dense update in ONE launch
+            if not em.grads_finish(cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon, dense_segs=self._segs_reduce):
+                ops.dense_update_(self._segs_reduce, cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon, apply=True)
             if category_ids is not None:      # one rank, no collectives: the plain trainer's sparse update
                 if cfg.optimizer == "sgd":
                     ops.sparse_sgd_(self.cat_table, it.demb, self.cat_plan, cfg.learning_rate)
@@ -559,6 +612,12 @@ class ShardedTwoTowerTrainer:
                                         cfg.adagrad_epsilon)
         else:
             ops.dense_update_(self._segs_reduce, cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon, apply=False)
+            if em.sync_ops_inline and em.fused_apply:
+                # C6 on the current stream, then ONE launch: the owner's sort + duplicate sums + sparse update (it waits
+                # for C3) with the dense update from the all-reduced gradient riding along
+                dist.all_reduce(self.dense_grad, op=dist.ReduceOp.SUM, group=self.group)                   # C6
+                em.grads_finish(cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon, dense_segs=self._segs_apply)
+                return self.loss
             if em.sync_ops_inline:
                 # C6 on the current stream, after the owner update (which waits for C3): the ~12 us of sparse update it
                 # could have overlapped are less than the two cross-stream hand-offs of an asynchronous op cost
