@@ -826,6 +826,33 @@ def test_route_tables_one_launch_combined_layout(dev, world, n, cap):
     assert any_oob == 1
 
 
+@pytest.mark.parametrize("batch,rows", [(2048, (5_000_000, 100_000_000)), (4096, (54_000_000, 48_000_000))])
+def test_routing_of_powerlaw_ids_over_8_owners_fits_the_default_capacity(dev, batch, rows):
+    """BASELINE configs[3] / [4] per-GPU batches (16384 / 8, 32768 / 8) of power-law ids routed to 8 owners (row id % 8) with
+    the exchange buffers ShardedTables reserves by default (capacity_factor 2.0 -> 512 / 1024 positions per owner and
+    table): no bucket overflows - a hot id occupies one slot per occurrence, and id % world spreads the hot low ids over
+    all owners - and every position finds its slot.  Several seeds (= several steps of the synthetic stream)."""
+    world = 8
+    mean = (batch + world - 1) // world
+    cap = min(batch, int(mean * 2.0 + 63) // 64 * 64)             # ShardedTables.__init__
+    offsets = [0, (rows[0] + world - 1) // world]
+    for seed in range(6):
+        ids = [T(synth.ids_powerlaw(100 + seed, 3 + t, batch, r), dev) for t, r in enumerate(rows)]
+        send = torch.full((world * 2 * cap,), -7, dtype=torch.int64, device=dev)
+        pos = [torch.empty(batch, dtype=torch.int64, device=dev) for _ in rows]
+        flags = torch.zeros(2, dtype=torch.int32, device=dev)
+        ops.route_tables_by_owner(ids, world, rows, offsets, cap, send, pos, flags)
+        assert flags.tolist() == [0, 0], f"seed {seed}: out-of-range / overflow flags {flags.tolist()} at cap {cap}"
+        for t in range(2):
+            x = ids[t].cpu().numpy()
+            per_owner = np.bincount(x % world, minlength=world)
+            assert per_owner.max() <= cap
+            p = pos[t].cpu().numpy()
+            assert (p >= 0).all()
+            got = send.cpu().numpy()[p]
+            assert np.array_equal(got, x // world + offsets[t])
+
+
 def test_scatter_rows(dev):
     n, d, rows = 5000, 128, 9000
     src = synth.uniform_f32(62, 1, n * d, -1.0, 2.0).reshape(n, d)

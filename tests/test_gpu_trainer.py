@@ -174,6 +174,70 @@ def test_full_size_train_step_properties_cfg3(dev):
     assert sums[0] == sums[1], "the train step is not bit-reproducible"
 
 
+@pytest.mark.parametrize("engine", ["plain", "sharded_world1_rccl"])
+def test_full_size_train_step_properties_cfg4(dev, engine):
+    """BASELINE configs[3] at FULL size on one GPU: 5M users x 100M items x 128 (53.8 GB of tables), towers 256-128, batch
+    16384, SGD - un-sharded through TwoTowerTrainer, and through ShardedTwoTowerTrainer on a one-rank "nccl" (= RCCL) group
+    with every collective really issued (route, id / row / gradient all-to-alls, dense all-reduce, owner update in one
+    launch where the received list fits: 2 x 16384 ids here, so sort plan + apply).  Properties that need no O(B^2) host work and no second copy of
+    the tables: the batch's rows change and sampled rows outside the batch do not, the first loss is ~ln(B), two runs from
+    the seed agree bit for bit - and the two engines agree with each other bit for bit."""
+    import os
+    import torch.distributed as dist
+    free, total_mem = torch.cuda.mem_get_info()
+    if total_mem < 120e9:
+        pytest.skip("needs > 120 GB of HBM")
+    nu, ni, d, dims, b = 5_000_000, 100_000_000, 128, [256, 128], 16384
+    if engine != "plain":
+        assert not dist.is_initialized()
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ["MASTER_PORT"] = "29581"
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        sums = []
+        for rep in range(2):
+            cfg = TwoTowerConfig(n_users=nu, n_items=ni, embedding_dim=d, tower_dims=dims, temperature=0.1, l2_regularization=1e-6,
+                                 learning_rate=0.001, optimizer="sgd", batch_size=b)
+            if engine == "plain":
+                tr = TwoTowerTrainer(cfg, dev, seed=1004)
+            else:
+                from two_tower_amazon_recommender_amd.sharded import ShardedTwoTowerTrainer
+                tr = ShardedTwoTowerTrainer(cfg, dev, seed=1004, negatives="global", force_collectives=True)
+                assert tr.collectives
+            u, i = tr.synthetic_batch(1004, 0, "Z")
+            probe = {}
+            for name, table, ids, rows in (("user", tr.user_table, u, nu), ("item", tr.item_table, i, ni)):
+                uniq = torch.unique(ids)
+                other = torch.randint(0, rows, (200_000,), device=dev, generator=torch.Generator(device=dev).manual_seed(rep))
+                other = other[~torch.isin(other, uniq)]
+                probe[name] = (uniq, other, table[uniq].clone(), table[other].clone())
+            dense_before = tr.dense_flat.clone()
+            loss = tr.step(u, i).item()
+            tr.check_ids()
+            assert abs(loss / b - np.log(b)) < 0.05, loss / b
+            for name, table in (("user", tr.user_table), ("item", tr.item_table)):
+                uniq, other, rows_before, other_before = probe[name]
+                assert torch.equal(table[other], other_before), f"{name}: a row outside the batch was modified"
+                assert (table[uniq] != rows_before).any(dim=1).float().mean().item() >= 0.99
+                assert torch.isfinite(table[uniq]).all()
+            assert (tr.dense_flat != dense_before).float().mean().item() > 0.5
+            loss2 = tr.step(*tr.synthetic_batch(1004, 1, "Z")).item()
+            tr.check_ids()
+            sums.append((loss, loss2, tr.user_table[probe["user"][0]].view(torch.int32).sum(dtype=torch.int64).item(),
+                         tr.item_table[probe["item"][0]].view(torch.int32).sum(dtype=torch.int64).item(),
+                         tr.dense_flat.view(torch.int32).sum(dtype=torch.int64).item()))
+            del tr, probe, table, uniq, other, rows_before, other_before
+            torch.cuda.empty_cache()
+        assert sums[0] == sums[1], "the cfg4 train step is not bit-reproducible"
+        # both engines must land on the same numbers (one rank: every collective is the identity)
+        ref = getattr(test_full_size_train_step_properties_cfg4, "_sums", None)
+        if ref is not None:
+            assert ref == sums[0], "plain and sharded(world 1, RCCL) cfg4 steps differ"
+        test_full_size_train_step_properties_cfg4._sums = sums[0]
+    finally:
+        if engine != "plain":
+            dist.destroy_process_group()
+
+
 def test_full_size_train_step_properties_cfg5(dev):
     """BASELINE configs[4] at FULL size on one GPU: 54M users x 48M items x 256 (+ Adagrad accumulators: 209 GB of
     tables), towers 256->512->256, batch 32768, fused sparse Adagrad, 30-bucket hashed category feature.  Properties
