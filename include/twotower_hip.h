@@ -273,6 +273,18 @@ int tt_dense_fwd_batched_f32(const tt_dense_fwd_args* probs, int32_t n_probs, in
 int tt_dense_bwd_batched_f32(const tt_dense_bwd_args* probs, int32_t n_probs, float dx_scale,
                              int64_t m, int32_t k, int32_t n, tt_stream_t stream);
 
+/* The forward pass of a TWO-layer tower in ONE launch (csrc/tower.hip): h = relu(x @ w0 + b0) [dropout], y = h @ w1 + b1 for
+ * the user and the item tower together.  A workgroup owns 32 batch rows for both layers; the hidden tile stays in LDS (it
+ * is still written to layer0[i].y - and its sign bits to layer0[i].relu_bits - because the backward pass reads them).
+ * layer0[i] / layer1[i] are the per-layer descriptions tt_dense_fwd_batched_f32 takes (layer1[i].x must be layer0[i].y or
+ * NULL; only layer 0 may carry a lookup); dropout applies to the hidden layer, with layer0[i].dropout_tensor_id and
+ * counter_offset as there.  Bit-identical to the two tt_dense_fwd_batched_f32 calls.  Shapes: k0 % 32 == 0, k0 <= 512,
+ * h and n1 in {128, 256} (tt_tower_fwd2_supported; otherwise TT_ERR_UNSUPPORTED - call the layers one by one).         */
+int32_t tt_tower_fwd2_supported(int64_t m, int32_t k0, int32_t h, int32_t n1);
+int tt_tower_fwd2_batched_f32(const tt_dense_fwd_args* layer0, const tt_dense_fwd_args* layer1, int32_t n_probs, int64_t m,
+                              int32_t k0, int32_t h, int32_t n1, float drop_rate, uint64_t seed, uint64_t counter_offset,
+                              tt_stream_t stream);
+
 /* Dense parameter update over up to TT_MAX_DENSE_SEGS segments in one launch.
  *   g = sum_s grad_slabs[s*slab_stride + i] (s ascending) + 2*l2*w[i]
  *   SGD: w -= fl(lr*g);  Adagrad: acc += g*g; w -= fl(lr*g)/sqrt(acc+eps)
@@ -327,7 +339,8 @@ int tt_optimizer_step_ids_f32(int32_t opt, const tt_sparse_table_ids* tables, in
  * never written) would run per batch.  A HOST struct of pointers describes the step once - every buffer is caller-owned
  * and fixed from step to step; per step the caller only rewrites the id pointers, the dropout row counter and the optional
  * per-pair inputs - and tt_train_step_f32 enqueues, on `stream`, exactly the launches the separate entry points would:
- *   for each layer l:            tt_dense_fwd_batched_f32(fwd[l], 2, ...)       (layer 0 reads the embedding rows itself)
+ *   for each layer l:            tt_dense_fwd_batched_f32(fwd[l], 2, ...)       (layer 0 reads the embedding rows itself;
+ *                                two-layer towers of supported shapes: ONE tt_tower_fwd2_batched_f32 launch instead)
  *   scorer + loss + dq, dc:      tt_retrieval_fwd_bwd_f32 / _bf16x3_f32         (q, c = fwd[n_layers-1][*].y; dq, dc = bwd[n_layers-1][*].dz)
  *   for each layer l, last first: tt_dense_bwd_batched_f32(bwd[l], 2, ...)
  *   optimizer:                   tt_optimizer_step_ids_f32(tables, segs)       (sort + duplicate sums + sparse update + dense update)

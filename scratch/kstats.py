@@ -1,11 +1,8 @@
-"""Print the top rows of a rocprofv3 kernel_stats.csv (short kernel names)."""
-import csv
-import re
-import sys
-
+"""kernel stats of a rocprofv3 --stats run: python scratch/kstats.py <trace_kernel_stats.csv> [substring ...]"""
+import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-n = int(sys.argv[2]) if len(sys.argv) > 2 else 18
-for r in rows[:n]:
-    name = re.sub(r"\(anonymous namespace\)::", "", r["Name"])
-    name = re.sub(r"^void ", "", name)
-    print("%6d %9.2f us %6.2f%%  %s" % (int(r["Calls"]), float(r["AverageNs"]) / 1e3, float(r["Percentage"]), name[:100]))
+keys = sys.argv[2:] or ['tower_fwd2', 'gemm_kernel', 'gemm_bwd', 'optimizer', 'score_kernel', 'fused_combine', 'reduce_slabs']
+for r in rows:
+    n = r['Name']
+    if any(k in n for k in keys):
+        print(f"{n.replace('void (anonymous namespace)::', '').replace('(anonymous namespace)::', '')[:64]:64s} calls {r['Calls']:>5s} avg {float(r['AverageNs'])/1e3:8.2f} us  min {float(r['MinNs'])/1e3:8.2f}  max {float(r['MaxNs'])/1e3:8.2f}")

@@ -1,0 +1,29 @@
+"""Phase stamps of tower_fwd2_kernel (debug build of tower.hip with -DTT_TOWER_STAMPS via TT_LIB_PATH):
+0 start, 1 input tile ready, 2 layer-0 MFMAs issued, 3 hidden tile complete (epilogue 1 done), 4 layer-1 MFMAs issued, 5 y stores issued, 6 stores landed."""
+import ctypes as C
+import os
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from two_tower_amazon_recommender_amd import _lib
+from two_tower_amazon_recommender_amd.trainer import TwoTowerConfig, TwoTowerTrainer
+
+dev = torch.device("cuda:0")
+lib = _lib.load()
+lib.tt_debug_tower_stamps.restype = C.c_int
+lib.tt_debug_tower_stamps.argtypes = [C.c_void_p, C.c_int]
+cfg = TwoTowerConfig(n_users=5_000_000, n_items=10_000_000, embedding_dim=128, tower_dims=[256, 128], batch_size=8192)
+tr = TwoTowerTrainer(cfg, dev, seed=3)
+u, i = tr.synthetic_batch(3, 0)
+for _ in range(5):
+    tr.step(u, i)
+torch.cuda.synchronize()
+buf = np.zeros(1024 * 8, dtype=np.uint64)
+assert lib.tt_debug_tower_stamps(buf.ctypes.data, buf.size) == 0
+s = buf.reshape(1024, 8)[:512, :7].astype(np.int64)
+t0 = s[:, 0].min()
+us = (s - t0) / 100.0
+names = ["start", "input tile", "layer-0 MFMAs", "hidden tile", "layer-1 MFMAs", "y stores issued", "stores landed"]
+print("512 workgroups; mean stamp (us):", ", ".join(f"{n} {us[:, k].mean():.2f}" for k, n in enumerate(names)))
+print("   max:", ", ".join(f"{n} {us[:, k].max():.2f}" for k, n in enumerate(names)), "| start spread", us[:, 0].max())

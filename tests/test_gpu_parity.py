@@ -518,6 +518,67 @@ def test_lookup_fused_into_the_first_layer_is_bit_identical_to_gather_then_dense
     assert torch.equal(y2[1], ops.dense_fwd(ops.embedding_gather(table, d_ids), w, b, relu=True))
 
 
+@pytest.mark.parametrize("m,k0,h,n1,lookup,rate", [(8192, 128, 256, 128, True, 0.0), (8192, 128, 256, 128, False, 0.1),
+                                                   (1000, 64, 128, 128, True, 0.1), (77, 256, 256, 256, False, 0.0),
+                                                   (4096, 128, 128, 256, True, 0.0), (33, 32, 128, 128, False, 0.0)])
+def test_fused_tower_forward_is_bit_identical_to_two_layers(dev, m, k0, h, n1, lookup, rate):
+    """tt_tower_fwd2_batched_f32 (both layers of both towers in one launch, hidden tile in LDS) against
+    tt_dense_fwd_batched_f32 called per layer: hidden activations, their sign bits and the outputs identical bit for bit -
+    with the fused embedding lookup (+ category row, padding and out-of-range ids), with dropout on the hidden layer, for
+    ragged row counts and every supported width combination."""
+    assert ops.tower_fwd2_supported(m, k0, h, n1)
+    rows, rows2 = 20_000, 30
+    tabs = [T(synth.embedding_table(71, 1 + i, rows, k0), dev) for i in range(2)]
+    cat = T(synth.embedding_table(71, 5, rows2, k0), dev)
+    ids = [synth.batch_ids(71, 3 + i, 0, m, rows, "Z") for i in range(2)]
+    ids2 = synth.batch_ids(71, 6, 0, m, rows2, "Z")
+    ids[0][3] = -1
+    if m > 50:
+        ids[1][40] = rows + 5
+    d_ids = [T(x, dev) for x in ids]
+    d_ids2 = T(ids2, dev)
+    xs = [T(synth.uniform_f32(71, 10 + i, m * k0, -0.3, 0.6).reshape(m, k0), dev) for i in range(2)]
+    w0 = [T(synth.uniform_f32(71, 20 + i, k0 * h, -0.2, 0.4).reshape(k0, h), dev) for i in range(2)]
+    b0 = [T(synth.uniform_f32(71, 22 + i, h, -0.1, 0.2), dev) for i in range(2)]
+    w1 = [T(synth.uniform_f32(71, 24 + i, h * n1, -0.2, 0.4).reshape(h, n1), dev) for i in range(2)]
+    b1 = [T(synth.uniform_f32(71, 26 + i, n1, -0.1, 0.2), dev) for i in range(2)]
+    drop = (rate, 9, (64, 65), 12345 * h) if rate > 0 else None
+
+    def run(fused):
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        lks = (ops.make_lookup(tabs[0], d_ids[0], oob_flag=flag), ops.make_lookup(tabs[1], d_ids[1], cat, d_ids2, flag)) if lookup else None
+        hs = [torch.full((m, h), 7.0, device=dev) for _ in range(2)]
+        ys = [torch.full((m, n1), 7.0, device=dev) for _ in range(2)]
+        bits = [ops.relu_bits_like(m, h, dev) for _ in range(2)]
+        for bt in bits:
+            bt.fill_(-1)
+        if fused:
+            ops.tower_fwd2(xs, w0, b0, hs, bits, w1, b1, ys, dropout=drop, lookups=lks)
+        else:
+            ops.dense_fwd2(xs, w0, b0, hs, relu=True, dropout=drop, lookups=lks, relu_bits=bits)
+            ops.dense_fwd2(hs, w1, b1, ys, relu=False)
+        return hs, ys, bits, flag.item()
+
+    ha, ya, ba, fa = run(True)
+    hb, yb, bb, fb = run(False)
+    for i in range(2):
+        assert torch.equal(ha[i], hb[i]), f"hidden activation of tower {i}"
+        assert torch.equal(ba[i], bb[i]), f"sign bits of tower {i}"
+        assert torch.equal(ya[i], yb[i]), f"output of tower {i}"
+    assert fa == fb == (1 if (lookup and m > 50) else 0)
+    if rate > 0:
+        assert (ha[0] == 0).float().mean().item() > rate * 0.8
+
+
+def test_fused_tower_forward_refuses_unsupported_shapes(dev):
+    assert not ops.tower_fwd2_supported(128, 128, 512, 256) and not ops.tower_fwd2_supported(128, 36, 128, 128)
+    x = [torch.zeros(64, 128, device=dev)] * 2
+    w0 = [torch.zeros(128, 512, device=dev)] * 2; w1 = [torch.zeros(512, 128, device=dev)] * 2
+    hs = [torch.zeros(64, 512, device=dev)] * 2; ys = [torch.zeros(64, 128, device=dev)] * 2
+    with pytest.raises(NotImplementedError):
+        ops.tower_fwd2(x, w0, [None, None], hs, [None, None], w1, [None, None], ys)
+
+
 @pytest.mark.parametrize("opt", ["sgd", "adagrad"])
 def test_dense_update_segments(dev, opt):
     rng = np.random.default_rng(5)

@@ -29,6 +29,9 @@ constexpr int BM = 64, BN = 64, BK = 32;
 #ifndef TT_GEMM_PF
 #define TT_GEMM_PF 2
 #endif
+#ifndef TT_GEMM_WIDE_STORE
+#define TT_GEMM_WIDE_STORE 1  // the output tile goes through LDS and leaves as 16-byte stores (0: 4-byte stores from the accumulators)
+#endif
 #ifndef TT_GEMM_PF_FWD
 #define TT_GEMM_PF_FWD 2
 #endif
@@ -338,6 +341,20 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int zsplit, c
   float* C = p.C + (int64_t)zsplit * p.slab_stride;
   const int64_t n = n0 + wn * 32 + ln;
   uint32_t posbits = 0u;                        // fwd: (C > 0) of this lane's 16 elements
+#if TT_GEMM_WIDE_STORE
+  // The output tile leaves through LDS: accumulators -> [64][64 + 4] floats in the (now idle) operand buffers -> 16 bytes
+  // per lane, a wave-instruction storing four whole 256-byte row pieces.  Stored straight from the accumulators a wave
+  // needs 16 instructions of 4 bytes per lane (two 128-byte pieces each) and the epilogue is store-ISSUE-bound: in the fused
+  // tower kernel the same change took the output stores from 3.7 to 1.1 us (r03 stamps, csrc/tower.hip).
+  constexpr int LSO = BN + 4;
+  // (rows of 16-byte pieces need N and ldc to be multiples of 4 floats: true for every tower layer - k % 4 == 0 and n % 4 == 0
+  // are API requirements - but not for the hard-negative search's [nq][nc] scratch matrix, which keeps the 4-byte stores)
+  const bool wide = ((p.ldc | p.N) & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15u) == 0;
+  if (wide) __syncthreads();                    // every wave has read its last fragments of the operand tiles
+#else
+  constexpr bool wide = false;
+  constexpr int LSO = 1;
+#endif
   if (n < p.N) {
     const float bias = p.bias != nullptr ? p.bias[n] : 0.f;
 #pragma unroll
@@ -356,11 +373,22 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int zsplit, c
         } else {
           if (p.mask_src != nullptr) v = p.mask_src[m * p.ldc + n] > 0.f ? v * p.mask_scale : 0.f;
         }
-        C[m * p.ldc + n] = v;
+        if (wide) smem[(wm * 32 + tt::acc_row(reg, h)) * LSO + wn * 32 + ln] = v;
+        else C[m * p.ldc + n] = v;
         if constexpr (A_KC && !B_KC) posbits |= (v > 0.f ? 1u : 0u) << reg;
       }
     }
   }
+#if TT_GEMM_WIDE_STORE
+  if (wide) __syncthreads();
+#pragma unroll
+  for (int j = 0; wide && j < BM * BN / 4 / 256; ++j) {
+    const int f = tid + 256 * j;
+    const int row = f / (BN / 4), c4 = f % (BN / 4);
+    const int64_t m = m0 + row, nn = n0 + 4 * c4;
+    if (m < p.M && nn < p.N) *reinterpret_cast<f32x4*>(C + m * p.ldc + nn) = *reinterpret_cast<const f32x4*>(smem + row * LSO + 4 * c4);
+  }
+#endif
   if constexpr (A_KC && !B_KC) {
     if (p.relu_bits != nullptr) {      // (workgroup-uniform) one ballot per register: low half = tile row acc_row(reg, 0), high = (reg, 1)
       uint32_t myword = 0u;

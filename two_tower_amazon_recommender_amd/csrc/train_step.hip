@@ -1,6 +1,7 @@
 // tt_train_step_f32 - the whole train step behind ONE C entry (include/twotower_hip.h, ABI v8).  Host code only: it calls the
 // library's own entry points in the order a caller would, so the arithmetic and the launches are theirs, bit for bit.
 #include "common.h"
+#include <cstdlib>
 
 extern "C" int tt_train_step_f32(const tt_train_step* s, tt_stream_t stream) {
   TT_REQUIRE(s != nullptr, "tt_train_step_f32: null step");
@@ -12,7 +13,16 @@ extern "C" int tt_train_step_f32(const tt_train_step* s, tt_stream_t stream) {
   TT_REQUIRE(s->n_segs >= 1 && s->n_segs <= TT_MAX_DENSE_SEGS, "tt_train_step_f32: 1..%d dense segments", TT_MAX_DENSE_SEGS);
   const int L = s->n_layers;
   int rc;
-  for (int l = 0; l < L; ++l) {
+  // two-layer towers: both layers of both towers in one launch (csrc/tower.hip); TT_FUSED_TOWER=0 keeps the two launches (A/B)
+  static const bool fused_tower = std::getenv("TT_FUSED_TOWER") == nullptr || std::atoi(std::getenv("TT_FUSED_TOWER")) != 0;
+  const bool fwd2 = fused_tower && L == 2 && tt_tower_fwd2_supported(s->batch, s->dims[0], s->dims[1], s->dims[2]);
+  if (fwd2) {
+    const bool drop = s->dropout_rate > 0.f;
+    rc = tt_tower_fwd2_batched_f32(s->fwd[0], s->fwd[1], 2, s->batch, s->dims[0], s->dims[1], s->dims[2], drop ? s->dropout_rate : 0.f,
+                                   s->dropout_seed, drop ? s->dropout_row0 * (uint64_t)s->dims[1] : 0ull, stream);
+    if (rc != TT_OK) return rc;
+  }
+  for (int l = 0; l < L && !fwd2; ++l) {
     const bool hidden = l < L - 1;
     const bool drop = hidden && s->dropout_rate > 0.f;
     rc = tt_dense_fwd_batched_f32(s->fwd[l], 2, s->batch, s->dims[l], s->dims[l + 1], hidden ? 1 : 0, drop ? s->dropout_rate : 0.f,

@@ -403,6 +403,34 @@ def dense_fwd2(xs, ws, bs, ys, relu: bool, dropout=None, lookups=None, relu_bits
                "tt_dense_fwd_batched_f32")
 
 
+def tower_fwd2_supported(m: int, k0: int, h: int, n1: int) -> bool:
+    """Shapes the fused two-layer tower forward takes (csrc/tower.hip).  TT_FUSED_TOWER=0 switches it off (A/B)."""
+    import os
+    if os.environ.get("TT_FUSED_TOWER", "1") == "0":
+        return False
+    return bool(_lib.load().tt_tower_fwd2_supported(m, k0, h, n1))
+
+
+def tower_fwd2(xs, w0s, b0s, hs, h_bits, w1s, b1s, ys, dropout=None, lookups=None):
+    """h = relu(x @ w0 + b0) [dropout], y = h @ w1 + b1 for both towers in ONE launch (the hidden tile stays in LDS; h and
+    its sign bits are still written for the backward pass).  Bit-identical to dense_fwd2 called for each layer.
+    dropout = (rate, seed, (tid_a, tid_b), offset) for the hidden layer; lookups as in dense_fwd2."""
+    m, k0 = _in_shape(xs[0], None if lookups is None else lookups[0])
+    h, n1 = w0s[0].shape[1], w1s[0].shape[1]
+    rate, seed, tids, off = dropout if dropout is not None else (0.0, 0, (0, 0), 0)
+    for i in range(2):
+        _chk(w0s[i], torch.float32, "w0", 2); _chk(w1s[i], torch.float32, "w1", 2)
+        _chk(hs[i], torch.float32, "h", 2); _chk(ys[i], torch.float32, "y", 2)
+        if tuple(w0s[i].shape) != (k0, h) or tuple(w1s[i].shape) != (h, n1) or tuple(hs[i].shape) != (m, h) or tuple(ys[i].shape) != (m, n1):
+            raise RuntimeError("tower_fwd2: shape mismatch between the layers' weights and buffers")
+        _chk_bits(h_bits[i], m, h, "tower_fwd2: h_bits")
+    l0 = (_lib.DenseFwdArgs * 2)(*[_lib.DenseFwdArgs(None if lookups is not None else _p(xs[i]), _p(w0s[i]), _p(b0s[i]), _p(hs[i]),
+                                                     tids[i], lookups[i] if lookups is not None else _no_lookup(), _p(h_bits[i]))
+                                   for i in range(2)])
+    l1 = (_lib.DenseFwdArgs * 2)(*[_lib.DenseFwdArgs(_p(hs[i]), _p(w1s[i]), _p(b1s[i]), _p(ys[i]), 0, _no_lookup(), None) for i in range(2)])
+    _lib.check(_lib.load().tt_tower_fwd2_batched_f32(l0, l1, 2, m, k0, h, n1, rate, seed, off, _stream()), "tt_tower_fwd2_batched_f32")
+
+
 def dense_bwd2(xs, ws, dzs, dxs, dx_relu_srcs, dw_slabs, db_slabs, dx_scale: float = 1.0, lookups=None, dx_relu_bits=(None, None)):
     """Backward of layer l of both towers: one launch (dx and dw+db tiles side by side; dx only / dw only: one each)."""
     m, k = _in_shape(xs[0], None if lookups is None else lookups[0])

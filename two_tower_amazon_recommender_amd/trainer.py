@@ -168,6 +168,16 @@ def towers_forward(ut: "Tower", it: "Tower", dropout=None, lookups=None):
     """Both towers layer by layer, one launch per layer (the towers have identical shapes).
     dropout = (rate, seed, first_global_row) in training, None at inference.
     lookups = (user lookup, item lookup): layer 0 gathers its input rows from the embedding tables itself."""
+    if ut.n_layers == 2 and ops.tower_fwd2_supported(ut.acts[1].shape[0], ut.dims[0], ut.dims[1], ut.dims[2]):
+        # both layers of both towers in ONE launch: the hidden tile never leaves the CU between the layers (csrc/tower.hip)
+        d = None
+        if dropout is not None and dropout[0] > 0.0:
+            rate, seed, row0 = dropout
+            d = (rate, seed, (TID_DROPOUT_BASE, TID_DROPOUT_BASE + 1), row0 * ut.dims[1])
+        ops.tower_fwd2((ut.acts[0], it.acts[0]), (ut.w[0], it.w[0]), (ut.b[0], it.b[0]), (ut.acts[1], it.acts[1]),
+                       (ut.bits[1], it.bits[1]), (ut.w[1], it.w[1]), (ut.b[1], it.b[1]), (ut.acts[2], it.acts[2]),
+                       dropout=d, lookups=lookups)
+        return ut.acts[-1], it.acts[-1]
     for l in range(ut.n_layers):
         hidden = l < ut.n_layers - 1
         d = None
