@@ -96,7 +96,9 @@ def cpu_share() -> int:
     return max(1, min(n, 16))
 
 
-PMC_FILE = "profiles/r02_pmc_cfg3_sgd.json"     # rocprofv3 --pmc passes of round r02 (scratch/prof_pmc.sh + pmc_summary.py)
+# rocprofv3 --pmc passes (scratch/prof_pmc.sh + pmc_summary.py) of the newest round that committed one
+PMC_FILE = next((f for f in ("profiles/r03_pmc_cfg3_sgd.json", "profiles/r02_pmc_cfg3_sgd.json")
+                 if os.path.exists(os.path.join(ROOT, f))), "profiles/r02_pmc_cfg3_sgd.json")
 
 
 def pmc_traffic(tag):
@@ -235,7 +237,9 @@ def main():
         unfused = {t: _lib.profile_read(t, 2 * n_layers * detail_steps + 8)[0]
                    for t in ("dense_fwd", "dense_bwd", "gather", "sparse_apply", "sparse_plan", "dense_update")}
         trainer.fuse_lookup = trainer.fuse_optimizer = True
-        f_l0 = mean(prof["dense_fwd"][0::n_layers]) - mean(unfused["dense_fwd"][0::n_layers])
+        # (forward launches per step: n_layers, or ONE when the two-layer tower forward is fused - csrc/tower.hip - in both passes)
+        fps = max(len(prof["dense_fwd"]) // detail_steps, 1)
+        f_l0 = mean(prof["dense_fwd"][0::fps]) - mean(unfused["dense_fwd"][0::fps])
         b_l0 = mean(prof["dense_bwd"][n_layers - 1::n_layers]) - mean(unfused["dense_bwd"][n_layers - 1::n_layers])
         lookup_us = (f_l0 + b_l0) * 1e3
     # ---- second, separately labelled measurement: the same train step with the scorer's matrix products in the
@@ -284,7 +288,9 @@ def main():
         a = alg_flops / t / 1e12
         return {"bound": "mfma", "kernel": name, "achieved": a, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": a / MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                "traffic_source": f"{PMC_FILE} (committed rocprofv3 --pmc passes of round r02; not re-measured in this run)",
+                "traffic_source": f"{PMC_FILE} (committed rocprofv3 --pmc passes; not re-measured in this run)",
+                "traffic_note": "4*B^2 bytes each way (268 MB at B 8192) are the raw dot products pass 1 keeps for pass 2 - "
+                                "24-27x the algorithmic q/c/gradient bytes, by design: it replaces a second GEMM1 (DESIGN.md section 4)",
                 "avg_launch_us": t * 1e6, "dtype": "f32-input MFMA",
                 "executed_tflops": exec_flops / t / 1e12, "executed_frac": exec_flops / t / 1e12 / MFMA_F32_PEAK_TFLOPS}
 
@@ -373,6 +379,21 @@ def main():
                          "algorithmic_bytes": gs_bytes},
         "loss_per_pair": loss / batch,
     }
+    # the tower GEMMs (K3): forward + dx + dw of every layer of both towers = 3 * 2*B*sum(in*out) * 2 FLOPs,
+    # over the hipEvent-bracketed launches of the untimed detail pass (each bracket adds ~3 us: rocprof figures in profiles/)
+    dims_all = [dim] + list(cfg.user_dims)
+    gemm_flops = 3.0 * 2.0 * batch * sum(a * b for a, b in zip(dims_all[:-1], dims_all[1:])) * 2.0
+    t_gemm = (per_step("dense_fwd") + per_step("dense_bwd")) * 1e-3
+    if t_gemm > 0 and cfg.symmetric:
+        out["roofline_gemm"] = {
+            "bound": "mfma", "kernel": "tower GEMMs: " + ("tower_fwd2_kernel (both layers of both towers, one launch) + " if
+                                                           len(tower_dims) == 2 and ops.tower_fwd2_supported(batch, *dims_all) else
+                                                           "gemm_kernel per layer (both towers per launch) + ")
+                                       + "gemm_bwd_kernel per layer (dx + dw + db tiles of both towers in one launch)",
+            "achieved": gemm_flops / t_gemm / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": gemm_flops / t_gemm / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+            "launches_per_step": (len(prof["dense_fwd"]) + len(prof["dense_bwd"])) // max(detail_steps, 1),
+            "us_per_step": t_gemm * 1e6, "algorithmic_gflop": gemm_flops / 1e9, "dtype": "f32-input MFMA"}
     if alt is not None:
         alt_steps, dta, tf_, tb_, aloss = alt
         # per launch of the FUSED pass: GEMM1 = 2*B^2*D algorithmic FLOPs at 6 bf16 products each, GEMM2 = 2*B^2*D at 3

@@ -188,6 +188,26 @@ def run_distributed(args, rank, world, dev):
                         "achieved": a, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": a / MFMA_F32_PEAK_TFLOPS,
                         "traffic": None, "avg_launch_us": t * 1e6, "samples": len(fused), "dtype": "f32-input MFMA"}
         tower = f"{dim}->" + "->".join(map(str, tower_dims))
+        # How to read the curve: per-GPU work at this N against N = 1.  With GLOBAL negatives every GPU scores its B_local
+        # queries against all N*B_local candidates, so in the weak-scaled family (cfg3) the scorer's FLOPs per GPU grow N-fold
+        # by construction - a flat pairs/s-per-GPU curve would be super-linear.  ms_expected_from_n1 = the committed N = 1
+        # kernel times (profiles/), the scorer part rescaled by that factor, + this run's measured stream time of every
+        # collective of a step: what the step would take if nothing but the model's terms changed.
+        work_model = None
+        try:
+            n1 = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_n1_reference.json")))[name]
+            factor = (nc / batch) * (batch / n1["batch_per_gpu"]) ** 2      # Bq*Bc*D against the N = 1 launch's
+            other = n1["ms_per_step"] - n1["scorer_ms"]
+            if name != "cfg3":
+                other *= batch / n1["batch_per_gpu"]                        # towers / lookup / optimizer scale with the local batch
+            coll_ms = sum(v["us_per_call"] * v["calls_per_step"] for v in coll.values()) * 1e-3 if coll else 0.0
+            work_model = {"scorer_flops_per_gpu_vs_n1": factor, "n1_reference": n1,
+                          "collectives_ms_per_step_measured": coll_ms,
+                          "ms_expected_from_n1": n1["scorer_ms"] * factor + other + coll_ms,
+                          "note": "a model: N = 1 kernel times rescaled + measured per-collective stream time; exposed waits "
+                                  "between ranks are what the difference to ms_per_step shows"}
+        except (OSError, KeyError, ValueError, ZeroDivisionError, TypeError):
+            pass
         out = {
             "metric": "user-item pairs/sec (train step) + embedding-gather HBM GB/s, 1/2/4/8 MI355X",
             "value": world * batch * args.steps / sec, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
@@ -205,6 +225,7 @@ def run_distributed(args, rank, world, dev):
                        "negatives": negatives},
             "roofline": roofline, "cpu_baseline": None,
             "collectives": coll or None,
+            "work_model": work_model,
             "other_negatives": None if alt is None else {
                 "negatives": other, "value": world * batch * alt[0] / alt[1], "unit": "pairs/s", "ms_per_step": alt[1] / alt[0] * 1e3,
                 "steps": alt[0], "note": "same run, same steps, in-batch negatives switched; NOT the headline value"},

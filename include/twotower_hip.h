@@ -462,6 +462,13 @@ int tt_retrieval_fwd_bwd_bf16x3_f32(const float* q, const float* c, int64_t nq, 
 int tt_retrieval_rank_f32(const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
                           float inv_temperature, const float* cand_prob, const int64_t* pos_index,
                           void* workspace, int64_t workspace_bytes, int32_t* rank, tt_stream_t stream);
+/* The same metric pass on the IN-BATCH candidates - tfrs.tasks.Retrieval(batch_metrics=[top-k categorical accuracy]):
+ * rank[i] = number of candidates j != i + diag_offset whose logit (after temperature, -log clip(cand_prob) and, with
+ * cand_ids, accidental-hit removal: the scores the loss sees) is strictly above the positive's; top-k accuracy =
+ * mean(rank < k).  Workspace: tt_retrieval_rank_workspace_bytes(nq, nc, dim).                                        */
+int tt_retrieval_batch_rank_f32(const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim, int64_t diag_offset,
+                                float inv_temperature, const float* cand_prob, const int64_t* cand_ids,
+                                void* workspace, int64_t workspace_bytes, int32_t* rank, tt_stream_t stream);
 
 #ifdef __cplusplus
 }

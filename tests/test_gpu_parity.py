@@ -948,6 +948,54 @@ def test_retrieval_rank_and_topk_metrics(dev, nq, nc, d, use_p):
     assert res["recall@100"] >= res["recall@10"] >= res["recall@1"]
 
 
+@pytest.mark.parametrize("nq,nc,d,off,opts", [(512, 512, 64, 0, {}), (300, 700, 128, 400, dict(use_p=True)),
+                                              (1000, 1000, 32, 0, dict(use_ids=True)), (777, 800, 256, 23, dict(use_p=True, use_ids=True))])
+def test_retrieval_task_batch_metrics_topk_accuracy(dev, nq, nc, d, off, opts):
+    """Retrieval(batch_metrics=[TopKCategoricalAccuracy(k)]): in-batch top-k accuracy = mean(rank < k) with the rank taken
+    under the scores the loss sees - temperature, -log clip(p), accidental hits removed - pinned between f64 +-eps bounds of
+    the oracle; the loss returned by the same call is unchanged."""
+    from two_tower_amazon_recommender_amd.metrics import TopKCategoricalAccuracy
+    from two_tower_amazon_recommender_amd.tasks import Retrieval
+    q = synth.uniform_f32(81, 1, nq * d, -0.3, 0.6).reshape(nq, d)
+    c = synth.uniform_f32(81, 2, nc * d, -0.3, 0.6).reshape(nc, d)
+    q[::2] += 0.5 * c[off:off + nq][::2]                           # half of the positives rank well
+    p = synth.uniform_f32(81, 4, nc, 0.001, 0.3) if opts.get("use_p") else None
+    ids = synth.ids_powerlaw(81, 5, nc, max(nc // 4, 2)) if opts.get("use_ids") else None
+    ms = [TopKCategoricalAccuracy(1), TopKCategoricalAccuracy(10)]
+    task = Retrieval(temperature=0.1, batch_metrics=ms, remove_accidental_hits=ids is not None)
+    kw = dict(candidate_sampling_probability=None if p is None else T(p, dev), candidate_ids=None if ids is None else T(ids, dev),
+              diag_offset=off)
+    loss = task(T(q, dev), T(c, dev), **kw)
+    rl, _, _ = tt.retrieval_loss(q, c, temperature=0.1, candidate_sampling_probability=p, candidate_ids=ids,
+                                 remove_accidental_hits=ids is not None, diag_offset=off)
+    assert abs(loss.item() - rl) <= 1e-4 * abs(rl)
+    # oracle ranks on the masked logits: accidental hits (same id as the positive, not the positive) never outrank it
+    s = tt.retrieval_logits(np.asarray(q, np.float64), np.asarray(c, np.float64), 0.1, p)
+    pos_col = np.arange(nq) + off
+    if ids is not None:
+        same = ids[None, :] == ids[pos_col][:, None]
+        same[np.arange(nq), pos_col] = False
+        s[same] = -np.inf
+    pos = s[np.arange(nq), pos_col].copy()
+    s[np.arange(nq), pos_col] = -np.inf
+    lo, hi = (s > (pos + 1e-5)[:, None]).sum(1), (s > (pos - 1e-5)[:, None]).sum(1)
+    rank = torch.ops.twotower.retrieval_batch_rank(T(q, dev), T(c, dev), kw["candidate_sampling_probability"], kw["candidate_ids"] if ids is not None else None,
+                                                   10.0, off).cpu().numpy()
+    assert (rank >= lo).all() and (rank <= hi).all()
+    for m in ms:
+        assert (hi < m.k).mean() - 1e-12 <= m.result() <= (lo < m.k).mean() + 1e-12
+    assert ms[1].result() >= ms[0].result() > 0.0
+    # compute_batch_metrics=False leaves the metric alone; weights give the Keras weighted mean
+    before = ms[0].result()
+    task(T(q, dev), T(c, dev), compute_batch_metrics=False, **kw)
+    assert ms[0].result() == before
+    m2 = TopKCategoricalAccuracy(3)
+    w = synth.uniform_f32(81, 6, nq, 0.5, 1.5)
+    Retrieval(temperature=0.1, batch_metrics=[m2])(T(q, dev), T(c, dev), sample_weight=T(w, dev), diag_offset=off)
+    r3 = torch.ops.twotower.retrieval_batch_rank(T(q, dev), T(c, dev), None, None, 10.0, off).cpu().numpy()
+    assert abs(m2.result() - float(((r3 < 3) * w.astype(np.float64)).sum() / w.astype(np.float64).sum())) < 1e-9
+
+
 # ----------------------------------------------------------------------------------- a6/a7 id encoding on the GPU
 def test_gpu_id_encoder_reproduces_the_reference_golden(dev):
     """PINNED: the golden file was produced by the reference's own create_user_item_mappings / LabelEncoder

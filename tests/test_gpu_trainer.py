@@ -760,6 +760,7 @@ def test_custom_ops_pass_opcheck_and_match_the_oracle(dev):
     opc(torch.ops.twotower.retrieval_loss, (q.detach(), c.detach(), None, None, None, 1.0, 0, 5))
     opc(torch.ops.twotower.retrieval_loss_value, (q.detach(), c.detach(), w, None, None, 10.0, 0, 0))
     opc(torch.ops.twotower.retrieval_rank, (q.detach(), c.detach(), torch.arange(b, device=dev), p, 10.0))
+    opc(torch.ops.twotower.retrieval_batch_rank, (q.detach(), c.detach(), p, ids, 10.0, 0))
     table = torch.rand(500, d, generator=g).to(dev)
     opc(torch.ops.twotower.embedding_gather, (table, torch.randint(0, 500, (77,), generator=g).to(dev)))
     x = (torch.rand(b, d, generator=g) - 0.5).to(dev).requires_grad_()

@@ -84,8 +84,17 @@ def test_retrieval_task_argument_errors_mirror_tfrs():
         Retrieval(num_hard_negatives=0)
     with pytest.raises(TypeError):
         Retrieval(metrics=object())                # only metrics.FactorizedTopK(candidates=...) is a metric the task can run
+    with pytest.raises(TypeError):
+        Retrieval(batch_metrics=[object()])        # only metrics.TopKCategoricalAccuracy (rank < k from the fused rank pass);
+                                                   # anything else would need the materialised in-batch score matrix
+    from two_tower_amazon_recommender_amd.metrics import TopKCategoricalAccuracy
+    from two_tower_amazon_recommender_amd.tasks import CategoricalCrossentropy
+    assert len(Retrieval(batch_metrics=[TopKCategoricalAccuracy(1), TopKCategoricalAccuracy(5)]).batch_metrics) == 2
+    Retrieval(loss=CategoricalCrossentropy(from_logits=True, reduction="SUM"))       # the TFRS default, spelled out
+    with pytest.raises(NotImplementedError, match="score matrix"):
+        Retrieval(loss=CategoricalCrossentropy(from_logits=False))
     with pytest.raises(NotImplementedError):
-        Retrieval(batch_metrics=[object()])        # would need the materialised in-batch score matrix
+        Retrieval(loss=object())
     with pytest.raises(TypeError):
         Retrieval(loss_metrics=[object()])
     with pytest.raises(ValueError):

@@ -452,7 +452,9 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? ((MODE ==
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const float v = __builtin_fmaf(X[reg], p.c1, ac[reg]);
-        cnt += (v > ar && tt::acc_row(reg, 0) != dloc) ? 1 : 0;
+        bool above = v > ar && tt::acc_row(reg, 0) != dloc;
+        if constexpr (HAS_IDS) above = above && !dup[reg];          // an accidental hit is not a competitor (tfrs: its logit is -inf)
+        cnt += above ? 1 : 0;
       }
     } else if constexpr (MODE == MODE_FWD) {
       float t2[16];
@@ -934,11 +936,12 @@ __global__ __launch_bounds__(256) void fused_combine_kernel(const float* __restr
 // thr[r] = c1 * <q_r, c_pos(r)> + bias[pos(r)]  (log2 domain): the positive's logit, 32 lanes per row
 __global__ __launch_bounds__(256) void pos_logit_kernel(const f32x4* __restrict__ q, const f32x4* __restrict__ c,
                                                         const int64_t* __restrict__ pos_idx, const float* __restrict__ bias,
-                                                        int64_t nq, int64_t nc, int d4, float c1, float* __restrict__ thr) {
+                                                        int64_t nq, int64_t nc, int d4, float c1, float* __restrict__ thr,
+                                                        int64_t diag) {
   const int64_t row = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
   const int lane = threadIdx.x & 31;
   if (row >= nq) return;
-  const int64_t pc = pos_idx[row];
+  const int64_t pc = pos_idx != nullptr ? pos_idx[row] : row + diag;
   float acc = 0.f;
   if (pc >= 0 && pc < nc) {
     for (int k = lane; k < d4; k += 32) {
@@ -1513,7 +1516,7 @@ extern "C" int tt_retrieval_rank_f32(const float* q, const float* c, int64_t nq,
   }
   const float* biasp = cand_prob != nullptr ? bias : nullptr;
   hipLaunchKernelGGL(pos_logit_kernel, dim3((unsigned)((nq + 7) / 8)), dim3(256), 0, stream, reinterpret_cast<const f32x4*>(q),
-                     reinterpret_cast<const f32x4*>(c), pos_index, biasp, nq, nc, dim / 4, c1, thr);
+                     reinterpret_cast<const f32x4*>(c), pos_index, biasp, nq, nc, dim / 4, c1, thr, (int64_t)0);
   if ((rc = tt::check_launch("pos_logit")) != TT_OK) return rc;
   ScoreArgs a{};
   a.R = q; a.K = c; a.n_r = nq; a.n_c = nc; a.diag = 0;
@@ -1524,6 +1527,52 @@ extern "C" int tt_retrieval_rank_f32(const float* q, const float* c, int64_t nq,
   a.c_per_split = align_up((nc + a.nsplit - 1) / a.nsplit, 32);
   a.part_cnt = part_cnt;
   if ((rc = dispatch_score<MODE_RANK>(dim, a, false, stream)) != TT_OK) return rc;
+  hipLaunchKernelGGL(rank_combine_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, part_cnt, nq, a.nsplit, rank);
+  return tt::check_launch("rank_combine");
+}
+
+// In-batch rank (tfrs.tasks.Retrieval(batch_metrics=...): Keras top-k categorical accuracy over the IN-BATCH score matrix):
+// rank[i] = number of in-batch candidates j != i + diag_offset whose logit - after temperature, sampling-probability
+// correction and accidental-hit removal, exactly the scores the loss sees - is strictly above the positive's.  Top-k
+// accuracy = mean(rank < k): no [nq, nc] score matrix is materialised, it is the metric pass above run on the batch.
+extern "C" int tt_retrieval_batch_rank_f32(const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim, int64_t diag_offset,
+                                           float inv_temperature, const float* cand_prob, const int64_t* cand_ids,
+                                           void* workspace, int64_t workspace_bytes, int32_t* rank, tt_stream_t stream_) {
+  int rc;
+  TT_REQUIRE(q && c && workspace && rank, "tt_retrieval_batch_rank_f32: null pointer");
+  TT_REQUIRE(nq > 0 && nc > 0, "tt_retrieval_batch_rank_f32: nq and nc must be positive");
+  TT_REQUIRE(diag_offset >= 0 && nq + diag_offset <= nc, "tt_retrieval_batch_rank_f32: need 0 <= diag_offset and nq + diag_offset <= nc");
+  TT_REQUIRE(dim == 32 || dim == 64 || dim == 128 || dim == 256, "tt_retrieval_batch_rank_f32: dim %d not in {32,64,128,256}", dim);
+  TT_REQUIRE(tt::aligned16(q) && tt::aligned16(c), "tt_retrieval_batch_rank_f32: q/c must be 16-byte aligned");
+  TT_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0, "tt_retrieval_batch_rank_f32: workspace must be 256-byte aligned");
+  const WsLayout w = ws_layout(nq, nc, dim);
+  if (workspace_bytes < w.off_pl)
+    return tt::fail(TT_ERR_WORKSPACE, "tt_retrieval_batch_rank_f32: workspace %lld < %lld bytes", (long long)workspace_bytes,
+                    (long long)w.off_pl);
+  hipStream_t stream = tt::as_stream(stream_);
+  char* ws = static_cast<char*>(workspace);
+  float* bias = reinterpret_cast<float*>(ws + w.off_bias);
+  float* thr = reinterpret_cast<float*>(ws + w.off_aq);
+  int32_t* part_cnt = reinterpret_cast<int32_t*>(ws + w.off_pm);
+  const float c1 = kLog2e * inv_temperature;
+  if (cand_prob != nullptr) {
+    hipLaunchKernelGGL(prob_bias_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, stream, cand_prob, bias, nc);
+    if ((rc = tt::check_launch("prob_bias")) != TT_OK) return rc;
+  }
+  const float* biasp = cand_prob != nullptr ? bias : nullptr;
+  hipLaunchKernelGGL(pos_logit_kernel, dim3((unsigned)((nq + 7) / 8)), dim3(256), 0, stream, reinterpret_cast<const f32x4*>(q),
+                     reinterpret_cast<const f32x4*>(c), static_cast<const int64_t*>(nullptr), biasp, nq, nc, dim / 4, c1, thr, diag_offset);
+  if ((rc = tt::check_launch("pos_logit")) != TT_OK) return rc;
+  ScoreArgs a{};
+  a.R = q; a.K = c; a.n_r = nq; a.n_c = nc; a.diag = diag_offset;
+  a.c1 = c1;
+  a.a_r = thr; a.a_c = biasp;
+  a.id_r = cand_ids != nullptr ? cand_ids + diag_offset : nullptr;
+  a.id_c = cand_ids;
+  a.nsplit = w.ns_q;
+  a.c_per_split = align_up((nc + a.nsplit - 1) / a.nsplit, 32);
+  a.part_cnt = part_cnt;
+  if ((rc = dispatch_score<MODE_RANK>(dim, a, cand_ids != nullptr, stream)) != TT_OK) return rc;
   hipLaunchKernelGGL(rank_combine_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, part_cnt, nq, a.nsplit, rank);
   return tt::check_launch("rank_combine");
 }

@@ -58,3 +58,37 @@ class FactorizedTopK:
             out[f"recall@{k}"] = h
             out[f"ndcg@{k}"] = d          # one relevant item per query: the ideal DCG is 1
         return out
+
+
+class TopKCategoricalAccuracy:
+    """In-batch top-k accuracy - the role of ``tf.keras.metrics.TopKCategoricalAccuracy(k)`` in
+    ``tfrs.tasks.Retrieval(batch_metrics=[...])``: the share of queries whose positive is among the k highest-scoring
+    candidates OF THE BATCH (ties at the boundary count as inside, like ``tf.math.in_top_k``).  It consumes the ranks the
+    fused metric pass produces (``torch.ops.twotower.retrieval_batch_rank``): no [queries x candidates] score matrix."""
+
+    def __init__(self, k: int = 5, name: str | None = None):
+        if k < 1:
+            raise ValueError("k must be >= 1")
+        self.k = int(k)
+        self.name = name or f"top_{self.k}_categorical_accuracy"
+        self.reset_state()
+
+    def reset_state(self):
+        self._hits = None
+        self._n = 0
+
+    def update_state_from_ranks(self, rank: torch.Tensor, sample_weight: torch.Tensor | None = None):
+        inside = (rank < self.k).to(torch.float64)
+        if sample_weight is not None:                    # Keras: a weighted mean
+            w = sample_weight.to(torch.float64)
+            hits, n = (inside * w).sum(), w.sum()
+        else:
+            hits, n = inside.sum(), torch.tensor(float(rank.numel()), dtype=torch.float64, device=rank.device)
+        self._hits = hits if self._hits is None else self._hits + hits
+        self._n = n if isinstance(self._n, int) and self._n == 0 else self._n + n
+
+    def result(self) -> float:
+        if self._hits is None:
+            return 0.0
+        return float((self._hits / self._n).item())
+

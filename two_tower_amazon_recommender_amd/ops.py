@@ -605,6 +605,21 @@ def retrieval_rank(q, c, inv_temperature: float, pos_index, workspace=None, cand
     return out
 
 
+def retrieval_batch_rank(q, c, inv_temperature: float, cand_prob=None, cand_ids=None, diag_offset: int = 0, workspace=None, out=None):
+    """In-batch rank of every query's positive (candidate i + diag_offset) under the scores the loss sees - temperature,
+    sampling-probability correction, accidental hits removed (int32 [nq]); top-k accuracy = mean(rank < k)."""
+    _chk_retrieval(q, c, None, cand_prob, cand_ids)
+    nq, nc, d = q.shape[0], c.shape[0], q.shape[1]
+    if workspace is None:
+        workspace = torch.empty(retrieval_rank_workspace_bytes(nq, nc, d), dtype=torch.uint8, device=q.device)
+    if out is None:
+        out = torch.empty(nq, dtype=torch.int32, device=q.device)
+    lib = _lib.load()
+    _lib.check(lib.tt_retrieval_batch_rank_f32(_p(q), _p(c), nq, nc, d, diag_offset, inv_temperature, _p(cand_prob), _p(cand_ids),
+                                               _p(workspace), workspace.numel(), _p(out), _stream()), "tt_retrieval_batch_rank_f32")
+    return out
+
+
 def retrieval_hard_negative_thresholds(q, c, inv_temperature: float, k: int, workspace, cand_prob=None, cand_ids=None,
                                        diag_offset: int = 0, scratch=None, out=None):
     """Per-query thresholds for ``num_hard_negatives = k`` (pass as ``hard_thr`` to the loss entry points)."""

@@ -10,12 +10,16 @@ both gradients in the fused two-pass form, 6*Bq*Bc*D executed FLOPs, gradients s
 ``torch.ops.twotower.retrieval_loss_value`` (no gradient needed: one statistics pass) — ``torch_ops.py``.
 
 Differences from TFRS, all loud:
-  * ``loss`` must be None (the TFRS default: CategoricalCrossentropy(from_logits=True, reduction=SUM));
+  * ``loss`` must be None or ``tasks.CategoricalCrossentropy(from_logits=True, reduction="sum")`` - the TFRS default, the
+    one loss the fused kernels implement; anything else (hinge / pairwise / MSE losses of tfrs.losses, or another
+    reduction) needs the [queries x candidates] score matrix and raises NotImplementedError;
   * ``metrics`` takes a ``metrics.FactorizedTopK`` built WITH its candidate corpus (``FactorizedTopK(candidates=...)``);
     it is updated when ``compute_metrics`` is true, and ``candidate_ids`` must then be the int64 index of every
     candidate in that corpus (the reference's ``item_idx``); ``loss_metrics`` takes objects with
-    ``update_state(loss)``; ``batch_metrics`` (metrics over the in-batch score matrix, which the fused kernels never
-    materialise) raises NotImplementedError;
+    ``update_state(loss)``; ``batch_metrics`` takes ``metrics.TopKCategoricalAccuracy(k)`` objects (the Keras metric TFRS
+    users pass there): in-batch top-k accuracy is ``rank < k`` from one fused rank pass over the batch's candidates, under
+    the scores the loss sees (temperature, sampling-probability correction, accidental hits removed) - no score matrix;
+    any other Keras metric would need the [queries x candidates] matrix and raises TypeError;
   * ``num_hard_negatives=k`` keeps the positive and the k highest-scoring negatives per query
     (tfrs.layers.loss.HardNegativeMining); negatives tied with the k-th are all kept;
   * ``candidate_ids`` must be an int64 tensor (the reference's ids are int64:
@@ -28,17 +32,29 @@ import torch
 from . import torch_ops  # noqa: F401  (registers torch.ops.twotower.*)
 
 
+class CategoricalCrossentropy:
+    """Marker for the TFRS default loss (``tf.keras.losses.CategoricalCrossentropy(from_logits=True, reduction=SUM)``)."""
+
+    def __init__(self, from_logits: bool = True, reduction: str = "sum"):
+        self.from_logits, self.reduction = bool(from_logits), str(reduction).lower()
+
+
 class Retrieval:
     """A factorized retrieval task: in-batch softmax over query x candidate dot products."""
 
     def __init__(self, loss=None, metrics=None, batch_metrics=None, loss_metrics=None, temperature=None,
                  num_hard_negatives=None, remove_accidental_hits=False, name="retrieval_task", precision="f32"):
-        if loss is not None:
-            raise NotImplementedError("Retrieval(loss=...): only the TFRS default loss (categorical cross-entropy "
-                                      "from logits, SUM reduction) is implemented in the HIP path")
-        if batch_metrics is not None:
-            raise NotImplementedError("Retrieval(batch_metrics=...): metrics over the in-batch score matrix need the "
-                                      "[queries x candidates] score matrix, which the fused kernels do not hand out")
+        if loss is not None and not (isinstance(loss, CategoricalCrossentropy) and loss.from_logits and loss.reduction == "sum"):
+            raise NotImplementedError("Retrieval(loss=...): only the TFRS default loss - tasks.CategoricalCrossentropy("
+                                      "from_logits=True, reduction='sum') - is implemented in the HIP path; hinge, pairwise "
+                                      "and pointwise losses (and other reductions) need the [queries x candidates] score "
+                                      "matrix, which the fused kernels never materialise")
+        from .metrics import TopKCategoricalAccuracy
+        self._batch_metrics = list(batch_metrics) if batch_metrics is not None else []
+        for m in self._batch_metrics:
+            if not isinstance(m, TopKCategoricalAccuracy):
+                raise TypeError("Retrieval(batch_metrics=...) takes metrics.TopKCategoricalAccuracy(k) objects (in-batch top-k "
+                                "accuracy from the fused rank pass); other metrics would need the in-batch score matrix")
         if metrics is not None:
             from .metrics import FactorizedTopK
             if not isinstance(metrics, FactorizedTopK) or metrics.candidates is None:
@@ -92,8 +108,17 @@ class Retrieval:
             with torch.no_grad():
                 true_index = candidate_ids[diag_offset:diag_offset + q.shape[0]]
                 self._factorized_metrics.update_state(q.detach(), None, true_index)
+        if compute_batch_metrics and self._batch_metrics:
+            with torch.no_grad():
+                rank = torch.ops.twotower.retrieval_batch_rank(q.detach(), c.detach(), cp, ids, inv_t, diag_offset)
+                for m in self._batch_metrics:
+                    m.update_state_from_ranks(rank, sw)
         for m in self._loss_metrics:
             m.update_state(loss.detach())
         return loss
+
+    @property
+    def batch_metrics(self):
+        return self._batch_metrics
 
     call = __call__

@@ -147,6 +147,19 @@ def _(q, c, true_candidate_index, candidate_sampling_probability, inv_temperatur
     return q.new_empty((q.shape[0],), dtype=torch.int32)
 
 
+@torch.library.custom_op(f"{NS}::retrieval_batch_rank", mutates_args=(), device_types="cuda")
+def retrieval_batch_rank(query_embeddings: Tensor, candidate_embeddings: Tensor, candidate_sampling_probability: Optional[Tensor],
+                         candidate_ids: Optional[Tensor], inv_temperature: float, diag_offset: int) -> Tensor:
+    """In-batch rank of every query's positive under the scores the loss sees (int32): batch top-k accuracy = mean(rank < k)."""
+    return ops.retrieval_batch_rank(query_embeddings.contiguous(), candidate_embeddings.contiguous(), inv_temperature,
+                                    cand_prob=candidate_sampling_probability, cand_ids=candidate_ids, diag_offset=diag_offset)
+
+
+@retrieval_batch_rank.register_fake
+def _(q, c, candidate_sampling_probability, candidate_ids, inv_temperature, diag_offset):
+    return q.new_empty((q.shape[0],), dtype=torch.int32)
+
+
 # --------------------------------------------------------------------------------------------- a2 dense layers
 @torch.library.custom_op(f"{NS}::dense_fwd", mutates_args=(), device_types="cuda")
 def dense_fwd(x: Tensor, w: Tensor, b: Optional[Tensor], relu: bool) -> Tensor:
@@ -213,5 +226,5 @@ def sparse_update_(table: Tensor, accum: Optional[Tensor], grads: Tensor, ids: T
         ops.sparse_adagrad_(table, accum, grads.contiguous(), plan, lr, eps)
 
 
-OPS = ("embedding_gather", "retrieval_loss", "retrieval_loss_value", "retrieval_rank", "dense_fwd", "dense_bwd",
+OPS = ("embedding_gather", "retrieval_loss", "retrieval_loss_value", "retrieval_rank", "retrieval_batch_rank", "dense_fwd", "dense_bwd",
        "sparse_update_")
