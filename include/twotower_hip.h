@@ -454,6 +454,17 @@ int tt_retrieval_fwd_bwd_bf16x3_f32(const float* q, const float* c, int64_t nq, 
                                     const float* hard_thr, float grad_scale, void* workspace, int64_t workspace_bytes,
                                     float* lse, float* per_row, float* loss, float* dq, float* dc,
                                     tt_stream_t stream);
+/* The forward-only (validation) pass and the metric (rank) pass in the same f32-emulated precision: both are pure GEMM1, so
+ * the 6-product bf16 split (2^-24 relative on every logit) is the whole kernel.  Arguments as tt_retrieval_fwd_f32 /
+ * tt_retrieval_rank_f32; dim in {128, 256}.                                                                          */
+int tt_retrieval_fwd_bf16x3_f32(const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
+                                int64_t diag_offset, float inv_temperature, const float* sample_weight,
+                                const float* cand_prob, const int64_t* cand_ids, const float* hard_thr,
+                                void* workspace, int64_t workspace_bytes, float* lse, float* per_row, float* loss,
+                                tt_stream_t stream);
+int tt_retrieval_rank_bf16x3_f32(const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
+                                 float inv_temperature, const float* cand_prob, const int64_t* pos_index,
+                                 void* workspace, int64_t workspace_bytes, int32_t* rank, tt_stream_t stream);
 
 /* Retrieval metrics (configs/data_config.yaml:71 top_k_eval; tfrs.metrics.FactorizedTopK's role):
  * rank[i] = number of candidates j != pos_index[i] with s_ij > s_{i,pos_index[i]} over ALL nc candidates

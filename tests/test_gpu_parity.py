@@ -620,6 +620,12 @@ def run_retrieval(dev, q, c, temperature, w=None, p=None, ids=None, off=0, grad_
     if fused:       # True: exact-f32 fused form; "bf16x3": the f32-emulated split-bf16 form of the same two passes
         ops.retrieval_fwd_bwd(dq_, dc_, 1.0 / temperature, ws, lse, per_row, loss, dq, dc, grad_scale=grad_scale,
                               precision="bf16x3" if fused == "bf16x3" else "f32", **kw)
+        if fused == "bf16x3":     # the forward-only (validation) entry in the same precision: same bars as the f32 one
+            lse2 = torch.empty(nq, device=dev); per2 = torch.empty(nq, device=dev); loss2 = torch.empty(1, device=dev)
+            ops.retrieval_fwd(dq_, dc_, 1.0 / temperature, ws, lse2, per2, loss2, precision="bf16x3", **kw)
+            assert abs(loss2.item() - loss.item()) <= 2e-6 * abs(loss.item()) + 1e-6 * nq
+            assert (lse2 - lse).abs().max().item() <= 2e-5 * max(1.0, lse.abs().max().item())
+            lse, per_row, loss = lse2, per2, loss2           # and the oracle comparison below is made on ITS outputs
     else:
         ops.retrieval_fwd(dq_, dc_, 1.0 / temperature, ws, lse, per_row, loss, **kw)
         ops.retrieval_bwd(dq_, dc_, 1.0 / temperature, ws, lse, dq, dc, grad_scale=grad_scale, **kw)
@@ -708,9 +714,10 @@ def test_retrieval_rank_pass_is_deterministic(dev, nq, nc, d):
     q = T(synth.uniform_f32(45, 1, nq * d, -0.3, 0.6).reshape(nq, d), dev)
     c = T(synth.uniform_f32(45, 2, nc * d, -0.3, 0.6).reshape(nc, d), dev)
     pos = T(synth.ids_uniform(45, 3, nq, nc), dev)
-    ranks = [ops.retrieval_rank(q, c, 10.0, pos).cpu().numpy() for _ in range(5)]
-    for r in ranks[1:]:
-        assert np.array_equal(ranks[0], r)
+    for precision in ("f32", "bf16x3"):
+        ranks = [ops.retrieval_rank(q, c, 10.0, pos, precision=precision).cpu().numpy() for _ in range(5)]
+        for r in ranks[1:]:
+            assert np.array_equal(ranks[0], r)
 
 
 @pytest.mark.parametrize("nq,nc,d", [(160, 160, 128), (1056, 1056, 128), (96, 96, 256), (1056, 1056, 256), (1120, 1184, 64)])
@@ -930,13 +937,26 @@ def test_scatter_rows(dev):
 @pytest.mark.parametrize("nq,nc,d,use_p", [(256, 256, 32, False), (1000, 5000, 64, True), (300, 100, 128, False),
                                            (2048, 50_000, 128, False), (77, 333, 256, True)])
 def test_retrieval_rank_and_topk_metrics(dev, nq, nc, d, use_p):
+    for precision in ("f32",) + (("bf16x3",) if d in (128, 256) else ()):
+        _check_rank_and_topk(dev, nq, nc, d, use_p, precision)
+
+
+def test_retrieval_rank_bf16x3_refuses_other_dims(dev):
+    q = torch.zeros(64, 64, device=dev)
+    with pytest.raises(_lib.TwoTowerError, match="not in"):
+        ops.retrieval_rank(q, q, 1.0, torch.zeros(64, dtype=torch.int64, device=dev), precision="bf16x3")
+    with pytest.raises(ValueError):
+        ops.retrieval_rank(q, q, 1.0, torch.zeros(64, dtype=torch.int64, device=dev), precision="bf16")
+
+
+def _check_rank_and_topk(dev, nq, nc, d, use_p, precision):
     from two_tower_amazon_recommender_amd.metrics import FactorizedTopK
     q = synth.uniform_f32(71, 1, nq * d, -0.3, 0.6).reshape(nq, d)
     c = synth.uniform_f32(71, 2, nc * d, -0.3, 0.6).reshape(nc, d)
     pos = synth.ids_uniform(71, 3, nq, nc)
     q[::3] += 0.4 * c[pos[::3]]                                    # make a third of the positives rank well
     p = synth.uniform_f32(71, 4, nc, 0.001, 0.3) if use_p else None
-    m = FactorizedTopK(ks=(1, 5, 10, 100), temperature=0.1)
+    m = FactorizedTopK(ks=(1, 5, 10, 100), temperature=0.1, precision=precision)
     rank = m.update_state(T(q, dev), T(c, dev), T(pos, dev), None if p is None else T(p, dev)).cpu().numpy()
     lo, hi = tt.retrieval_rank_bounds(q, c, pos, temperature=0.1, candidate_sampling_probability=p)
     assert (rank >= lo).all() and (rank <= hi).all(), (np.abs(rank - lo).max(), (hi - lo).max())

@@ -134,6 +134,8 @@ SIGNATURES = {
     "tt_retrieval_fwd_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "tt_retrieval_rank_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "tt_retrieval_fwd_f32": (C.c_int, [_p, _p, _i64, _i64, _i32, _i64, _f, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p]),
+    "tt_retrieval_fwd_bf16x3_f32": (C.c_int, [_p, _p, _i64, _i64, _i32, _i64, _f, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p]),
+    "tt_retrieval_rank_bf16x3_f32": (C.c_int, [_p, _p, _i64, _i64, _i32, _f, _p, _p, _p, _i64, _p, _p]),
     "tt_retrieval_fwd_bwd_f32": (C.c_int, [_p, _p, _i64, _i64, _i32, _i64, _f, _p, _p, _p, _p, _f, _p, _i64, _p, _p, _p, _p, _p, _p]),
     "tt_retrieval_fwd_bwd_bf16x3_f32": (C.c_int, [_p, _p, _i64, _i64, _i32, _i64, _f, _p, _p, _p, _p, _f, _p, _i64, _p, _p, _p, _p, _p, _p]),
     "tt_retrieval_hard_negative_thresholds_f32": (C.c_int, [_p, _p, _i64, _i64, _i32, _i64, _f, _p, _p, _i32, _p, _i64, _p, _i64, _p, _p]),

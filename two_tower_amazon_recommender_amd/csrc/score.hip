@@ -151,8 +151,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? ((MODE ==
   using G_ = Geo<D, PREC>;
   constexpr int LS = G_::LS, NG = G_::NG, NB = G_::NB, TILE_F = G_::TILE_F, BUF_F = G_::BUF_F;
   constexpr int KS = G_::KS, HALF_B = G_::HALF_B, PIECE_B = G_::PIECE_B;
-  static_assert(PREC == 0 || (D % 128 == 0 && MODE != MODE_FWD && MODE != MODE_RANK),
-                "bf16x3: gradient passes at dim 128 / 256 only");
+  static_assert(PREC == 0 || D % 128 == 0, "bf16x3: dim 128 / 256 only (whole [32][128] bf16 images)");
   constexpr int ROW4 = D / 4;                       // float4 per K row
   constexpr int THREADS = WAVES * 64;
   constexpr int NV = (32 * ROW4 + THREADS - 1) / THREADS;   // staged float4 per thread
@@ -1205,7 +1204,7 @@ int launch_score(const ScoreArgs& a_in, bool has_ids, hipStream_t stream) {
   return go(score_kernel<D, MODE, false, false, W, PREC>);
 }
 
-// bf16x3 gradient passes (MODE_FUSED / MODE_BWD) at the dims whose tiles are whole [32][128] bf16 images
+// bf16x3 passes at the dims whose tiles are whole [32][128] bf16 images
 template <int MODE>
 int dispatch_score_bx3(int32_t dim, const ScoreArgs& a, bool has_ids, hipStream_t stream) {
   switch (dim) {
@@ -1260,11 +1259,11 @@ extern "C" int64_t tt_retrieval_rank_workspace_bytes(int64_t nq, int64_t nc, int
   return ws_layout(nq, nc, dim).off_pl;
 }
 
-extern "C" int tt_retrieval_fwd_f32(const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
-                                    int64_t diag_offset, float inv_temperature, const float* sample_weight,
-                                    const float* cand_prob, const int64_t* cand_ids, const float* hard_thr,
-                                    void* workspace, int64_t workspace_bytes, float* lse, float* per_row, float* loss,
-                                    tt_stream_t stream_) {
+static int retrieval_fwd(int prec, const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
+                         int64_t diag_offset, float inv_temperature, const float* sample_weight,
+                         const float* cand_prob, const int64_t* cand_ids, const float* hard_thr,
+                         void* workspace, int64_t workspace_bytes, float* lse, float* per_row, float* loss,
+                         tt_stream_t stream_) {
   int rc = check_common("tt_retrieval_fwd_f32", q, c, nq, nc, dim, diag_offset, workspace, workspace_bytes);
   if (rc != TT_OK) return rc;
   TT_REQUIRE(lse && per_row && loss, "tt_retrieval_fwd_f32: null output pointer");
@@ -1288,13 +1287,35 @@ extern "C" int tt_retrieval_fwd_f32(const float* q, const float* c, int64_t nq, 
   a.part_m = reinterpret_cast<float*>(ws + w.off_pm);
   a.part_l = reinterpret_cast<float*>(ws + w.off_pl);
   a.pos2 = reinterpret_cast<float*>(ws + w.off_pos);
-  if ((rc = dispatch_score<MODE_FWD>(dim, a, cand_ids != nullptr, stream)) != TT_OK) return rc;
+  rc = prec == 1 ? dispatch_score_bx3<MODE_FWD>(dim, a, cand_ids != nullptr, stream) : dispatch_score<MODE_FWD>(dim, a, cand_ids != nullptr, stream);
+  if (rc != TT_OK) return rc;
   tt::ProfScope prof("score_aux", stream);
   hipLaunchKernelGGL(fwd_combine_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, a.part_m, a.part_l, a.pos2,
                      sample_weight, nq, a.nsplit, lse, per_row);
   if ((rc = tt::check_launch("fwd_combine")) != TT_OK) return rc;
   hipLaunchKernelGGL(sum_rows_kernel, dim3(1), dim3(1024), 0, stream, per_row, nq, loss);
   return tt::check_launch("sum_rows");
+}
+
+extern "C" int tt_retrieval_fwd_f32(const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
+                                    int64_t diag_offset, float inv_temperature, const float* sample_weight,
+                                    const float* cand_prob, const int64_t* cand_ids, const float* hard_thr,
+                                    void* workspace, int64_t workspace_bytes, float* lse, float* per_row, float* loss,
+                                    tt_stream_t stream) {
+  return retrieval_fwd(0, q, c, nq, nc, dim, diag_offset, inv_temperature, sample_weight, cand_prob, cand_ids, hard_thr, workspace,
+                       workspace_bytes, lse, per_row, loss, stream);
+}
+
+// The validation pass with the logits' products on the bf16 matrix cores (the 6-product split of GEMM1: 2^-24 relative,
+// f32 accumulation, f32 softmax): the forward pass is pure GEMM1, so the 6-product form is the whole kernel.  dim in {128, 256}.
+extern "C" int tt_retrieval_fwd_bf16x3_f32(const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
+                                           int64_t diag_offset, float inv_temperature, const float* sample_weight,
+                                           const float* cand_prob, const int64_t* cand_ids, const float* hard_thr,
+                                           void* workspace, int64_t workspace_bytes, float* lse, float* per_row, float* loss,
+                                           tt_stream_t stream) {
+  if (dim != 128 && dim != 256) return tt::fail(TT_ERR_UNSUPPORTED, "tt_retrieval_fwd_bf16x3_f32: dim %d not in {128,256}", dim);
+  return retrieval_fwd(1, q, c, nq, nc, dim, diag_offset, inv_temperature, sample_weight, cand_prob, cand_ids, hard_thr, workspace,
+                       workspace_bytes, lse, per_row, loss, stream);
 }
 
 extern "C" int tt_retrieval_bwd_f32(const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
@@ -1490,9 +1511,9 @@ extern "C" int tt_retrieval_fwd_bwd_bf16x3_f32(const float* q, const float* c, i
 // Retrieval metric support (configs/data_config.yaml:71 top_k_eval): rank of each query's true
 // candidate among ALL nc candidates = number of other candidates with a strictly larger logit.  One fused pass over
 // the [nq, nc] logits (never materialised); Recall@K / NDCG@K follow from rank < K on the host side.
-extern "C" int tt_retrieval_rank_f32(const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
-                                     float inv_temperature, const float* cand_prob, const int64_t* pos_index,
-                                     void* workspace, int64_t workspace_bytes, int32_t* rank, tt_stream_t stream_) {
+static int retrieval_rank(int prec, const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
+                          float inv_temperature, const float* cand_prob, const int64_t* pos_index,
+                          void* workspace, int64_t workspace_bytes, int32_t* rank, tt_stream_t stream_) {
   // (not check_common: a rank pass has no diagonal, so nq > nc is fine, and it needs only the front of the workspace)
   int rc;
   TT_REQUIRE(q && c && workspace && pos_index && rank, "tt_retrieval_rank_f32: null pointer");
@@ -1526,9 +1547,26 @@ extern "C" int tt_retrieval_rank_f32(const float* q, const float* c, int64_t nq,
   a.nsplit = w.ns_q;
   a.c_per_split = align_up((nc + a.nsplit - 1) / a.nsplit, 32);
   a.part_cnt = part_cnt;
-  if ((rc = dispatch_score<MODE_RANK>(dim, a, false, stream)) != TT_OK) return rc;
+  rc = prec == 1 ? dispatch_score_bx3<MODE_RANK>(dim, a, false, stream) : dispatch_score<MODE_RANK>(dim, a, false, stream);
+  if (rc != TT_OK) return rc;
   hipLaunchKernelGGL(rank_combine_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, part_cnt, nq, a.nsplit, rank);
   return tt::check_launch("rank_combine");
+}
+
+extern "C" int tt_retrieval_rank_f32(const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
+                                     float inv_temperature, const float* cand_prob, const int64_t* pos_index,
+                                     void* workspace, int64_t workspace_bytes, int32_t* rank, tt_stream_t stream) {
+  return retrieval_rank(0, q, c, nq, nc, dim, inv_temperature, cand_prob, pos_index, workspace, workspace_bytes, rank, stream);
+}
+
+// Top-K over a 10M-100M-row corpus is pure GEMM1 as well: the same rank pass with the 6-product bf16 split.  The positive's
+// threshold logit stays an exact f32 dot product (pos_logit_kernel); a competitor within ~2^-22 relative of it may fall on
+// either side, exactly as between two exact-f32 evaluation orders (the tests pin ranks between f64 +-1e-5 bounds).
+extern "C" int tt_retrieval_rank_bf16x3_f32(const float* q, const float* c, int64_t nq, int64_t nc, int32_t dim,
+                                            float inv_temperature, const float* cand_prob, const int64_t* pos_index,
+                                            void* workspace, int64_t workspace_bytes, int32_t* rank, tt_stream_t stream) {
+  if (dim != 128 && dim != 256) return tt::fail(TT_ERR_UNSUPPORTED, "tt_retrieval_rank_bf16x3_f32: dim %d not in {128,256}", dim);
+  return retrieval_rank(1, q, c, nq, nc, dim, inv_temperature, cand_prob, pos_index, workspace, workspace_bytes, rank, stream);
 }
 
 // In-batch rank (tfrs.tasks.Retrieval(batch_metrics=...): Keras top-k categorical accuracy over the IN-BATCH score matrix):

@@ -12,10 +12,12 @@ from . import ops
 
 
 class FactorizedTopK:
-    def __init__(self, ks=(1, 5, 10, 20, 50, 100), temperature: float | None = None, candidates: torch.Tensor | None = None):
+    def __init__(self, ks=(1, 5, 10, 20, 50, 100), temperature: float | None = None, candidates: torch.Tensor | None = None,
+                 precision: str = "f32"):
         """candidates: optional [n_candidates, D] corpus embeddings (tfrs.metrics.FactorizedTopK(candidates=...)); then
         ``update_state(q, None, true_index)`` and ``tasks.Retrieval(metrics=...)`` rank against it."""
         self.ks = tuple(int(k) for k in ks)
+        self.precision = precision        # "bf16x3": the corpus pass on the bf16 matrix cores (scorer dim 128 / 256)
         self.inv_t = 1.0 if temperature is None else 1.0 / temperature
         self.candidates = None if candidates is None else candidates.contiguous()
         self.reset_state()
@@ -38,7 +40,7 @@ class FactorizedTopK:
         if self._ws is None or self._ws[0] != key:         # one small buffer per shape, not one allocation per batch
             self._ws = (key, torch.empty(ops.retrieval_rank_workspace_bytes(*key[:3]), dtype=torch.uint8, device=q.device))
         rank = ops.retrieval_rank(q, c, self.inv_t, true_candidate_index.contiguous(), workspace=self._ws[1],
-                                  cand_prob=candidate_sampling_probability)
+                                  cand_prob=candidate_sampling_probability, precision=self.precision)
         r = rank.to(torch.float64)
         ks = torch.tensor(self.ks, dtype=torch.float64, device=r.device)
         inside = (r[:, None] < ks[None, :]).to(torch.float64)                   # [nq, len(ks)]

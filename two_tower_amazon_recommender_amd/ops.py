@@ -502,6 +502,9 @@ def make_dense_seg(param, accum, grad_slabs, n_slabs: int, l2: float, grad_out=N
 
 
 # ----------------------------------------------------------------------------- a3+a4 retrieval
+SCORER_PRECISIONS = ("f32", "bf16x3")
+
+
 def retrieval_workspace_bytes(nq: int, nc: int, dim: int) -> int:
     """Workspace of the fused training entries (retrieval_fwd_bwd): includes the [nq, nc] f32 logit buffer pass 2 reads back."""
     return int(_lib.load().tt_retrieval_workspace_bytes(nq, nc, dim))
@@ -543,12 +546,17 @@ def retrieval_rank_workspace_bytes(nq: int, nc: int, dim: int) -> int:
 
 
 def retrieval_fwd(q, c, inv_temperature: float, workspace, lse, per_row, loss, sample_weight=None,
-                  cand_prob=None, cand_ids=None, diag_offset: int = 0, hard_thr=None):
+                  cand_prob=None, cand_ids=None, diag_offset: int = 0, hard_thr=None, precision: str = "f32"):
+    """Forward only (validation loss).  precision "bf16x3": the logits' products on the bf16 MFMA (dim 128 / 256)."""
     _chk_retrieval(q, c, sample_weight, cand_prob, cand_ids, hard_thr, lse, per_row)
+    if precision not in SCORER_PRECISIONS:
+        raise ValueError(f"precision must be one of {SCORER_PRECISIONS}, got {precision!r}")
     lib = _lib.load()
-    _lib.check(lib.tt_retrieval_fwd_f32(_p(q), _p(c), q.shape[0], c.shape[0], q.shape[1], diag_offset, inv_temperature,
-                                        _p(sample_weight), _p(cand_prob), _p(cand_ids), _p(hard_thr), _p(workspace),
-                                        workspace.numel(), _p(lse), _p(per_row), _p(loss), _stream()), "tt_retrieval_fwd_f32")
+    fn = lib.tt_retrieval_fwd_f32 if precision == "f32" else lib.tt_retrieval_fwd_bf16x3_f32
+    _lib.check(fn(_p(q), _p(c), q.shape[0], c.shape[0], q.shape[1], diag_offset, inv_temperature,
+                  _p(sample_weight), _p(cand_prob), _p(cand_ids), _p(hard_thr), _p(workspace),
+                  workspace.numel(), _p(lse), _p(per_row), _p(loss), _stream()),
+               "tt_retrieval_fwd_f32" if precision == "f32" else "tt_retrieval_fwd_bf16x3_f32")
     return loss
 
 
@@ -563,7 +571,6 @@ def retrieval_bwd(q, c, inv_temperature: float, workspace, lse, dq, dc, sample_w
     return dq, dc
 
 
-SCORER_PRECISIONS = ("f32", "bf16x3")
 
 
 def retrieval_fwd_bwd(q, c, inv_temperature: float, workspace, lse, per_row, loss, dq, dc, sample_weight=None,
@@ -583,8 +590,11 @@ def retrieval_fwd_bwd(q, c, inv_temperature: float, workspace, lse, per_row, los
     return loss
 
 
-def retrieval_rank(q, c, inv_temperature: float, pos_index, workspace=None, cand_prob=None, out=None):
-    """rank[i] = #candidates scoring strictly above query i's true candidate ``pos_index[i]`` (int32 [nq])."""
+def retrieval_rank(q, c, inv_temperature: float, pos_index, workspace=None, cand_prob=None, out=None, precision: str = "f32"):
+    """rank[i] = #candidates scoring strictly above query i's true candidate ``pos_index[i]`` (int32 [nq]).
+    precision "bf16x3": the logits' products on the bf16 MFMA (dim 128 / 256)."""
+    if precision not in SCORER_PRECISIONS:
+        raise ValueError(f"precision must be one of {SCORER_PRECISIONS}, got {precision!r}")
     _chk(q, torch.float32, "query_embeddings", 2)
     _chk(c, torch.float32, "candidate_embeddings", 2)
     _chk(pos_index, torch.int64, "pos_index", 1)
@@ -600,8 +610,10 @@ def retrieval_rank(q, c, inv_temperature: float, pos_index, workspace=None, cand
     if out is None:
         out = torch.empty(nq, dtype=torch.int32, device=q.device)
     lib = _lib.load()
-    _lib.check(lib.tt_retrieval_rank_f32(_p(q), _p(c), nq, nc, d, inv_temperature, _p(cand_prob), _p(pos_index),
-                                         _p(workspace), workspace.numel(), _p(out), _stream()), "tt_retrieval_rank_f32")
+    fn = lib.tt_retrieval_rank_f32 if precision == "f32" else lib.tt_retrieval_rank_bf16x3_f32
+    _lib.check(fn(_p(q), _p(c), nq, nc, d, inv_temperature, _p(cand_prob), _p(pos_index),
+                  _p(workspace), workspace.numel(), _p(out), _stream()),
+               "tt_retrieval_rank_f32" if precision == "f32" else "tt_retrieval_rank_bf16x3_f32")
     return out
 
 

@@ -531,7 +531,8 @@ class TwoTowerTrainer:
             q, c = towers_forward(ut, it, lookups=lks) if cfg.symmetric else (ut.forward(lookup=lks[0]), it.forward(lookup=lks[1]))
         kw = dict(sample_weight=loss_kw.get("sample_weight"), cand_prob=loss_kw.get("candidate_sampling_probability"),
                   cand_ids=loss_kw.get("candidate_ids"))
-        return ops.retrieval_fwd(q, c, 1.0 / cfg.temperature, self.ws, self.lse, self.per_row, self.loss, **kw)
+        return ops.retrieval_fwd(q, c, 1.0 / cfg.temperature, self.ws, self.lse, self.per_row, self.loss,
+                                 precision=cfg.scorer_precision, **kw)
 
     # ------------------------------------------------------------------ retrieval metrics
     @torch.no_grad()
