@@ -396,7 +396,7 @@ int tt_train_step_f32(const tt_train_step* step, tt_stream_t stream);
  * Workspace: tt_retrieval_workspace_bytes(nq, nc, dim) bytes, 256-byte aligned.  For the fused training entries this
  * INCLUDES the raw dot products of pass 1, ceil(nq/32) * ceil(nc/32) blocks of 4 KB = 4*nq*nc bytes (268 MB at 8192 x
  * 8192, 4.3 GB at 32768 x 32768; ABI v5 and later - a workspace sized by an older library is refused with
- * TT_ERR_WORKSPACE).  The bf16x3 entry at dim 256 recomputes instead and accepts tt_retrieval_fwd_workspace_bytes.    */
+ * TT_ERR_WORKSPACE).  Both precisions keep them, at every dim (ABI v8; bf16x3 at dim 256 recomputed through v7).    */
 int64_t tt_retrieval_workspace_bytes(int64_t nq, int64_t nc, int32_t dim);
 /* the part of it the forward-only (tt_retrieval_fwd_f32) and separate-backward (tt_retrieval_bwd_f32) entries need: no
  * [nq][nc] logit buffer (only the fused training entries keep the raw dot products between their two passes) */
@@ -432,7 +432,7 @@ int tt_retrieval_hard_negative_thresholds_f32(const float* q, const float* c, in
 /* Fused training form: loss AND both gradients in two passes over the logits instead of three
  * (pass 1: online softmax with the candidate-weighted sum -> lse, per_row, loss, dq;  pass 2: dc).
  * Same semantics and outputs as tt_retrieval_fwd_f32 followed by tt_retrieval_bwd_f32.
- * The exact-f32 entry keeps the raw dot products [nq][nc] (f32) in the workspace between the passes — pass 2 reads them
+ * Both entries keep the raw dot products [nq][nc] (f32) in the workspace between the passes — pass 2 reads them
  * back instead of recomputing them (half its matrix-pipe work; 6*nq*nc*dim executed FLOPs in total instead of 8) —
  * which is why tt_retrieval_workspace_bytes includes 4*nq*nc bytes; tt_retrieval_fwd_workspace_bytes is enough for the
  * forward-only and separate-backward entries.                                                                        */

@@ -11,7 +11,10 @@ dev = torch.device("cuda:0")
 
 
 def main():
-    for b, d in ((8192, 128), (16384, 128), (8192, 256)):
+    shapes = ((8192, 128), (16384, 128), (8192, 256), (32768, 256))
+    if len(sys.argv) > 1:
+        shapes = tuple(tuple(int(v) for v in a.split("x")) for a in sys.argv[1:])
+    for b, d in shapes:
         q = torch.empty(b, d, device=dev); c = torch.empty(b, d, device=dev)
         ops.fill_uniform_(q, 2, 1, -0.3, 0.6); ops.fill_uniform_(c, 2, 2, -0.3, 0.6)
         ws = torch.empty(ops.retrieval_workspace_bytes(b, b, d), dtype=torch.uint8, device=dev)
@@ -31,6 +34,20 @@ def main():
             _lib.profile_enable("")
             out[prec] = {"fused_us": sum(f) / len(f) * 1e3, "bwd_us": sum(bw) / len(bw) * 1e3, "loss": loss.item(),
                          "dq_abs_max": dq.abs().max().item()}
+            # validation forward and the rank pass (pure GEMM1), hipEvents over back-to-back calls
+            pos = torch.arange(b, device=dev)
+            rk = torch.empty(b, dtype=torch.int32, device=dev)
+            for name, g in (("fwd_us", lambda: ops.retrieval_fwd(q, c, 10.0, ws, lse, pr, loss, precision=prec)),
+                            ("rank_us", lambda: ops.retrieval_rank(q, c, 10.0, pos, workspace=ws, out=rk, precision=prec))):
+                for _ in range(2):
+                    g()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    g()
+                e1.record()
+                torch.cuda.synchronize()
+                out[prec][name] = e0.elapsed_time(e1) / 10 * 1e3
         print(json.dumps(out), flush=True)
 
 

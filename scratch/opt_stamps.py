@@ -29,7 +29,11 @@ us = (s - t0) / 100.0
 names = ["start", "appended", "barrier", "rows requested", "classified", "ranked", "updated", "ids landed"]
 order = [0, 7, 4, 1, 2, 3, 5, 6]
 print(len(s), "sorting WGs; mean stamp times (us):", ", ".join(f"{names[k]} {us[:, k].mean():.2f}" for k in order), "| max end", us[:, 6].max(), "start spread", us[:, 0].max())
+pc = lambda a: " ".join(f"{np.percentile(a, q):.2f}" for q in (0, 10, 50, 90, 99, 100))
+print("percentiles 0/10/50/90/99/100: ids landed", pc(us[:, 7]), "| barrier", pc(us[:, 2]), "| fast_apply done", pc(us[:, 3]), "| end", pc(us[:, 6]))
+late = np.argsort(-us[:, 6])[:8]
+print("latest WGs (index, start, barrier, fast_apply done, ranked, end):", [(int(k) + 36, *[round(float(us[k, c]), 2) for c in (0, 2, 3, 5, 6)]) for k in late])
 d = allw[:36]
 d = d[d[:, 6] > d[:, 0]]
 ud = (d - t0) / 100.0
-print(len(d), "dense blocks: start", ud[:, 0].round(2).tolist()[:40], "end", ud[:, 6].round(2).tolist()[:40])
+print(len(d), "dense blocks: start", pc(ud[:, 0]), "end", pc(ud[:, 6]), "ends:", ud[:, 6].round(1).tolist())

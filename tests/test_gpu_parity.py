@@ -943,7 +943,7 @@ def test_retrieval_rank_and_topk_metrics(dev, nq, nc, d, use_p):
 
 def test_retrieval_rank_bf16x3_refuses_other_dims(dev):
     q = torch.zeros(64, 64, device=dev)
-    with pytest.raises(_lib.TwoTowerError, match="not in"):
+    with pytest.raises(NotImplementedError, match="not in"):
         ops.retrieval_rank(q, q, 1.0, torch.zeros(64, dtype=torch.int64, device=dev), precision="bf16x3")
     with pytest.raises(ValueError):
         ops.retrieval_rank(q, q, 1.0, torch.zeros(64, dtype=torch.int64, device=dev), precision="bf16")

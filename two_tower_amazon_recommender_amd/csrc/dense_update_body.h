@@ -25,8 +25,23 @@ __device__ __forceinline__ float apply_one(const tt_dense_seg& s, int64_t i, flo
   return w;
 }
 
-// One thread owns 4 consecutive elements (float4 loads when the segment allows it) and keeps 8 slabs' loads in
-// flight; the additions stay in slab order (the oracle's order).
+// the same update on values already in registers (the vector path loads parameter and accumulator as float4, with the slabs)
+template <int OPT>
+__device__ __forceinline__ float apply_val(float w, float& acc, float g, float l2, float lr, float eps) {
+  g = __fadd_rn(g, __fmul_rn(2.0f * l2, w));
+  if constexpr (OPT == TT_OPT_SGD) {
+    return __fsub_rn(w, __fmul_rn(lr, g));
+  } else {
+    acc = __fadd_rn(acc, __fmul_rn(g, g));
+    return __fsub_rn(w, __fdiv_rn(__fmul_rn(lr, g), sqrtf(__fadd_rn(acc, eps))));
+  }
+}
+
+// One thread owns 4 consecutive elements (float4 loads when the segment allows it) and keeps 16 slabs' loads in flight -
+// together with the element's parameter (and accumulator) float4, requested FIRST; the additions stay in slab order (the
+// oracle's order).  All loads are unconditional from clamped slab indices: 32 slabs are two memory round trips.  (Through
+// r02: 8 in flight behind a first load of slab 0 and in front of four scalar parameter loads - six dependent round trips,
+// 5 us for the step's 18 MB on the 36 CUs the fused optimizer launch leaves for it; r03 stamps.)
 // (TPB = threads per block of the launch; every element is summed and updated on its own, so TPB changes nothing in the results)
 template <int OPT, int TPB = 256>
 __device__ __forceinline__ void dense_update_body(const tt_dense_seg& s, const int bx, const int nbx, int apply, float lr, float eps) {
@@ -35,27 +50,47 @@ __device__ __forceinline__ void dense_update_body(const tt_dense_seg& s, const i
                    (s.grad_out == nullptr || al16(s.grad_out)) && (!apply || al16(s.param)) &&
                    (!apply || OPT == TT_OPT_SGD || al16(s.accum));
   if (vec) {
+    constexpr int U = 16;
     const int64_t n4 = s.count / 4, st4 = s.slab_stride / 4;
     const f32x4* __restrict__ gs = reinterpret_cast<const f32x4*>(s.grad_slabs);
+    const int ns = s.n_slabs;
+    const float l2 = s.l2;
+    f32x4* param4 = reinterpret_cast<f32x4*>(s.param);
+    f32x4* accum4 = reinterpret_cast<f32x4*>(s.accum);
+    f32x4* gout4 = reinterpret_cast<f32x4*>(s.grad_out);
     for (int64_t i = (int64_t)bx * TPB + threadIdx.x; i < n4; i += stride) {
-      f32x4 g = gs[i];
-      for (int k0 = 1; k0 < s.n_slabs; k0 += 8) {
-        f32x4 v[8];
+      f32x4 w = f32x4{0.f, 0.f, 0.f, 0.f}, ac = w;
+      if (apply) {                                        // (uniform)
+        w = param4[i];
+        if constexpr (OPT != TT_OPT_SGD) ac = accum4[i];
+      }
+      f32x4 g = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int k0 = 0; k0 < ns; k0 += U) {
+        f32x4 v[U];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = (k0 + u < s.n_slabs) ? gs[(int64_t)(k0 + u) * st4 + i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < U; ++u) {
+          const int k = k0 + u < ns ? k0 + u : ns - 1;    // past the last slab: re-read it (an L1 hit), not added
+          v[u] = gs[(int64_t)k * st4 + i];
+        }
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (k0 + u < s.n_slabs) {
+        for (int u = 0; u < U; ++u)
+          if (k0 + u < ns) {
+            if (k0 + u == 0) g = v[u];                    // the sum STARTS at slab 0 (0 + x would turn -0 into +0)
+            else
 #pragma unroll
-            for (int e = 0; e < 4; ++e) g[e] = __fadd_rn(g[e], v[u][e]);
+              for (int e = 0; e < 4; ++e) g[e] = __fadd_rn(g[e], v[u][e]);
           }
       }
-      if (s.grad_out != nullptr) reinterpret_cast<f32x4*>(s.grad_out)[i] = g;
+      if (gout4 != nullptr) gout4[i] = g;
       if (!apply) continue;
-      f32x4 w;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) w[e] = apply_one<OPT>(s, 4 * i + e, g[e], lr, eps);
-      reinterpret_cast<f32x4*>(s.param)[i] = w;
+      for (int e = 0; e < 4; ++e) {
+        float acc = ac[e];
+        w[e] = apply_val<OPT>(w[e], acc, g[e], l2, lr, eps);
+        ac[e] = acc;
+      }
+      if constexpr (OPT != TT_OPT_SGD) accum4[i] = ac;
+      param4[i] = w;
     }
     return;
   }

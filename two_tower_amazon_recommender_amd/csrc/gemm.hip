@@ -570,10 +570,13 @@ extern "C" int tt_dense_fwd_dropout_f32(const float* x, const float* w, const fl
   return tt_dense_fwd_batched_f32(&q, 1, m, k, n, relu, drop_rate, seed, counter_offset, stream);
 }
 
+#ifndef TT_DW_MAX_SLABS
+#define TT_DW_MAX_SLABS 32
+#endif
 extern "C" int32_t tt_dense_bwd_num_slabs(int64_t m) {
   int64_t s = (m + 255) / 256;
   if (s < 1) s = 1;
-  if (s > 32) s = 32;
+  if (s > TT_DW_MAX_SLABS) s = TT_DW_MAX_SLABS;
   return (int32_t)s;
 }
 

@@ -199,15 +199,35 @@ __device__ __forceinline__ uint32_t part_scan_append(const PartTable& t, const i
   uint32_t* ctr = wbel + 16;                                // [16] ctr[0] = keys of this range appended so far, ctr[1] = keys below
   uint16_t* poss = reinterpret_cast<uint16_t*>(ctr + 16);   // [cap]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // the descriptor's fields as values (read through the reference inside the loops below they stayed scalar LOADS, which the
+  // compiler placed - and waited for - between the id loads)
+  // (global address space spelled out: a pointer that went through the caller's SGPR pin is a generic one, and flat loads
+  // count against lgkmcnt as well - every LDS wait would wait for them)
+  const __attribute__((address_space(1))) int64_t* ids = (const __attribute__((address_space(1))) int64_t*)t.ids;
+  const int64_t num_rows = t.num_rows;
   const int n = t.n, J = (n + T - 1) / T;
+  const uint32_t sentinel = t.sentinel, width = t.width;
+  const int groups = t.groups;
   SSTAMP(0);
+  if (n <= 0) { offset = 0u; base_key = 0u; return 0u; }   // (uniform; the host never launches an empty table)
 
   // ---- scan: every id of the table; clamp; which range ----
+  // ALL of this thread's ids are requested before any is looked at: unconditional loads from clamped addresses.  (r03 ISA
+  // audit: written as `cond ? ids[i] : ...` with the range checks in the same statement, each load sat in its own branch
+  // with `s_waitcnt vmcnt(0)` behind it - 8 dependent L2 round trips, the 3.2 us "ids landed" stamp of every workgroup.)
+  int64_t raw[JMAX];
+  const int last = n - 1;
 #pragma unroll
   for (int j = 0; j < JMAX; ++j) {
     const int i = j * T + tid;
-    const int64_t id = t.ids[(j < J && i < n) ? i : 0];
-    sc.kj[j] = (j < J && i < n) ? ((id >= 0 && id < t.num_rows) ? (uint32_t)id : t.sentinel) : 0xffffffffu;   // past n: no range
+    raw[j] = ids[i < last ? i : last];
+  }
+#pragma unroll
+  for (int j = 0; j < JMAX; ++j) {
+    const int i = j * T + tid;
+    const int64_t id = raw[j];
+    const uint32_t k = (id >= 0 && id < num_rows) ? (uint32_t)id : sentinel;
+    sc.kj[j] = i < n ? k : 0xffffffffu;                      // past n: no range
   }
   if (tid == 0) { ctr[0] = 0u; ctr[1] = 0u; }
   __syncthreads();                                          // counters zeroed; the ids have landed (the barrier's fence waits for them)
@@ -219,8 +239,8 @@ __device__ __forceinline__ uint32_t part_scan_append(const PartTable& t, const i
   // instead of computing its group number first (multiply-high, multiply, compare, subtract, min: bucket_of, kept for the
   // routing kernels).  The last group's span runs up to the out-of-range sentinel; the all-ones key of a slot past n is in
   // no range and not below any.  Every workgroup classifies all n ids, so these instructions ARE the scan's VALU time.)
-  base_key = (uint32_t)g * t.width;
-  const uint32_t span = (g == t.groups - 1) ? (base_key <= t.sentinel ? t.sentinel - base_key + 1u : 0u) : t.width;
+  base_key = (uint32_t)g * width;
+  const uint32_t span = (g == groups - 1) ? (base_key <= sentinel ? sentinel - base_key + 1u : 0u) : width;
   uint32_t below = 0u, wave_mine = 0u;
 #pragma unroll
   for (int j = 0; j < JMAX; ++j) {

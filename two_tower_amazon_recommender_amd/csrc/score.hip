@@ -143,6 +143,18 @@ constexpr int tiles_per_barrier() {
              ? TT_TILES_PER_BARRIER : 1;
 }
 
+// bf16x3 at dim 256, passes with GEMM1 AND GEMM2: a PAIR of waves shares 32 stationary rows and splits the embedding
+// dimension - each wave holds the three bf16 pieces of R[r][128 hw .. 128 hw + 127] (96 VGPRs instead of 192), multiplies
+// the tile's matching k-half, the two partial dot-product blocks meet through LDS (4 KB per wave, one extra barrier), both
+// waves run the (identical) softmax on the sum, and each accumulates its own 128 columns of the gradient block (64 AGPRs
+// instead of 128).  r02's one-wave-per-32-rows form needed ~640 registers of the 512 and spilled 416-556 B per lane.
+template <int D, int MODE, int PREC>
+constexpr bool split_d() {
+  return PREC == 1 && D == 256 && (MODE == MODE_BWD || MODE == MODE_FUSED || MODE == MODE_FUSED_S);
+}
+template <int D, int MODE, int PREC, int WAVES>
+constexpr int rows_per_wg() { return (split_d<D, MODE, PREC>() ? WAVES / 2 : WAVES) * 32; }
+
 template <int D, int MODE, bool HAS_IDS, bool HAS_HN, int WAVES, int PREC>
 __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? ((MODE == MODE_BWD_S && PREC == 0) ? TT_BWDS_WAVES : 2) : 1))) void score_kernel(ScoreArgs p) {   // (min waves per SIMD)
   constexpr bool IS_FUSED = MODE == MODE_FUSED || MODE == MODE_FUSED_S;     // online softmax + dq
@@ -150,7 +162,10 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? ((MODE ==
   constexpr bool FROM_S = MODE == MODE_BWD_S, TO_S = MODE == MODE_FUSED_S;
   using G_ = Geo<D, PREC>;
   constexpr int LS = G_::LS, NG = G_::NG, NB = G_::NB, TILE_F = G_::TILE_F, BUF_F = G_::BUF_F;
-  constexpr int KS = G_::KS, HALF_B = G_::HALF_B, PIECE_B = G_::PIECE_B;
+  constexpr int HALF_B = G_::HALF_B, PIECE_B = G_::PIECE_B;
+  constexpr bool SPLIT = split_d<D, MODE, PREC>();
+  constexpr int KS = SPLIT ? G_::KS / 2 : G_::KS;     // GEMM1 k-steps of THIS wave
+  constexpr int NBW = SPLIT ? NB / 2 : NB;            // GEMM2 d-blocks of THIS wave
   static_assert(PREC == 0 || D % 128 == 0, "bf16x3: dim 128 / 256 only (whole [32][128] bf16 images)");
   constexpr int ROW4 = D / 4;                       // float4 per K row
   constexpr int THREADS = WAVES * 64;
@@ -170,7 +185,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? ((MODE ==
   // scratch/audit_barriers.py checks the built ISA: in all instantiations every barrier loop closes on scalar branches.
   const int split = __builtin_amdgcn_readfirstlane((int)(blockIdx.x % (unsigned)p.nsplit));
   const int64_t rblk = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / (unsigned)p.nsplit));
-  const int64_t r0w = rblk * (WAVES * 32) + wave * 32;   // first row of this wave
+  const int hw = SPLIT ? (wave & 1) : 0;             // SPLIT: the half of the embedding dimension this wave owns
+  const int64_t r0w = rblk * rows_per_wg<D, MODE, PREC, WAVES>() + (SPLIT ? wave >> 1 : wave) * 32;   // first row of this wave
   const int64_t r = r0w + ln;                       // this lane's row (both halves)
   const bool r_ok = r < p.n_r;
   const int64_t c_begin = (int64_t)split * p.c_per_split;
@@ -199,7 +215,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? ((MODE ==
 #pragma unroll
     for (int g = 0; g < NG; ++g) rf[g] = r_ok ? R4[2 * g] : f32x4{0.f, 0.f, 0.f, 0.f};
   } else {
-    const f32x4* R4 = reinterpret_cast<const f32x4*>(p.R + (r_ok ? r : 0) * D) + 2 * h;
+    const f32x4* R4 = reinterpret_cast<const f32x4*>(p.R + (r_ok ? r : 0) * D) + 2 * h + 32 * hw;
     const float live = r_ok ? 1.f : 0.f;            // rows past n_r read row 0 and are zeroed (all loads unconditional)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -309,7 +325,24 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? ((MODE ==
     float* blk = p.S + (ctile * p.ldS + (r0w >> 5)) * 1024 + ln * 32 + 4 * h;
 #pragma unroll
     for (int g = 0; g < 4; ++g)
-      *reinterpret_cast<f32x4*>(blk + 8 * g) = f32x4{X[4 * g], X[4 * g + 1], X[4 * g + 2], X[4 * g + 3]};
+      if (!SPLIT || (g >> 1) == hw)       // SPLIT: both waves of the pair hold the same block, each stores half of it
+        *reinterpret_cast<f32x4*>(blk + 8 * g) = f32x4{X[4 * g], X[4 * g + 1], X[4 * g + 2], X[4 * g + 3]};
+  };
+  // SPLIT: the partial dot products of the two k-halves meet in LDS.  a + b == b + a bit for bit, so both waves of a pair go
+  // on with the same block (their softmax statistics are duplicates, their gradient columns disjoint).
+  float* xch = smem + NBUF * BUF_F;
+  auto exchange = [&](f32x16& X) {
+    f32x4* mine = reinterpret_cast<f32x4*>(xch + wave * 1024) + lane;
+    const f32x4* other = reinterpret_cast<const f32x4*>(xch + (wave ^ 1) * 1024) + lane;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) mine[64 * g] = f32x4{X[4 * g], X[4 * g + 1], X[4 * g + 2], X[4 * g + 3]};
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 o = other[64 * g];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) X[4 * g + i] += o[i];
+    }
   };
   auto load_S = [&](int t, f32x16& X) {
     const int64_t q0 = c_begin + 32 * (int64_t)t;
@@ -326,10 +359,10 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? ((MODE ==
   float run_m = kNegBig, run_l = 0.f, pos = 0.f;
   int cnt = 0;
   bool have_pos = false;
-  f32x16 G[NB];
+  f32x16 G[NBW];
   if constexpr (IS_BWD || IS_FUSED) {
 #pragma unroll
-    for (int b = 0; b < NB; ++b)
+    for (int b = 0; b < NBW; ++b)
 #pragma unroll
       for (int i = 0; i < 16; ++i) G[b][i] = 0.f;
   }
@@ -357,7 +390,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? ((MODE ==
       const char* img = reinterpret_cast<const char*>(T);
       constexpr int KSN = (TT_BX3_ABL & 2) ? 1 : KS;
       auto frag = [&](int ks, bf16x8& f_hi, bf16x8& f_mid, bf16x8& f_lo, bf16x8& r_lo) {
-        const int off = (ks >> 3) * HALF_B + img_off(ln, 2 * (ks & 7) + h);
+        const int off = (SPLIT ? hw : (ks >> 3)) * HALF_B + img_off(ln, 2 * (ks & 7) + h);
         f_hi = *reinterpret_cast<const bf16x8*>(img + off);
         f_mid = *reinterpret_cast<const bf16x8*>(img + PIECE_B + off);
         f_lo = *reinterpret_cast<const bf16x8*>(img + 2 * PIECE_B + off);
@@ -545,7 +578,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? ((MODE ==
           const float alpha = __builtin_amdgcn_exp2f(run_m - m_new);
           run_l *= alpha;
 #pragma unroll
-          for (int b = 0; b < NB; ++b)
+          for (int b = 0; b < NBW; ++b)
 #pragma unroll
             for (int i = 0; i < 16; ++i) G[b][i] *= alpha;
           run_m = m_new;
@@ -594,10 +627,10 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? ((MODE ==
       const char* img = reinterpret_cast<const char*>(T);
       const int g16 = (lane >> 4) & 1, q = (lane >> 2) & 3, pp = lane & 3;
       // flat step i = 2 b + s; the four transposing reads of step i+1 are in flight under the three MFMAs of step i
-      constexpr int NSTEP = 2 * ((TT_BX3_ABL & 4) ? 1 : NB);
+      constexpr int NSTEP = 2 * ((TT_BX3_ABL & 4) ? 1 : NBW);
       auto frag = [&](int i, bf16x8& k_hi, bf16x8& k_mid) {
         const int b = i >> 1, s = i & 1;
-        const int sub = ((32 * b) >> 7) * HALF_B + 8 * (pp & 1);
+        const int sub = (SPLIT ? hw : ((32 * b) >> 7)) * HALF_B + 8 * (pp & 1);     // (SPLIT: b counts inside the wave's own 128 columns)
         const int ch = (((32 * b) & 127) >> 3) + 2 * g16 + (pp >> 1);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -735,6 +768,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? ((MODE ==
       const float* T = smem + (t % NBUF) * BUF_F;
       f32x16 X;
       if constexpr (FROM_S) X = xs; else X = gemm1(T);
+      if constexpr (SPLIT) exchange(X);
       if constexpr (TO_S) store_S(t, X);
       float coef[16];
       epilogue(T, t, X, coef);
@@ -759,6 +793,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? ((MODE ==
       const float* T = smem + (t % NBUF) * BUF_F;
       f32x16 X;
       if constexpr (FROM_S) X = xs; else X = gemm1(T);
+      if constexpr (SPLIT) exchange(X);
       if constexpr (TO_S) store_S(t, X);
       float coef[16];
       epilogue(T, t, X, coef);
@@ -776,7 +811,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? ((MODE ==
   // ---- epilogue ----
   if constexpr (IS_FUSED) {
     const float L = run_l + __shfl_xor(run_l, 32);      // both halves share run_m
-    if (r_ok) {
+    if (r_ok && hw == 0) {
       if (h == 0) {
         p.part_m[(int64_t)split * p.n_r + r] = run_m;
         p.part_l[(int64_t)split * p.n_r + r] = L;
@@ -801,10 +836,10 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? ((MODE ==
     }
   } else {
     if (r_ok) {
-      float* out = p.slab + ((int64_t)split * p.n_r + r) * D;
+      float* out = p.slab + ((int64_t)split * p.n_r + r) * D + 128 * hw;
       if constexpr (PREC == 1) {          // G[b][reg] = G^T[d = 32 b + acc row(reg, h)][r]: registers 4g .. 4g+3 are 4 consecutive d
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
+        for (int b = 0; b < NBW; ++b)
 #pragma unroll
           for (int g = 0; g < 4; ++g)
             *reinterpret_cast<f32x4*>(out + 32 * b + 8 * g + 4 * h) = f32x4{G[b][4 * g], G[b][4 * g + 1], G[b][4 * g + 2], G[b][4 * g + 3]};
@@ -1180,11 +1215,13 @@ constexpr int waves_for() {
 template <int D, int MODE, int PREC = 0>
 int launch_score(const ScoreArgs& a_in, bool has_ids, hipStream_t stream) {
   constexpr int W = waves_for<D, MODE, PREC>();
-  const int64_t nrb = (a_in.n_r + W * 32 - 1) / (W * 32);
+  constexpr int RPW = rows_per_wg<D, MODE, PREC, W>();
+  const int64_t nrb = (a_in.n_r + RPW - 1) / RPW;
   const int64_t blocks = nrb * a_in.nsplit;
   // bf16x3 with 8 waves: a third tile buffer (staggered wave halves) + the R_lo fragments of the 8 waves
   const int lds = Geo<D, PREC>::LDS_BYTES * tiles_per_barrier<D, MODE, PREC>() +
-                  ((PREC == 1 && W == 8) ? (TT_BX3_STAGGER ? Geo<D, PREC>::BUF_F * 4 : 0) + W * Geo<D, PREC>::KS * 64 * 16 : 0);
+                  ((PREC == 1 && W == 8) ? (TT_BX3_STAGGER ? Geo<D, PREC>::BUF_F * 4 : 0) + W * Geo<D, PREC>::KS * 64 * 16 : 0) +
+                  (split_d<D, MODE, PREC>() ? W * 4096 : 0);          // + the pair's dot-product exchange
   const bool has_hn = (a_in.h_r != nullptr) || (a_in.h_c != nullptr);
   const ScoreArgs& a = a_in;
   auto go = [&](auto kern) -> int {
@@ -1404,8 +1441,12 @@ static int retrieval_fwd_bwd(int prec, const float* q, const float* c, int64_t n
                              const float* cand_prob, const int64_t* cand_ids, const float* hard_thr,
                              float grad_scale, void* workspace, int64_t workspace_bytes, float* lse,
                              float* per_row, float* loss, float* dq, float* dc, tt_stream_t stream_) {
-  // the dot-product buffer is part of the workspace only for the forms that use it: exact f32, and bf16x3 at dim 128
-  int rc = check_common("tt_retrieval_fwd_bwd_f32", q, c, nq, nc, dim, diag_offset, workspace, workspace_bytes, prec == 0 || dim == 128);
+  // Both precisions keep pass 1's dot products for pass 2 (the workspace includes the buffer).  bf16x3 at dim 256 recomputed them
+  // until r03 (TT_BX3_RECOMPUTE256=1 still does, for A/B): with the wave-pair kernels, B 32768: pass 1 / pass 2 = 6.10 / 5.87 ms
+  // recomputing, 6.45 / 3.51 ms keeping them (exact f32: 8.77 / 5.17 ms) - profiles/r03_score_f32_vs_bf16x3.jsonl.
+  static const bool recompute256 = [] { const char* e = getenv("TT_BX3_RECOMPUTE256"); return e != nullptr && e[0] == '1'; }();
+  const bool bx3_keep = prec == 1 && (dim == 128 || !recompute256);
+  int rc = check_common("tt_retrieval_fwd_bwd_f32", q, c, nq, nc, dim, diag_offset, workspace, workspace_bytes, true);
   if (rc != TT_OK) return rc;
   TT_REQUIRE(lse && per_row && loss && dq && dc, "tt_retrieval_fwd_bwd_f32: null output pointer");
   TT_REQUIRE(tt::aligned16(dq) && tt::aligned16(dc), "tt_retrieval_fwd_bwd_f32: dq/dc must be 16-byte aligned");
@@ -1437,10 +1478,8 @@ static int retrieval_fwd_bwd(int prec, const float* q, const float* c, int64_t n
     a.part_l = reinterpret_cast<float*>(ws + w.off_pl);
     a.pos2 = reinterpret_cast<float*>(ws + w.off_pos);
     a.slab = slab;
-    // (bf16x3 at dim 128 too keeps the dot products: 134 + 89 us against 123 + 124 us recomputing - with the row-major buffer
-    // it had been 200 + 127 us, the blocked layout is what makes it pay.  Not at dim 256: its 4-wave kernels are at the
-    // register limit and the buffer path measured 17.7 ms against 12.4 ms per cfg5 step.)
-    const bool bx3_keep = prec == 1 && dim == 128;
+    // (bf16x3 at dim 128 keeps the dot products too: 134 + 89 us against 123 + 124 us recomputing - with the row-major buffer
+    // it had been 200 + 127 us, the blocked layout is what makes it pay.)
     rc = prec == 1 ? (bx3_keep ? dispatch_score_bx3<MODE_FUSED_S>(dim, a, cand_ids != nullptr, stream)
                                : dispatch_score_bx3<MODE_FUSED>(dim, a, cand_ids != nullptr, stream))
                    : dispatch_score<MODE_FUSED_S>(dim, a, cand_ids != nullptr, stream);
@@ -1469,11 +1508,11 @@ static int retrieval_fwd_bwd(int prec, const float* q, const float* c, int64_t n
     a.h_c = hq;
     a.id_r = cand_ids;
     a.id_c = cand_ids != nullptr ? cand_ids + diag_offset : nullptr;
-    a.nsplit = (prec == 1 && dim != 128) ? w.ns_c : w.ns_cs;
+    a.nsplit = (prec == 1 && !bx3_keep) ? w.ns_c : w.ns_cs;
     a.c_per_split = align_up((nq + a.nsplit - 1) / a.nsplit, 32);
     a.slab = slab;
     a.S = smat; a.ldS = (nq + 31) / 32;
-    rc = prec == 1 ? (dim == 128 ? dispatch_score_bx3<MODE_BWD_S>(dim, a, cand_ids != nullptr, stream)
+    rc = prec == 1 ? (bx3_keep ? dispatch_score_bx3<MODE_BWD_S>(dim, a, cand_ids != nullptr, stream)
                                  : dispatch_score_bx3<MODE_BWD>(dim, a, cand_ids != nullptr, stream))
                    : dispatch_score<MODE_BWD_S>(dim, a, cand_ids != nullptr, stream);
     if (rc != TT_OK) return rc;

@@ -596,20 +596,44 @@ __device__ __forceinline__ void apply_from_lds(const ApplyArgs& a, const int t, 
 
 template <int OPT, int DBITS, int JMAX>
 __global__ __launch_bounds__(1024) void optimizer_ids_kernel(ApplyArgs a, FusedTables ft, int n_tables, int dim4, int lpr_log2,
-                                                              tt::SegTable tbl, int dense_blocks, float lr, float eps) {
+                                                              tt::SegTable tbl, int dense_blocks, int n_dense, float lr, float eps) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   __shared__ int s_multi, s_slow;
   // flat grid: exactly the dense blocks each segment needs FIRST (a sorting workgroup fills a CU - 16 waves at up to 128
   // VGPRs - so dense blocks dispatched behind 256 of them would only start when those retire: r02 stamps, 10 us late),
   // then the sorting workgroups of table 0, 1, (2); the host keeps the total at one workgroup per CU
-  const int b = (int)blockIdx.x - ft.seg_first[dense_blocks];
+  // (r03: everything a sorting workgroup needs from the kernel arguments sits at STATIC offsets - the dense block count is an
+  // argument of its own, the table is picked by compares and the three descriptors by selects - so the scalar loads leave in
+  // one batch.  Indexed by values that were themselves loaded (seg_first[n_segs], first[ti + 1] in a loop, part[ti]) they
+  // formed a chain of three dependent scalar-cache misses in front of the first id load.)
+  const int b = (int)blockIdx.x - n_dense;
   if (b >= 0) {
-    int ti = 0;
-    while (ti + 1 < n_tables && b >= ft.first[ti + 1]) ++ti;
-    const tt::PartTable& t = ft.part[ti];
+    static_assert(kMaxSparseTables == 3, "table pick below");
+    const int ti = (n_tables > 2 && b >= ft.first[2]) ? 2 : ((n_tables > 1 && b >= ft.first[1]) ? 1 : 0);
+    tt::PartTable t{};
+    {
+      // all three descriptors' fields into SGPRs first (the empty asm pins the VALUES: left to itself the compiler selects the
+      // field's ADDRESS by ti and loads through it - a second dependent round trip), then scalar selects
+      const int64_t *i0 = ft.part[0].ids, *i1 = ft.part[1].ids, *i2 = ft.part[2].ids;
+      int64_t r0 = ft.part[0].num_rows, r1 = ft.part[1].num_rows, r2 = ft.part[2].num_rows;
+      int32_t n0 = ft.part[0].n, n1 = ft.part[1].n, n2 = ft.part[2].n;
+      int32_t g0 = ft.part[0].groups, g1 = ft.part[1].groups, g2 = ft.part[2].groups;
+      uint32_t w0 = ft.part[0].width, w1 = ft.part[1].width, w2 = ft.part[2].width;
+      uint32_t m0 = ft.part[0].magic, m1 = ft.part[1].magic, m2 = ft.part[2].magic;
+      uint32_t s0 = ft.part[0].sentinel, s1 = ft.part[1].sentinel, s2 = ft.part[2].sentinel;
+      asm volatile("" : "+s"(i0), "+s"(i1), "+s"(i2), "+s"(r0), "+s"(r1), "+s"(r2), "+s"(n0), "+s"(n1), "+s"(n2), "+s"(g0), "+s"(g1),
+                        "+s"(g2), "+s"(w0), "+s"(w1), "+s"(w2), "+s"(m0), "+s"(m1), "+s"(m2), "+s"(s0), "+s"(s1), "+s"(s2));
+      t.ids = ti == 2 ? i2 : (ti == 1 ? i1 : i0);
+      t.num_rows = ti == 2 ? r2 : (ti == 1 ? r1 : r0);
+      t.n = ti == 2 ? n2 : (ti == 1 ? n1 : n0);
+      t.groups = ti == 2 ? g2 : (ti == 1 ? g1 : g0);
+      t.width = ti == 2 ? w2 : (ti == 1 ? w1 : w0);
+      t.magic = ti == 2 ? m2 : (ti == 1 ? m1 : m0);
+      t.sentinel = ti == 2 ? s2 : (ti == 1 ? s1 : s0);
+    }
     if (threadIdx.x == 0) { s_multi = 0; s_slow = 0; }
     uint32_t offset, base_key;
-    const int g = b - ft.first[ti];
+    const int g = b - (ti == 2 ? ft.first[2] : (ti == 1 ? ft.first[1] : 0));
     tt::PartScan<JMAX> sc;
     const uint32_t m = tt::part_scan_append<DBITS, JMAX>(t, g, ft.cap, smem, sc, offset, base_key);
     if (m == 0u) return;
@@ -887,7 +911,7 @@ extern "C" int tt_optimizer_step_ids_f32(int32_t opt, const tt_sparse_table_ids*
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return tt::fail(TT_ERR_LAUNCH, "tt_optimizer_step_ids_f32: hipFuncSetAttribute(LDS %d) failed", lds);
     tt::ProfScope prof("optimizer", stream);
-    hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(1024), lds, stream, a, ft, n_tables, dim4, lpr_log2, tbl, n_segs, lr, eps);
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(1024), lds, stream, a, ft, n_tables, dim4, lpr_log2, tbl, n_segs, (int)ft.seg_first[n_segs], lr, eps);
     return tt::check_launch("tt_optimizer_step_ids_f32");
   };
   if (opt == TT_OPT_SGD) {
