@@ -12,7 +12,7 @@ import csv, json
 rows = list(csv.DictReader(open('gpurun_out/prof_ab${k}_$v/trace_kernel_stats.csv')))
 for r in rows:
     n = r['Name']
-    if any(s in n for s in ('optimizer_ids', 'gemm_kernel<true, false, false, 1', 'gemm_bwd_kernel<0>')):
+    if any(s in n for s in ('optimizer_ids', 'tower_fwd2', 'gemm_kernel<true, false, false, 1', 'gemm_bwd_kernel<0>')):
         print(f"{n[28:70]:42s} calls {r['Calls']:>5s} avg {float(r['AverageNs'])/1e3:7.2f} us  min {float(r['MinNs'])/1e3:7.2f}  max {float(r['MaxNs'])/1e3:7.2f}")
 try:
     print('ms_per_step', json.loads(open('gpurun_out/prof_ab${k}_$v/bench.json').read().strip().split('\n')[-1])['ms_per_step'])

@@ -115,61 +115,92 @@ __global__ __launch_bounds__(256, 2) void tower_fwd2_kernel(Tower2Batch pb) {
   };
   const int nt1 = K0 / KT1;
   TSTAMP(0);
+  // ---- the input tile: 32 rows x K0, through the ids when the lookup is fused.  Four float4 per thread and round, in phases:
+  // the round's ids, then its rows, then the LDS stores.  Every load of a phase is UNCONDITIONAL, from a clamped (valid)
+  // address: written as `if (live) { id = ids[r]; if (in range) ... }` per float4, hipcc put each id load in its own branch
+  // with `s_waitcnt vmcnt(0)` behind it - four dependent round trips in front of the rows (r03 ISA audit,
+  // scratch/audit_serial_loads.py).  Rows that do not exist / ids out of range read row 0 and are zeroed afterwards.
+  // The ids of round 0 are the FIRST loads of the kernel - they head its longest dependency chain (ids -> rows -> LDS ->
+  // barrier -> first MFMA); the bias and weight prefetches are issued behind them, the rows behind those. ----
+  const int c4n = K0 / 4;                                    // float4 per row
+  const int total = RB * c4n;
+  const bool has_ids = p.ids != nullptr, has2 = p.table2 != nullptr;        // (uniform)
+  const int64_t* idp1 = has_ids ? p.ids : reinterpret_cast<const int64_t*>(p.x);
+  const int64_t* idp2 = has2 ? p.ids2 : idp1;
+  int64_t rr[4], id1[4], id2[4];
+  int c4s[4];
+  bool live[4];
+  auto request_ids = [&](int f0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int f = f0 + tid + 256 * j;
+      const int row = f / c4n;
+      c4s[j] = f - row * c4n;
+      const int64_t r = m0 + row;
+      live[j] = f < total && r < pb.M;
+      rr[j] = live[j] ? r : m0;                              // (m0 < M: the workgroup has at least one row)
+    }
+    // no branch, no "0 unless loaded" merge (hipcc resolves that with register copies behind an s_waitcnt right after the
+    // loads): without a lookup the same 8 bytes are read from x itself (in bounds: 8 r < 4 M K0) and never looked at
+#pragma unroll
+    for (int j = 0; j < 4; ++j) id1[j] = idp1[rr[j]];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) id2[j] = idp2[rr[j]];
+  };
+  auto fetch_rows = [&](int f0) {
+    bool ok1[4], ok2[4];
+    f32x4 v[4], v2[4];
+    const float* src = has_ids ? p.table : p.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ok1[j] = live[j] && (!has_ids || (id1[j] >= 0 && id1[j] < p.table_rows));
+      ok2[j] = live[j] && has2 && id2[j] >= 0 && id2[j] < p.table2_rows;
+      const int64_t row1 = has_ids ? (ok1[j] ? id1[j] : 0) : rr[j];
+      v[j] = ldg4(src + row1 * K0 + 4 * c4s[j]);
+    }
+    if (has2) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v2[j] = ldg4(p.table2 + (ok2[j] ? id2[j] : 0) * K0 + 4 * c4s[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 x = ok1[j] ? v[j] : zero;
+      if (has2) x = ok2[j] ? x + v2[j] : x;                                  // one f32 add per element, only where the second row exists
+      const int f = f0 + tid + 256 * j;
+      if (f < total) *reinterpret_cast<f32x4*>(XT + (f / c4n) * LX + 4 * c4s[j]) = x;
+    }
+    if (has_ids && p.oob_flag != nullptr) {                                  // an id outside [0, rows) other than the -1 padding is reported
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (live[j] && c4s[j] == 0 &&
+            ((!ok1[j] && id1[j] != -1) || (has2 && !ok2[j] && id2[j] != -1)))
+          atomicOr(p.oob_flag, 1);
+    }
+  };
+  request_ids(0);
   float bias0[HB], bias1[NB];                                // requested up front: a load behind the k loop would be exposed
+  // (unconditional as well: without a bias the same index is read from the weight matrix - in bounds - and the value dropped;
+  // a branch here ends the basic block, and hipcc then parks the wait for the ids in front of it)
+  const float* b0p = p.b0 != nullptr ? p.b0 : p.w0;
+  const float* b1p = p.b1 != nullptr ? p.b1 : p.w1;
 #pragma unroll
-  for (int b = 0; b < HB; ++b) bias0[b] = p.b0 != nullptr ? p.b0[wave * C1 + 32 * b + ln] : 0.f;
+  for (int b = 0; b < HB; ++b) bias0[b] = b0p[wave * C1 + 32 * b + ln];
 #pragma unroll
-  for (int b = 0; b < NB; ++b) bias1[b] = p.b1 != nullptr ? p.b1[wave * C2 + 32 * b + ln] : 0.f;
+  for (int b = 0; b < NB; ++b) bias1[b] = b1p[wave * C2 + 32 * b + ln];
   // (every ring load is UNCONDITIONAL - past the end it re-reads the last sub-tile, an L1 hit nobody consumes: with an `if`
   // around it hipcc loads into temporaries and copies them into the ring behind an `s_waitcnt vmcnt`)
 #pragma unroll
   for (int u = 0; u < PF; ++u) load_w(st[u], p.w0, H, C1, KT1, u < nt1 ? u : nt1 - 1);
-
-  // ---- the input tile: 32 rows x K0, through the ids when the lookup is fused.  Four float4 per thread and round: all the
-  // ids first, then all the rows, then the LDS stores - two memory round trips per round, not two per float4 (r03 stamps: the
-  // tile took 4.1 us as a plain loop) ----
-  {
-    const int c4n = K0 / 4;                                  // float4 per row
-    const int total = RB * c4n;
-    for (int f0 = 0; f0 < total; f0 += 4 * 256) {
-      int64_t o1[4], o2[4];
-      bool live[4];
+  __builtin_amdgcn_sched_barrier(0);                         // nothing that needs the ids moves above the prefetches
+  fetch_rows(0);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int f = f0 + tid + 256 * j;
-        const int row = f / c4n, c4 = f - row * c4n;
-        const int64_t r = m0 + row;
-        live[j] = f < total && r < pb.M;
-        o1[j] = -1; o2[j] = -1;
-        if (live[j]) {
-          if (p.ids != nullptr) {
-            const int64_t id = p.ids[r];
-            if (id >= 0 && id < p.table_rows) o1[j] = id * K0 + 4 * c4;
-            else if (c4 == 0 && id != -1 && p.oob_flag != nullptr) atomicOr(p.oob_flag, 1);
-            if (p.table2 != nullptr) {
-              const int64_t id2 = p.ids2[r];
-              if (id2 >= 0 && id2 < p.table2_rows) o2[j] = id2 * K0 + 4 * c4;
-              else if (c4 == 0 && id2 != -1 && p.oob_flag != nullptr) atomicOr(p.oob_flag, 1);
-            }
-          } else {
-            o1[j] = r * K0 + 4 * c4;
-          }
-        }
-      }
-      f32x4 v[4];
-      const float* src = p.ids != nullptr ? p.table : p.x;
+  for (int b = 0; b < HB; ++b) bias0[b] = p.b0 != nullptr ? bias0[b] : 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        v[j] = o1[j] >= 0 ? ldg4(src + o1[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
-        if (o2[j] >= 0) v[j] = v[j] + ldg4(p.table2 + o2[j]);             // one f32 add per element
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int f = f0 + tid + 256 * j;
-        const int row = f / c4n, c4 = f - row * c4n;
-        if (f < total) *reinterpret_cast<f32x4*>(XT + row * LX + 4 * c4) = v[j];
-      }
-    }
+  for (int b = 0; b < NB; ++b) bias1[b] = p.b1 != nullptr ? bias1[b] : 0.f;
+  for (int f0 = 4 * 256; f0 < total; f0 += 4 * 256) {        // (K0 > 128: further rounds)
+    request_ids(f0);
+    fetch_rows(f0);
   }
   __syncthreads();                                           // the input tile is complete
   TSTAMP(1);
