@@ -186,7 +186,10 @@ struct PartScan {
   uint64_t mm[JMAX];       // per load: which lanes of the wave hold a key of this group's range
 };
 
-template <int DBITS, int JMAX>
+// DROP_OOR: an id outside [0, num_rows) - the exchange's -1 padding, a corrupt id - belongs to NO range (the fused optimizer:
+// such an id has no row to update, and a half-empty fixed-capacity list would otherwise pile its padding onto the last
+// group as one hot "sentinel" range).  !DROP_OOR: it takes the sentinel key and sorts last (the plan's sorted_ids hold all n).
+template <int DBITS, int JMAX, bool DROP_OOR = false>
 __device__ __forceinline__ uint32_t part_scan_append(const PartTable& t, const int g, const int cap, uint32_t* smem, PartScan<JMAX>& sc,
                                                      uint32_t& offset, uint32_t& base_key) {
   constexpr int RADIX = 1 << DBITS;
@@ -226,7 +229,7 @@ __device__ __forceinline__ uint32_t part_scan_append(const PartTable& t, const i
   for (int j = 0; j < JMAX; ++j) {
     const int i = j * T + tid;
     const int64_t id = raw[j];
-    const uint32_t k = (id >= 0 && id < num_rows) ? (uint32_t)id : sentinel;
+    const uint32_t k = (id >= 0 && id < num_rows) ? (uint32_t)id : (DROP_OOR ? 0xffffffffu : sentinel);   // (num_rows < 2^31: no key is all-ones)
     sc.kj[j] = i < n ? k : 0xffffffffu;                      // past n: no range
   }
   if (tid == 0) { ctr[0] = 0u; ctr[1] = 0u; }

@@ -3,8 +3,8 @@
 // route_kernel   : stable partition of a batch of ids by owner rank (owner = id % world, local row = id / world
 //                  + the table's offset inside the owner's combined shard) into fixed-capacity per-owner send
 //                  buffers (padding id -1) + the flat slot of every position; one workgroup per table.
-//                  16 waves, 8 consecutive positions per thread; per 8192-position round: `world` wave scans of the
-//                  per-thread counts give the first slot inside the wave, a 16 x world table in LDS gives the
+//                  16 waves, 512 consecutive positions per wave read as 8 coalesced loads; per 8192-position round:
+//                  `world` x 8 ballots give every position its rank inside the wave, a 16 x world table in LDS the
 //                  offsets across waves (ascending position order inside every owner bucket: deterministic).
 //                  Integer/byte work, latency-bound (a few microseconds).
 // scatter_rows   : dst[idx[p], :] = src[p, :] (idx < 0 skipped) — per-position gradient rows into the send buffer;
@@ -21,9 +21,12 @@ struct RouteTables {
 
 // One workgroup per table (blockIdx.x = table t); bucket (owner o, table t) of the send buffer is
 // send_ids[(o*n_tables + t)*cap ...]: one all-to-all moves every table's ids (and later rows) at once.
-// A thread owns kIpt CONSECUTIVE positions, so "ascending position" = (thread, j) order: per owner, a wave
-// scan of the per-thread counts + a 16 x world table across waves gives every thread its first slot; a batch
-// of 8192 ids is one round (two barriers) instead of eight.
+// A wave owns kIpt * 64 CONSECUTIVE positions per round and reads them 64 at a time (load j = positions 64 j .. 64 j + 63 of
+// its span: one coalesced 512-byte request), so "ascending position" = (wave, j, lane) order: per owner, the ballot of a load
+// gives every lane its rank among the wave's earlier positions, the running popcounts the load's base, and a 16 x world table
+// in LDS the offsets across waves; a batch of 8192 ids is one round (two barriers).
+// (Through r02 a THREAD owned 8 consecutive positions: every load and store instruction then touched 64 different cache
+// lines - 24 such stores and 8 loads per wave and round, ~10 us of line requests on the one CU that runs a table; r03.)
 constexpr int kIpt = 8;
 
 // WORLD is a template parameter: id % WORLD and id / WORLD on int64 are multiply-shift sequences for a constant
@@ -35,7 +38,6 @@ __global__ __launch_bounds__(1024) void route_kernel(RouteTables tabs, int n_tab
   __shared__ int wave_cnt[16][kMaxWorld];
   __shared__ int wave_off[16][kMaxWorld];
   __shared__ int running[kMaxWorld];
-  __shared__ unsigned short thread_excl[kMaxWorld][1024];      // first slot of a thread inside its wave, per owner
   const int t = blockIdx.x;
   const int64_t* __restrict__ ids = tabs.t[t].ids;
   int64_t* __restrict__ pos_flat = tabs.t[t].pos_flat;
@@ -49,30 +51,33 @@ __global__ __launch_bounds__(1024) void route_kernel(RouteTables tabs, int n_tab
   const int64_t chunk = 1024 * kIpt;
   const int64_t rounds = (n + chunk - 1) / chunk;
   for (int64_t r = 0; r < rounds; ++r) {
-    const int64_t base = r * chunk + (int64_t)tid * kIpt;
+    const int64_t base = r * chunk + (int64_t)wave * (64 * kIpt) + lane;      // this lane's position of load 0
     int64_t id[kIpt];
-    int owner[kIpt];
+    int owner[kIpt], loc[kIpt];
+    // all eight ids requested before any is looked at, unconditionally from clamped positions
 #pragma unroll
     for (int j = 0; j < kIpt; ++j) {
-      const int64_t p = base + j;
+      const int64_t p = base + 64 * j;
+      id[j] = ids[p < n ? p : n - 1];
+    }
+#pragma unroll
+    for (int j = 0; j < kIpt; ++j) {
+      const int64_t p = base + 64 * j;
       const bool valid = p < n;
-      id[j] = valid ? ids[p] : 0;
       const bool bad = valid && (id[j] < 0 || id[j] >= num_rows);
       oob = oob || bad;
       owner[j] = (valid && !bad) ? (int)((uint64_t)id[j] % (uint64_t)world) : -1;
+      loc[j] = 0;
     }
     for (int o = 0; o < world; ++o) {
-      int c = 0;
+      int c = 0;                                                               // (wave-uniform) positions of owner o so far
 #pragma unroll
-      for (int j = 0; j < kIpt; ++j) c += owner[j] == o;
-      int incl = c;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const int v = __shfl_up(incl, d);
-        if (lane >= d) incl += v;
+      for (int j = 0; j < kIpt; ++j) {
+        const uint64_t m = __builtin_amdgcn_ballot_w64(owner[j] == o);
+        if (owner[j] == o) loc[j] = c + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        c += (int)__popcll(m);
       }
-      thread_excl[o][tid] = (unsigned short)(incl - c);
-      if (lane == 63) wave_cnt[wave][o] = incl;
+      if (lane == 0) wave_cnt[wave][o] = c;
     }
     __syncthreads();
     if (tid < world) {
@@ -86,27 +91,23 @@ __global__ __launch_bounds__(1024) void route_kernel(RouteTables tabs, int n_tab
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < kIpt; ++j) {
-      const int64_t p = base + j;
-      if (p >= n) break;
-      const int o = owner[j];
-      if (o < 0) {
-        pos_flat[p] = -1;
-        continue;
-      }
-      int before = 0;                       // earlier positions of this thread with the same owner
-#pragma unroll
-      for (int i = 0; i < kIpt; ++i) before += (i < j) && (owner[i] == o);
-      const int slot = wave_off[wave][o] + thread_excl[o][tid] + before;
-      if (slot < cap) {
-        const int64_t flat = ((int64_t)o * n_tables + t) * cap + slot;
-        send_ids[flat] = (int64_t)((uint64_t)id[j] / (uint64_t)world) + local_offset;
+      const int64_t p = base + 64 * j;
+      if (p < n) {
+        const int o = owner[j];
+        int64_t flat = -1;
+        if (o >= 0) {
+          const int slot = wave_off[wave][o] + loc[j];
+          if (slot < cap) {
+            flat = ((int64_t)o * n_tables + t) * cap + slot;
+            send_ids[flat] = (int64_t)((uint64_t)id[j] / (uint64_t)world) + local_offset;
+          } else {
+            over = true;
+          }
+        }
         pos_flat[p] = flat;
-      } else {
-        pos_flat[p] = -1;
-        over = true;
       }
     }
-    __syncthreads();                        // thread_excl / wave_off are rewritten by the next round
+    __syncthreads();                        // wave_cnt / wave_off are rewritten by the next round
   }
   if (flags != nullptr) {
     if (oob) atomicOr(&flags[0], 1);

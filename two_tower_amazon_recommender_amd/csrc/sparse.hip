@@ -635,7 +635,7 @@ __global__ __launch_bounds__(1024) void optimizer_ids_kernel(ApplyArgs a, FusedT
     uint32_t offset, base_key;
     const int g = b - (ti == 2 ? ft.first[2] : (ti == 1 ? ft.first[1] : 0));
     tt::PartScan<JMAX> sc;
-    const uint32_t m = tt::part_scan_append<DBITS, JMAX>(t, g, ft.cap, smem, sc, offset, base_key);
+    const uint32_t m = tt::part_scan_append<DBITS, JMAX, true>(t, g, ft.cap, smem, sc, offset, base_key);
     if (m == 0u) return;
     const uint32_t* K = tt::part_keys(smem);
     const uint16_t* P = tt::part_poss<DBITS>(smem, ft.cap);
