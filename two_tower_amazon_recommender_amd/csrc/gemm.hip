@@ -573,8 +573,14 @@ extern "C" int tt_dense_fwd_dropout_f32(const float* x, const float* w, const fl
 #ifndef TT_DW_MAX_SLABS
 #define TT_DW_MAX_SLABS 32
 #endif
+// Batch rows per dW slab (the slab count is capped at TT_DW_MAX_SLABS).  64: batches below 8192 get more, shorter slabs - the
+// dW tiles' k loop is a chain of load -> barrier -> MFMA rounds, 256 rows of it were 10 of gemm_bwd's 14 us at B = 256
+// (r03 A/B, step time with 256 -> 64: cfg1 51.0 -> 43.8 us, cfg2 124.9 -> 119.6 us, cfg3 / cfg4 unchanged: capped at 32 slabs)
+#ifndef TT_DW_SLAB_ROWS
+#define TT_DW_SLAB_ROWS 64
+#endif
 extern "C" int32_t tt_dense_bwd_num_slabs(int64_t m) {
-  int64_t s = (m + 255) / 256;
+  int64_t s = (m + TT_DW_SLAB_ROWS - 1) / TT_DW_SLAB_ROWS;
   if (s < 1) s = 1;
   if (s > TT_DW_MAX_SLABS) s = TT_DW_MAX_SLABS;
   return (int32_t)s;

@@ -899,46 +899,58 @@ __global__ __launch_bounds__(256) void fwd_combine_kernel(const float* __restric
 }
 
 // FUSED pass 1 epilogue: per-split (max, sum, G) -> lse, per-row loss, the per-row terms of the dc pass, and
-//   dq[r] = (w_r/T*g) * ( sum_s G_s[r]*2^(m_s-M) / L  -  c[r+diag] ).   32 lanes per row, 8 rows per block.
+//   dq[r] = (w_r/T*g) * ( sum_s G_s[r]*2^(m_s-M) / L  -  c[r+diag] ).
+// dim/4 lanes per row (8 .. 64: one float4 column each - no idle half rows at dim 64, no second column trip at dim 256),
+// 256 >> lpr_log2 rows per block.  Splits are taken 8 at a time, every chunk's loads issued together from clamped (valid)
+// split indices; additions in split order.  (Through r02: 32 lanes per row whatever the dim, and the splits past the 8th -
+// B <= 4096 runs 16 or more - one dependent load after the other: 11.9 us at cfg2.)
 __global__ __launch_bounds__(256) void fused_combine_kernel(const float* __restrict__ part_m, const float* __restrict__ part_l,
                                                             const float* __restrict__ pos2, const float* __restrict__ w,
                                                             const f32x4* __restrict__ slab, const f32x4* __restrict__ cpos,
-                                                            int64_t n_r, int d4, int nsplit, float scale,
+                                                            int64_t n_r, int d4, int lpr_log2, int nsplit, float scale,
                                                             float* __restrict__ lse, float* __restrict__ per_row,
                                                             float* __restrict__ aq, float* __restrict__ sq,
                                                             f32x4* __restrict__ dq) {
-  const int64_t row = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
-  const int lane = threadIdx.x & 31;
+  const int rpb = 256 >> lpr_log2;
+  const int64_t row = (int64_t)blockIdx.x * rpb + (threadIdx.x >> lpr_log2);
+  const int lane = threadIdx.x & ((1 << lpr_log2) - 1);
   if (row >= n_r) return;
-  // The slab rows of the first 8 splits (33 of the kernel's 42 MB at cfg3) do not depend on the row statistics: their
-  // loads are issued first, the (max, sum) passes over part_m / part_l run underneath them.
   constexpr int U = 8;
+  const int c = lane < d4 ? lane : d4 - 1;           // (lpr == d4 for the supported dims; clamped all the same)
+  const int last = nsplit - 1;
+  // The slab rows of the first 8 splits do not depend on the row statistics: their loads are issued first, the (max, sum)
+  // passes over part_m / part_l run underneath them.
   f32x4 v0[U];
-  f32x4 cp0 = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (lane < d4) {
-    cp0 = cpos[row * d4 + lane];
+  const f32x4 cp = cpos[row * d4 + c];
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-      v0[u] = u < nsplit ? slab[((int64_t)u * n_r + row) * d4 + lane] : f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  float pm[U], pl[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    pm[u] = u < nsplit ? part_m[(int64_t)u * n_r + row] : kNegBig;
-    pl[u] = u < nsplit ? part_l[(int64_t)u * n_r + row] : 0.f;
-  }
+  for (int u = 0; u < U; ++u) v0[u] = slab[((int64_t)(u < last ? u : last) * n_r + row) * d4 + c];
   const float p2 = pos2[row];
   const float wr = (w != nullptr ? w[row] : 1.0f);
+  float pm0[U];                                      // the first chunk's maxima stay in registers for the sum below
   float M = kNegBig;
+  for (int s0 = 0; s0 < nsplit; s0 += U) {
+    float pm[U];
 #pragma unroll
-  for (int u = 0; u < U; ++u) M = fmaxf(M, pm[u]);
-  for (int s = U; s < nsplit; ++s) M = fmaxf(M, part_m[(int64_t)s * n_r + row]);
+    for (int u = 0; u < U; ++u) pm[u] = part_m[(int64_t)(s0 + u < last ? s0 + u : last) * n_r + row];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      M = fmaxf(M, pm[u]);                           // (a clamped duplicate of the last split changes no maximum)
+      if (s0 == 0) pm0[u] = pm[u];
+    }
+  }
   float L = 0.f;
+  for (int s0 = 0; s0 < nsplit; s0 += U) {
+    float pm[U], pl[U];
 #pragma unroll
-  for (int u = 0; u < U; ++u)
-    if (u < nsplit) L += pl[u] * __builtin_amdgcn_exp2f(pm[u] - M);
-  for (int s = U; s < nsplit; ++s)
-    L += part_l[(int64_t)s * n_r + row] * __builtin_amdgcn_exp2f(part_m[(int64_t)s * n_r + row] - M);
+    for (int u = 0; u < U; ++u) {
+      const int64_t o = (int64_t)(s0 + u < last ? s0 + u : last) * n_r + row;
+      pm[u] = part_m[o];
+      pl[u] = part_l[o];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (s0 + u < nsplit) L += pl[u] * __builtin_amdgcn_exp2f(pm[u] - M);
+  }
   const float lse2 = M + __log2f(L);
   const float sr = wr * scale;
   if (lane == 0) {
@@ -948,23 +960,24 @@ __global__ __launch_bounds__(256) void fused_combine_kernel(const float* __restr
     sq[row] = sr;
   }
   const float inv_l = 1.0f / L;
-  for (int c = lane; c < d4; c += 32) {
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 cp;
-    if (c == lane) {                               // first column chunk: operands already in registers
-      cp = cp0;
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (u < nsplit) acc += v0[u] * __builtin_amdgcn_exp2f(pm[u] - M);
-    } else {
-      cp = cpos[row * d4 + c];
-      for (int s = 0; s < nsplit && s < U; ++s)
-        acc += slab[((int64_t)s * n_r + row) * d4 + c] * __builtin_amdgcn_exp2f(part_m[(int64_t)s * n_r + row] - M);
+  for (int u = 0; u < U; ++u)
+    if (u < nsplit) acc += v0[u] * __builtin_amdgcn_exp2f(pm0[u] - M);
+  for (int s0 = U; s0 < nsplit; s0 += U) {           // splits beyond the first 8, in order, 8 loads at a time
+    f32x4 v[U];
+    float pm[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t sidx = s0 + u < last ? s0 + u : last;
+      v[u] = slab[(sidx * n_r + row) * d4 + c];
+      pm[u] = part_m[sidx * n_r + row];
     }
-    for (int s = U; s < nsplit; ++s)               // splits beyond the first 8, in order
-      acc += slab[((int64_t)s * n_r + row) * d4 + c] * __builtin_amdgcn_exp2f(part_m[(int64_t)s * n_r + row] - M);
-    dq[row * d4 + c] = (acc * inv_l - cp) * sr;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (s0 + u < nsplit) acc += v[u] * __builtin_amdgcn_exp2f(pm[u] - M);
   }
+  if (lane < d4) dq[row * d4 + lane] = (acc * inv_l - cp) * sr;
 }
 
 // thr[r] = c1 * <q_r, c_pos(r)> + bias[pos(r)]  (log2 domain): the positive's logit, 32 lanes per row
@@ -1486,9 +1499,12 @@ static int retrieval_fwd_bwd(int prec, const float* q, const float* c, int64_t n
     if (rc != TT_OK) return rc;
     {
       tt::ProfScope prof("score_aux", stream);
-      hipLaunchKernelGGL(fused_combine_kernel, dim3((unsigned)((nq + 7) / 8)), dim3(256), 0, stream, a.part_m, a.part_l, a.pos2,
+      int lpr_log2 = 3;                              // dim/4 lanes per row: 8 (dim 32) .. 64 (dim 256)
+      while ((1 << lpr_log2) < dim / 4) ++lpr_log2;
+      const int rpb = 256 >> lpr_log2;
+      hipLaunchKernelGGL(fused_combine_kernel, dim3((unsigned)((nq + rpb - 1) / rpb)), dim3(256), 0, stream, a.part_m, a.part_l, a.pos2,
                          sample_weight, reinterpret_cast<const f32x4*>(slab),
-                         reinterpret_cast<const f32x4*>(c + diag_offset * dim), nq, dim / 4, a.nsplit,
+                         reinterpret_cast<const f32x4*>(c + diag_offset * dim), nq, dim / 4, lpr_log2, a.nsplit,
                          inv_temperature * grad_scale, lse, per_row, aq, sq, reinterpret_cast<f32x4*>(dq));
       if ((rc = tt::check_launch("fused_combine")) != TT_OK) return rc;
       // loss = sum(per_row): by one extra workgroup of the dc slab reduction below

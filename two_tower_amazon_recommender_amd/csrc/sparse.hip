@@ -871,8 +871,7 @@ extern "C" int tt_optimizer_step_ids_f32(int32_t opt, const tt_sparse_table_ids*
     tt::PartTable& p = ft.part[t];
     p.ids = s.ids; p.sorted_ids = nullptr; p.order = nullptr; p.num_rows = s.rows; p.n = (int32_t)n_ids;
     int64_t g = (n_ids + 63) / 64;
-    if (g > 128) g = 128;
-    if (g > group_cap) g = group_cap;
+    if (g > group_cap) g = group_cap;              // (one table - a sharded owner's combined shard - takes all the CUs the dense blocks leave)
     if (g > s.rows / 2) g = s.rows / 2;
     p.groups = g < 1 ? 1 : (int32_t)g;
     p.width = (uint32_t)((s.rows + p.groups - 1) / p.groups);
