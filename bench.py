@@ -228,7 +228,8 @@ def main():
     # materialised input), measured by a second untimed detail pass with the lookup un-fused (gather2 launch + acts[0])
     n_layers = len(tower_dims)
     lookup_us, unfused = None, {}
-    if trainer.fuse_lookup and cfg.symmetric and not args.graph:
+    lookup_fused = trainer.fuse_lookup          # (False by default when the first tower layer is 512 wide: trainer.py)
+    if cfg.symmetric and not args.graph:
         trainer.fuse_lookup = trainer.fuse_optimizer = False      # every kernel as its own launch
         _lib.profile_enable("dense_fwd,dense_bwd,gather,sparse_apply,sparse_plan,dense_update", capacity=2 * n_layers * detail_steps + 8)
         for s in range(total - detail_steps, total):
@@ -236,12 +237,13 @@ def main():
         torch.cuda.synchronize()
         unfused = {t: _lib.profile_read(t, 2 * n_layers * detail_steps + 8)[0]
                    for t in ("dense_fwd", "dense_bwd", "gather", "sparse_apply", "sparse_plan", "dense_update")}
-        trainer.fuse_lookup = trainer.fuse_optimizer = True
-        # (forward launches per step: n_layers, or ONE when the two-layer tower forward is fused - csrc/tower.hip - in both passes)
-        fps = max(len(prof["dense_fwd"]) // detail_steps, 1)
-        f_l0 = mean(prof["dense_fwd"][0::fps]) - mean(unfused["dense_fwd"][0::fps])
-        b_l0 = mean(prof["dense_bwd"][n_layers - 1::n_layers]) - mean(unfused["dense_bwd"][n_layers - 1::n_layers])
-        lookup_us = (f_l0 + b_l0) * 1e3
+        trainer.fuse_lookup, trainer.fuse_optimizer = lookup_fused, True
+        if lookup_fused:
+            # (forward launches per step: n_layers, or ONE when the two-layer tower forward is fused - csrc/tower.hip - in both passes)
+            fps = max(len(prof["dense_fwd"]) // detail_steps, 1)
+            f_l0 = mean(prof["dense_fwd"][0::fps]) - mean(unfused["dense_fwd"][0::fps])
+            b_l0 = mean(prof["dense_bwd"][n_layers - 1::n_layers]) - mean(unfused["dense_bwd"][n_layers - 1::n_layers])
+            lookup_us = (f_l0 + b_l0) * 1e3
     # ---- second, separately labelled measurement: the same train step with the scorer's matrix products in the
     # f32-EMULATED bf16x3 precision (three-way bf16 split on the bf16 MFMA; same 1e-4 parity bars).  Never the headline:
     # `value` / `roofline` above are the exact-f32 run.
@@ -346,9 +348,12 @@ def main():
                        f"from an untimed detail pass of {detail_steps} further steps",
         "roofline": dominant,
         "roofline_hbm": {"bound": "hbm",
-                         "kernel": "K1 + K2 on the critical path: the embedding lookup fused into the first tower layer's GEMM "
-                                   "loaders (time = what the layer-0 fwd and bwd launches cost MORE than on a materialised "
-                                   "input, from an un-fused detail pass) + "
+                         "kernel": "K1 + K2 on the critical path: "
+                                   + ("the embedding lookup fused into the first tower layer's GEMM "
+                                      "loaders (time = what the layer-0 fwd and bwd launches cost MORE than on a materialised "
+                                      "input, from an un-fused detail pass) + " if lookup_fused else
+                                      "gather2 (the lookup as its own launch, both towers: gather_us) + ")
+                                   + ""
                                    + ("optimizer_ids_kernel, the step's ONE optimizer launch, whole duration: every table's ids "
                                       "are sorted per row range in LDS by the workgroups that then sum the duplicate gradient rows "
                                       "and apply fused SGD/Adagrad to exactly those rows (no plan launch, no sorted ids in HBM); "

@@ -34,7 +34,7 @@ def encode_categories(values, unknown="Unknown") -> tuple[np.ndarray, list]:
 def encode_ids_utf8(values) -> np.ndarray:
     """Same ranks computed the way a byte-oriented (C/GPU) encoder would: sort the
     UTF-8 encodings bytewise.  Must equal encode_ids (code-point order == UTF-8
-    byte order); checked in tests/test_id_encoding.py."""
+    byte order); checked in tests/test_oracle_cpu.py."""
     enc = [v.encode("utf-8") for v in values]
     vocab = sorted(set(enc))
     lut = {v: i for i, v in enumerate(vocab)}

@@ -6,7 +6,9 @@ cnt = collections.Counter(r["Queue_Id"] for r in rows if "score_kernel" in r["Ke
 q = cnt.most_common(1)[0][0]
 rows = sorted((r for r in rows if r["Queue_Id"] == q), key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "")[:46] for r in rows]
-g = [i for i, n in enumerate(names) if n.startswith("gemm_kernel<true, false, false, 1")]   # layer-0 forward (fused lookup) opens a step
+# a step opens with the forward pass: the fused two-layer tower kernel (r03), else the layer-0 GEMM with the fused lookup
+opener = "tower_fwd2_kernel" if any(n.startswith("tower_fwd2_kernel") for n in names) else "gemm_kernel<true, false, false, 1"
+g = [i for i, n in enumerate(names) if n.startswith(opener)]
 steps = [(g[k], g[k + 1]) for k in range(len(g) - 1)]
 # the timed region's steps only: the usual kernel count, exact-f32 scorer, fused optimizer launch
 steps = [(a, b) for a, b in steps if b - a <= 12 and any("score_kernel<128, 4, false, false, 4, 0>" in names[j] or

@@ -293,3 +293,55 @@ def test_two_tables_one_exchange(world):
     mp.spawn(_worker_combined, args=(world, _free_port(), ret), nprocs=world, join=True)
     for r in range(world):
         assert ret.get(r) == "ok", f"rank {r}: {ret.get(r)}"
+
+
+def _worker_cand_ids(rank, world, port, ret):
+    """The all-gathers that build the global-negatives candidate set, as ShardedTwoTowerTrainer issues them (C4 for the
+    embeddings, _cand_ids / _cand_prob for their ids and sampling probabilities): gloo, no GPU."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from types import SimpleNamespace
+        from two_tower_amazon_recommender_amd.sharded import ShardedTwoTowerTrainer as T
+        b, d = 5, 4
+        me = SimpleNamespace(negatives="global", collectives=True, world=world, rank=rank, dev=torch.device("cpu"),
+                             group=dist.group.WORLD, cfg=SimpleNamespace(batch_size=b))
+        ids = torch.arange(b, dtype=torch.int64) * 7 + 1000 * rank                  # rank r's candidate ids
+        prob = (torch.arange(b, dtype=torch.float32) + 1) / (10.0 * (rank + 1))
+        c = ids.to(torch.float32)[:, None].repeat(1, d)                             # an embedding row that names its id
+        id_all = T._cand_ids(me, ids)
+        p_all = T._cand_prob(me, prob)
+        c_all = torch.empty(world * b, d)
+        dist.all_gather_into_tensor(c_all, c, group=me.group)                       # C4, exactly as in step() / evaluate()
+        # rank-major order, the same for all three; this rank's own candidates (the positives) start at diag_offset = rank * b
+        assert id_all.shape == (world * b,) and p_all.shape == (world * b,)
+        for r in range(world):
+            assert torch.equal(id_all[r * b:(r + 1) * b], torch.arange(b, dtype=torch.int64) * 7 + 1000 * r)
+            assert torch.equal(p_all[r * b:(r + 1) * b], (torch.arange(b, dtype=torch.float32) + 1) / (10.0 * (r + 1)))
+        assert torch.equal(c_all[:, 0].to(torch.int64), id_all)                     # row i of c_all IS candidate id_all[i]
+        off = rank * b
+        assert torch.equal(id_all[off:off + b], ids) and torch.equal(p_all[off:off + b], prob)
+        # local negatives / no collectives: the rank's own tensors, untouched
+        me.negatives = "local"
+        assert T._cand_ids(me, ids) is ids and T._cand_prob(me, prob) is prob
+        me.negatives, me.collectives = "global", False
+        assert T._cand_ids(me, ids) is ids and T._cand_ids(me, None) is None
+        ret[rank] = "ok"
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        ret[rank] = traceback.format_exc() + repr(e)
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_global_negatives_candidate_ids_follow_the_candidate_rows(world):
+    """id_all / p_all must be in the order of c_all (rank-major) and a rank's own block must start at its
+    diag_offset = rank * batch - otherwise accidental-hit removal and the log-Q correction act on the wrong columns."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_cand_ids, args=(world, _free_port(), ret), nprocs=world, join=True)
+    for r in range(world):
+        assert ret.get(r) == "ok", f"rank {r}: {ret.get(r)}"

@@ -258,7 +258,11 @@ class TwoTowerTrainer:
         # cost more than the kernel: cfg3 step 0.687-0.689 ms against 0.677-0.681 ms; DESIGN.md section 4, K2 plan)
         self.plan_on_side_stream = os.environ.get("TT_PLAN_STREAM", "main") == "side"
         self.step_index = 0                      # counter of the dropout stream (global batch row = step*batch + r)
-        self.fuse_lookup = True                  # K1 inside the first tower layer's GEMMs (False: gather2 launch + acts[0])
+        # K1 inside the first tower layer's GEMMs (0: gather2 launch + acts[0]).  Every 64-column tile of the first layer reads
+        # the embedding rows through the ids again: up to 256 columns that costs less than materialising them (cfg3: 13.6 us
+        # of gather against +3.6 us in the GEMMs; cfg4 1.875 vs 1.881 ms), at 512 columns it costs more (cfg5: the layer-0
+        # launches 99 us longer, the gather 55 us; step 15.28 vs 15.24 ms) - r03 A/B
+        self.fuse_lookup = os.environ.get("TT_FUSE_LOOKUP", "1" if cfg.tower_dims[0] < 512 else "0") != "0"
         self.fuse_sort = os.environ.get("TT_FUSE_SORT", "1") != "0"   # the optimizer launch sorts the ids itself (no plan launch)
         self.fuse_optimizer = True               # sparse + dense optimizer in one launch (False: dense_update, sparse_update2 [, cat])
         # the whole step behind ONE C call (tt_train_step_f32: the same nine launches, enqueued in C - one FFI crossing per step
