@@ -11,7 +11,7 @@ using tt::SegTable;
 
 template <int OPT>
 __global__ __launch_bounds__(256) void dense_update_kernel(SegTable tbl, int apply, float lr, float eps) {
-  tt::dense_update_body<OPT>(tbl.seg[blockIdx.y], blockIdx.x, gridDim.x, apply, lr, eps);
+  tt::dense_update_body<OPT, 256, 16>(tbl.seg[blockIdx.y], blockIdx.x, gridDim.x, apply, lr, eps);
 }
 
 }  // namespace

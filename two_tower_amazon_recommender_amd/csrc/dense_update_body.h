@@ -37,20 +37,21 @@ __device__ __forceinline__ float apply_val(float w, float& acc, float g, float l
   }
 }
 
-// One thread owns 4 consecutive elements (float4 loads when the segment allows it) and keeps 16 slabs' loads in flight -
+// One thread owns 4 consecutive elements (float4 loads when the segment allows it) and keeps U (8 or 16) slabs' loads in flight -
 // together with the element's parameter (and accumulator) float4, requested FIRST; the additions stay in slab order (the
-// oracle's order).  All loads are unconditional from clamped slab indices: 32 slabs are two memory round trips.  (Through
+// oracle's order).  All loads are unconditional from clamped slab indices: with U = 16, 32 slabs are two memory round trips.  (Through
 // r02: 8 in flight behind a first load of slab 0 and in front of four scalar parameter loads - six dependent round trips,
 // 5 us for the step's 18 MB on the 36 CUs the fused optimizer launch leaves for it; r03 stamps.)
 // (TPB = threads per block of the launch; every element is summed and updated on its own, so TPB changes nothing in the results)
-template <int OPT, int TPB = 256>
+// (U = slab loads in flight per thread: 16 where the kernel has the registers - 64 VGPRs of loads -, 8 inside kernels bound to
+// 8 waves per SIMD)
+template <int OPT, int TPB = 256, int U = 8>
 __device__ __forceinline__ void dense_update_body(const tt_dense_seg& s, const int bx, const int nbx, int apply, float lr, float eps) {
   const int64_t stride = (int64_t)nbx * TPB;
   const bool vec = (s.count % 4 == 0) && (s.slab_stride % 4 == 0) && al16(s.grad_slabs) &&
                    (s.grad_out == nullptr || al16(s.grad_out)) && (!apply || al16(s.param)) &&
                    (!apply || OPT == TT_OPT_SGD || al16(s.accum));
   if (vec) {
-    constexpr int U = 16;
     const int64_t n4 = s.count / 4, st4 = s.slab_stride / 4;
     const f32x4* __restrict__ gs = reinterpret_cast<const f32x4*>(s.grad_slabs);
     const int ns = s.n_slabs;

@@ -184,7 +184,7 @@ __device__ TT_TAIL_ATTR void finish_run_piece(f32x4* __restrict__ table, f32x4* 
 // the piece that draws the last ticket acquires, adds the pieces in INDEX order (never arrival order: bitwise
 // reproducible) and applies the update.  A block holds at most one run head that continues past its end, so the counter is
 // unambiguous; the last arriver leaves it at 0 for the next launch.
-template <int OPT>
+template <int OPT, bool AHEAD = true>
 __device__ __forceinline__ void sparse_apply_body(const ApplyArgs& a, const int t, const int64_t bx, int dim4, int lpr_log2,
                                                   int64_t n_ids, float lr, float eps) {
   f32x4* __restrict__ table = reinterpret_cast<f32x4*>(a.table[t]);
@@ -199,15 +199,29 @@ __device__ __forceinline__ void sparse_apply_body(const ApplyArgs& a, const int 
   const int64_t k = bx * groups + (threadIdx.x >> lpr_log2);   // sorted slot
   const int l = threadIdx.x & (lpr - 1);
   if (k >= n_ids) return;
+  // One round trip for everything the slot's position gives: its id, both neighbours, its batch position - then ONE more for
+  // the gradient row together with the table (accumulator) row.  (Through r02 five dependent ones: id and left neighbour,
+  // right neighbour, batch position, gradient row, table row; the 1M-id Adagrad line was 11 % behind r01h.)
   const int64_t id = sid[k];
-  const bool run_head = (k == 0) || (sid[k - 1] != id);
+  const int64_t id_left = sid[k > 0 ? k - 1 : 0], id_right = sid[k + 1 < n_ids ? k + 1 : n_ids - 1];
+  const int32_t ord0 = order[k];
+  const bool run_head = (k == 0) || (id_left != id);
   const bool boundary = (k % kPiece) == 0;
   if (!run_head && !boundary) return;             // inside a piece
   if (id < 0 || id >= rows) return;               // out-of-range / padding ids (the plan's sentinel) are skipped
+  const int lc = l < dim4 ? l : dim4 - 1;
+  // (SGD: the table row with the gradient row.  Adagrad has no registers left for two more rows at 8 waves per SIMD - with
+  // them it spills 20-72 B per lane and the 1M-id lines get 6 % slower, at 6 waves they are level - so its rows are read
+  // where they are needed; r03 A/B on one box, SGD U/Z 371/544 -> 354/523 us.)
+  // (AHEAD = false: inside optimizer_kernel, whose dense half needs the registers too)
+  constexpr bool ROW_AHEAD = AHEAD && OPT == TT_OPT_SGD;
+  const f32x4 g_first = grads[(int64_t)ord0 * dim4 + lc];
+  f32x4 w_first = f32x4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (ROW_AHEAD) w_first = table[id * dim4 + lc];
   int64_t pend = (k / kPiece + 1) * kPiece;       // this piece ends at the next 64-slot boundary at the latest
   if (pend > n_ids) pend = n_ids;
-  int64_t e = k + 1;                              // end of this piece: one id load for the usual run of length 1,
-  if (e < pend && sid[e] == id) {                 // else a binary search (sorted ids): <= 6 dependent loads per piece
+  int64_t e = k + 1;                              // end of this piece: known from the right neighbour for the usual run of length 1,
+  if (e < pend && id_right == id) {               // else a binary search (sorted ids): <= 6 dependent loads per piece
     int64_t lo = e + 1, hi = pend;
     while (lo < hi) {
       const int64_t mid = (lo + hi) >> 1;
@@ -220,7 +234,7 @@ __device__ __forceinline__ void sparse_apply_body(const ApplyArgs& a, const int 
   const int64_t blk = k / kPiece;
 
   for (int c = l; c < dim4; c += lpr) {
-    f32x4 g = grads[(int64_t)order[k] * dim4 + c];
+    f32x4 g = c == l ? g_first : grads[(int64_t)ord0 * dim4 + c];
     // sequential walk over [k, e); four independent row loads in flight (more would cost a wave of occupancy,
     // which the random single-row case — almost every slot — needs more)
     int64_t j = k + 1;
@@ -240,8 +254,9 @@ __device__ __forceinline__ void sparse_apply_body(const ApplyArgs& a, const int 
       for (int e = 0; e < 4; ++e) g[e] = __fadd_rn(g[e], g1[e]);
       ++j;
     }
-    if (whole) {
-      update_row<OPT>(table, accum, id * dim4 + c, g, lr, eps);           // whole run summed: fused update
+    if (whole) {                                                          // whole run summed: fused update
+      if (ROW_AHEAD && c == l) update_store<OPT>(table, accum, id * dim4 + c, w_first, w_first, g, lr, eps);
+      else update_row<OPT>(table, accum, id * dim4 + c, g, lr, eps);
     } else if (run_head) {
       store_piece(reinterpret_cast<f32x4*>(a.p_sum[t]) + blk * dim4 + c, g);   // first piece of a long run
     } else {
@@ -253,8 +268,11 @@ __device__ __forceinline__ void sparse_apply_body(const ApplyArgs& a, const int 
                         a.p_flag[t], k, e, pend, id, run_head, continues, dim4, lpr_log2, n_ids, lr, eps);
 }
 
+#ifndef TT_APPLY_WAVES
+#define TT_APPLY_WAVES 8      // min waves per SIMD of the large-list kernels (8: 64 VGPRs, 6: 80)
+#endif
 template <int OPT>
-__global__ __launch_bounds__(256, 8) void sparse_apply_kernel(ApplyArgs a, int dim4, int lpr_log2, int64_t n_ids, float lr,
+__global__ __launch_bounds__(256, TT_APPLY_WAVES) void sparse_apply_kernel(ApplyArgs a, int dim4, int lpr_log2, int64_t n_ids, float lr,
                                                            float eps) {
   sparse_apply_body<OPT>(a, blockIdx.y, blockIdx.x, dim4, lpr_log2, n_ids, lr, eps);
 }
@@ -263,11 +281,11 @@ __global__ __launch_bounds__(256, 8) void sparse_apply_kernel(ApplyArgs a, int d
 // else dense segment y - n_tables (csrc/dense_update_body.h).  The two halves are independent and both memory-bound; as
 // two launches they cost 7.5 + 9.0 us plus a launch boundary per step.
 template <int OPT>
-__global__ __launch_bounds__(256, 8) void optimizer_kernel(ApplyArgs a, int n_tables, int dim4, int lpr_log2, int64_t n_ids,
+__global__ __launch_bounds__(256, TT_APPLY_WAVES) void optimizer_kernel(ApplyArgs a, int n_tables, int dim4, int lpr_log2, int64_t n_ids,
                                                          int64_t sparse_blocks, tt::SegTable tbl, int dense_blocks, float lr,
                                                          float eps) {
   if ((int)blockIdx.y < n_tables) {
-    if ((int64_t)blockIdx.x < sparse_blocks) sparse_apply_body<OPT>(a, blockIdx.y, blockIdx.x, dim4, lpr_log2, n_ids, lr, eps);
+    if ((int64_t)blockIdx.x < sparse_blocks) sparse_apply_body<OPT, false>(a, blockIdx.y, blockIdx.x, dim4, lpr_log2, n_ids, lr, eps);
   } else if ((int)blockIdx.x < dense_blocks) {
     tt::dense_update_body<OPT>(tbl.seg[blockIdx.y - n_tables], blockIdx.x, dense_blocks, 1, lr, eps);
   }
@@ -669,7 +687,7 @@ __global__ __launch_bounds__(1024) void optimizer_ids_kernel(ApplyArgs a, FusedT
     int si = 0;
     while (si + 1 < dense_blocks && d >= ft.seg_first[si + 1]) ++si;        // (dense_blocks = number of segments here)
     SSTAMP(0);
-    tt::dense_update_body<OPT, 1024>(tbl.seg[si], d - ft.seg_first[si], ft.seg_first[si + 1] - ft.seg_first[si], 1, lr, eps);
+    tt::dense_update_body<OPT, 1024, 16>(tbl.seg[si], d - ft.seg_first[si], ft.seg_first[si + 1] - ft.seg_first[si], 1, lr, eps);
     SSTAMP(6);
   }
 }
