@@ -39,20 +39,10 @@ struct ApplyArgs {
   int32_t* p_flag[kMaxSparseTables];   // [nblk]       arrival ticket of the deferred run whose head is in block j (0 between launches)
 };
 
-// TT_OPT_NT_STORES=1: the updated rows leave with nontemporal stores (A/B hook).  Measured on one box: the cfg3 optimizer
-// launch 15.1 -> 14.8 us, but the large-list kernel over 1M ids 351 -> 370 us (SGD/U), 512 -> 544 us (Adagrad/U), 535 -> 546
-// and 642 -> 661 us (Z): off.
-#ifndef TT_OPT_NT_STORES
-#define TT_OPT_NT_STORES 0
-#endif
-#if TT_OPT_NT_STORES
-#define TT_ROW_STORE(ptr, v) __builtin_nontemporal_store((v), (ptr))
-#else
-#define TT_ROW_STORE(ptr, v) (*(ptr) = (v))
-#endif
-
-// the update of 4 elements of a row given its (already loaded) weights w and accumulator acc
-template <int OPT>
+// NT: the updated rows leave with nontemporal stores.  Only the fused optimizer launch's rank-free path uses them (fast_apply:
+// the end-of-kernel write-back has less left to do, cfg3 launch 15.1 -> 14.8 us in r03's A/B); for the large-list kernel
+// the same stores cost 5 % (1M ids: 351 -> 370 us SGD/U, 512 -> 544 us Adagrad/U), so everything else stores normally.
+template <int OPT, bool NT = false>
 __device__ __forceinline__ void update_store(f32x4* __restrict__ table, f32x4* __restrict__ accum, int64_t off, f32x4 w, f32x4 acc,
                                              const f32x4& g, float lr, float eps) {
   if constexpr (OPT == TT_OPT_SGD) {
@@ -65,9 +55,9 @@ __device__ __forceinline__ void update_store(f32x4* __restrict__ table, f32x4* _
       const float den = sqrtf(__fadd_rn(acc[e], eps));
       w[e] = __fsub_rn(w[e], __fdiv_rn(__fmul_rn(lr, g[e]), den));
     }
-    TT_ROW_STORE(accum + off, acc);
+    if constexpr (NT) __builtin_nontemporal_store(acc, accum + off); else accum[off] = acc;
   }
-  TT_ROW_STORE(table + off, w);
+  if constexpr (NT) __builtin_nontemporal_store(w, table + off); else table[off] = w;
 }
 
 template <int OPT>
@@ -268,6 +258,15 @@ __device__ __forceinline__ void sparse_apply_body(const ApplyArgs& a, const int 
                         a.p_flag[t], k, e, pend, id, run_head, continues, dim4, lpr_log2, n_ids, lr, eps);
 }
 
+// TT_OPT_PREFETCH=1: the fused optimizer touches every line of a row the moment the scan finds its id (optimizer_ids_kernel).
+// Built, measured three ways on cfg3 and left OFF: the rows do arrive earlier (apply phase 4.9 -> 3.6-3.8 us between the
+// stamps) but issuing the touches costs the scan more than that - a load instruction occupies the address path for a whole
+// wave however few lanes are active, and the per-id broadcast / address arithmetic runs on every wave: launch 12.6 us ->
+// 14.1 (per lane and line, inside the classification loop: its in-order vmcnt waits then also wait for the touches),
+// 13.7 (same, after the loop), 13.25 us (one instruction per id, 12 lanes = the row's lines).  profiles/r03_optimizer_ab.txt
+#ifndef TT_OPT_PREFETCH
+#define TT_OPT_PREFETCH 0
+#endif
 #ifndef TT_APPLY_WAVES
 #define TT_APPLY_WAVES 8      // min waves per SIMD of the large-list kernels (8: 64 VGPRs, 6: 80)
 #endif
@@ -443,7 +442,7 @@ __device__ __forceinline__ uint32_t fast_apply(const ApplyArgs& a, const int t, 
 #pragma unroll
   for (int r = 0; r < RP; ++r)
     if (((put >> r) & 1u) && l < (uint32_t)dim4)
-      update_store<OPT>(table, accum, ((int64_t)base_key + key[r]) * dim4 + l, w[r], ac[r], g[r], lr, eps);
+      update_store<OPT, true>(table, accum, ((int64_t)base_key + key[r]) * dim4 + l, w[r], ac[r], g[r], lr, eps);
   return slow;
 }
 
@@ -653,7 +652,42 @@ __global__ __launch_bounds__(1024) void optimizer_ids_kernel(ApplyArgs a, FusedT
     uint32_t offset, base_key;
     const int g = b - (ti == 2 ? ft.first[2] : (ti == 1 ? ft.first[1] : 0));
     tt::PartScan<JMAX> sc;
-    const uint32_t m = tt::part_scan_append<DBITS, JMAX, true>(t, g, ft.cap, smem, sc, offset, base_key);
+    // (TT_OPT_PREFETCH, off - see the top of the file: the rows' trip from HBM started at the scan.  A wave that finds an id of
+    // this workgroup's range touches every 128-byte line of that id's table (accumulator) row and of its gradient row with a
+    // 4-byte load nobody reads; inline asm, the destination is one scratch VGPR kept reserved until the apply phase has
+    // waited for its own, later loads.)
+    uint32_t sink = 0u;
+    [[maybe_unused]] const char* pf_tab = reinterpret_cast<const char*>(a.table[ti]);
+    [[maybe_unused]] const char* pf_acc = reinterpret_cast<const char*>(a.accum[ti]);
+    [[maybe_unused]] const char* pf_grd = reinterpret_cast<const char*>(a.grads[ti]);
+    [[maybe_unused]] const int row_bytes = dim4 * 16;
+    // ONE load instruction per id of the range: its key and position are broadcast from the lane that holds them, lane 4 s + i
+    // of the wave touches line i of row s (s = 0 table, 1 gradient, 2 accumulator).  (A load instruction occupies the address
+    // path for a whole wave however few lanes are active - one instruction per lane and line, the first form of this
+    // prefetch, cost more than the rows' earlier arrival saved: launch 12.6 -> 13.7 us.)
+    const int lines = row_bytes >> 7;                                   // 128-byte lines per row (dim 128: 4)
+    const int pf_lane = (int)(threadIdx.x & 63u);
+    const int pf_div = lines > 0 ? lines : 1;
+    const int pf_seg = pf_lane / pf_div;
+    // this lane's row base + line offset, chosen once (plain selects: indexed by pf_seg the three pointers became a scratch array)
+    const char* pf_base = pf_tab;
+    if (pf_seg == 1) pf_base = pf_grd;
+    if (pf_seg == 2) pf_base = pf_acc;
+    pf_base += 128 * (pf_lane % pf_div);
+    const bool pf_by_pos = pf_seg == 1;
+    const bool pf_on = lines > 0 && pf_seg < (OPT != TT_OPT_SGD ? 3 : 2);
+    auto prefetch = [&](uint64_t mask, uint32_t key, uint32_t pos) {
+#if TT_OPT_PREFETCH
+      while (mask != 0ull) {
+        const int b = __builtin_ctzll(mask);
+        mask &= mask - 1ull;
+        const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, b), p = (uint32_t)__builtin_amdgcn_readlane((int)pos, b);
+        const char* addr = pf_base + (int64_t)(pf_by_pos ? p : k) * row_bytes;
+        if (pf_on) asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(addr) : "memory");
+      }
+#endif
+    };
+    const uint32_t m = tt::part_scan_append<DBITS, JMAX, true>(t, g, ft.cap, smem, sc, offset, base_key, prefetch);
     if (m == 0u) return;
     const uint32_t* K = tt::part_keys(smem);
     const uint16_t* P = tt::part_poss<DBITS>(smem, ft.cap);
@@ -664,7 +698,7 @@ __global__ __launch_bounds__(1024) void optimizer_ids_kernel(ApplyArgs a, FusedT
         // if some id of the range occurs three times or more, and then only those pairs go through it
         const uint32_t todo = fast_apply<OPT>(a, ti, K, P, m, base_key, dim4, lpr_log2, lr, eps, &s_slow);
         SSTAMP(3);                         // (fast_apply holds the workgroup barrier: s_slow is final, the unordered list read)
-        if (s_slow == 0) { SSTAMP(5); SSTAMP(6); return; }
+        if (s_slow == 0) { SSTAMP(5); SSTAMP(6); asm volatile("" :: "v"(sink)); return; }
         tt::part_rank_small<DBITS, false>(t, ft.cap, smem, m, offset, base_key);
         apply_from_lds<OPT, DBITS, true, false>(a, ti, K, P, tt::part_ranks(smem, ft.cap), m, offset, base_key, dim4, lpr_log2, lr, eps,
                                                 &s_multi, none, todo);
@@ -682,6 +716,7 @@ __global__ __launch_bounds__(1024) void optimizer_ids_kernel(ApplyArgs a, FusedT
       apply_from_lds<OPT, DBITS, false, false>(a, ti, K, P, nullptr, m, offset, base_key, dim4, lpr_log2, lr, eps, &s_multi, none, 0u);
     }
     SSTAMP(6);
+    asm volatile("" :: "v"(sink));                 // (the scratch VGPR of the prefetch loads stays reserved to here)
   } else {
     const int d = (int)blockIdx.x;
     int si = 0;
