@@ -657,10 +657,11 @@ __global__ __launch_bounds__(1024) void optimizer_ids_kernel(ApplyArgs a, FusedT
     // 4-byte load nobody reads; inline asm, the destination is one scratch VGPR kept reserved until the apply phase has
     // waited for its own, later loads.)
     uint32_t sink = 0u;
-    [[maybe_unused]] const char* pf_tab = reinterpret_cast<const char*>(a.table[ti]);
-    [[maybe_unused]] const char* pf_acc = reinterpret_cast<const char*>(a.accum[ti]);
-    [[maybe_unused]] const char* pf_grd = reinterpret_cast<const char*>(a.grads[ti]);
-    [[maybe_unused]] const int row_bytes = dim4 * 16;
+#if TT_OPT_PREFETCH
+    const char* pf_tab = reinterpret_cast<const char*>(a.table[ti]);
+    const char* pf_acc = reinterpret_cast<const char*>(a.accum[ti]);
+    const char* pf_grd = reinterpret_cast<const char*>(a.grads[ti]);
+    const int row_bytes = dim4 * 16;
     // ONE load instruction per id of the range: its key and position are broadcast from the lane that holds them, lane 4 s + i
     // of the wave touches line i of row s (s = 0 table, 1 gradient, 2 accumulator).  (A load instruction occupies the address
     // path for a whole wave however few lanes are active - one instruction per lane and line, the first form of this
@@ -677,7 +678,6 @@ __global__ __launch_bounds__(1024) void optimizer_ids_kernel(ApplyArgs a, FusedT
     const bool pf_by_pos = pf_seg == 1;
     const bool pf_on = lines > 0 && pf_seg < (OPT != TT_OPT_SGD ? 3 : 2);
     auto prefetch = [&](uint64_t mask, uint32_t key, uint32_t pos) {
-#if TT_OPT_PREFETCH
       while (mask != 0ull) {
         const int b = __builtin_ctzll(mask);
         mask &= mask - 1ull;
@@ -685,9 +685,11 @@ __global__ __launch_bounds__(1024) void optimizer_ids_kernel(ApplyArgs a, FusedT
         const char* addr = pf_base + (int64_t)(pf_by_pos ? p : k) * row_bytes;
         if (pf_on) asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(addr) : "memory");
       }
-#endif
     };
     const uint32_t m = tt::part_scan_append<DBITS, JMAX, true>(t, g, ft.cap, smem, sc, offset, base_key, prefetch);
+#else
+    const uint32_t m = tt::part_scan_append<DBITS, JMAX, true>(t, g, ft.cap, smem, sc, offset, base_key);
+#endif
     if (m == 0u) return;
     const uint32_t* K = tt::part_keys(smem);
     const uint16_t* P = tt::part_poss<DBITS>(smem, ft.cap);
