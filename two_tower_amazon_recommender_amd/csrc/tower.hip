@@ -66,7 +66,8 @@ __device__ unsigned long long g_tstamps[1024 * 8];
 //     the same with one or two tiles of loads in flight - it waits at the barriers, not for the loads;
 //   no LDS weights, every lane loading its own fragment with global_load_dword (one 4-byte load per MFMA): 34.2 us, the same at
 //     2 or 4 workgroups per CU - 32 B/clk/CU of 4-byte requests is what the vector memory pipe delivers;
-//   this form: see profiles/r03_tower_forms.txt.
+//   this form (private per-wave LDS buffer + register ring, 16-byte output stores from LDS, ids first): 29.6 us - the steps in
+//     between and the stamps are in profiles/r03_tower_forms.txt.
 #ifndef TT_TOWER_PF
 #define TT_TOWER_PF 2             // weight sub-tiles of loads in flight per wave (register ring)
 #endif
