@@ -101,6 +101,29 @@ PMC_FILE = next((f for f in ("profiles/r03_pmc_cfg3_sgd.json", "profiles/r02_pmc
                  if os.path.exists(os.path.join(ROOT, f))), "profiles/r02_pmc_cfg3_sgd.json")
 
 
+# rocprofv3 --kernel-trace --stats of `bench.py --steps 200 --warmup 20` (scratch/prof.sh), newest committed round
+KSTATS_FILE = next((f for f in ("profiles/r03_bench_cfg3_kernel_stats.csv", "profiles/r02_bench_cfg3_kernel_stats.csv")
+                    if os.path.exists(os.path.join(ROOT, f))), None)
+
+
+def rocprof_avg_us(*needles):
+    """Sum of the average durations (us) of the kernels whose name contains one of `needles`, from the COMMITTED rocprofv3
+    kernel stats of the cfg3 / sgd step - not measured in this run (hipEvent brackets add ~3 us to launches this short; the
+    profiler's begin / end timestamps do not).  None when the file or a kernel is missing."""
+    try:
+        import csv
+        rows = list(csv.DictReader(open(os.path.join(ROOT, KSTATS_FILE))))
+        tot = 0.0
+        for n in needles:
+            hit = [r for r in rows if n in r["Name"]]
+            if not hit:
+                return None
+            tot += sum(float(r["AverageNs"]) for r in hit) * 1e-3
+        return tot
+    except (OSError, KeyError, ValueError, TypeError):
+        return None
+
+
 def pmc_traffic(tag):
     """HBM bytes per launch of kernel `tag` from the COMMITTED rocprofv3 --pmc summary (separate passes,
     MI355X_MICROARCH.md §HBM corrections applied) — not measured in this run: the line says so in `traffic_source`."""
@@ -375,6 +398,8 @@ def main():
                          "gather_us": per_step("gather") * 1e3,
                          "sparse_apply_us": apply_ms * 1e3,
                          "optimizer_launch_us": per_step("optimizer") * 1e3,
+                         "rocprof_optimizer_launch_us": rocprof_avg_us("optimizer_ids_kernel") if (args.config == "cfg3" and args.optimizer == "sgd") else None,
+                         "rocprof_source": KSTATS_FILE,
                          "unfused_dense_update_us": (mean(unfused["dense_update"]) * 1e3) if unfused.get("dense_update") else None,
                          "sparse_plan_us": plan_ms * 1e3,
                          "sparse_plan_stream": "inside the optimizer launch (un-fused detail pass figure above)" if fused_sort
@@ -399,6 +424,12 @@ def main():
             "frac": gemm_flops / t_gemm / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None,
             "launches_per_step": (len(prof["dense_fwd"]) + len(prof["dense_bwd"])) // max(detail_steps, 1),
             "us_per_step": t_gemm * 1e6, "algorithmic_gflop": gemm_flops / 1e9, "dtype": "f32-input MFMA"}
+        if args.config == "cfg3" and args.optimizer == "sgd":
+            rp = rocprof_avg_us("tower_fwd2_kernel", "gemm_bwd_kernel<0>", "gemm_bwd_kernel<256>")
+            if rp:
+                out["roofline_gemm"].update({"rocprof_us_per_step": rp, "rocprof_frac": gemm_flops / (rp * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                                             "rocprof_source": f"{KSTATS_FILE} (committed; not re-measured in this run - the live figure "
+                                                               "carries ~3 us of hipEvent bracket per launch)"})
     if alt is not None:
         alt_steps, dta, tf_, tb_, aloss = alt
         # per launch of the FUSED pass: GEMM1 = 2*B^2*D algorithmic FLOPs at 6 bf16 products each, GEMM2 = 2*B^2*D at 3

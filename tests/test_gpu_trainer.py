@@ -427,6 +427,9 @@ def test_composite_step_entry_equals_the_python_sequence_bit_for_bit(dev, opt, b
     assert a.use_composite
     g = torch.Generator(device="cpu").manual_seed(3)
     for step in range(4):
+        if step == 3:          # the precision may be switched between steps (bench.py's second line does): the C struct follows
+            other = "bf16x3" if precision == "f32" else "f32"
+            a.cfg.scorer_precision = b.cfg.scorer_precision = other
         u, i = a.synthetic_batch(41, step, "Z")
         extra = {"category_ids": a.synthetic_categories(41, step)} if buckets else {}
         if step >= 1:

@@ -516,6 +516,8 @@ class TwoTowerTrainer:
             st.tables[2].ids = p(ids[2])
         st.dropout_seed = self.dropout_seed
         st.dropout_row0 = self.step_index * self.cfg.batch_size
+        st.scorer_precision = ops.SCORER_PRECISIONS.index(self.cfg.scorer_precision)   # (may be switched between steps: bench's second line)
+        st.lr = self.cfg.learning_rate
         st.sample_weight, st.cand_prob, st.cand_ids = p(sample_weight), p(candidate_sampling_probability), p(candidate_ids)
         _lib.check(_lib.load().tt_train_step_f32(st, ops._stream()), "tt_train_step_f32")
         self.step_index += 1
