@@ -344,9 +344,10 @@ int tt_optimizer_step_ids_f32(int32_t opt, const tt_sparse_table_ids* tables, in
  *   scorer + loss + dq, dc:      tt_retrieval_fwd_bwd_f32 / _bf16x3_f32         (q, c = fwd[n_layers-1][*].y; dq, dc = bwd[n_layers-1][*].dz)
  *   for each layer l, last first: tt_dense_bwd_batched_f32(bwd[l], 2, ...)
  *   optimizer:                   tt_optimizer_step_ids_f32(tables, segs)       (sort + duplicate sums + sparse update + dense update)
- * Nine launches for two 2-layer towers; no other work, no allocation, no synchronisation.  It exists for the HOST side: a
- * caller that reaches the library through an FFI (ctypes: ~7 us per call) pays that once per step instead of once per
- * launch - cfg1 (B 256) is 9 launches of ~2 us of GPU work each.  Results are identical to the separate calls, bit for bit.
+ * Eight launches for two 2-layer towers of a fused shape (nine otherwise); no other work, no allocation, no synchronisation.
+ * It exists for the HOST side: a caller that reaches the library through an FFI (ctypes: ~7 us per call) pays that once per
+ * step instead of once per launch - cfg1 (B 256) is 7 launches of a few us each.  Results are identical to the separate
+ * calls, bit for bit.
  * Both towers must have the same layer shapes (the batched launches); batch <= 16384 (tt_optimizer_step_ids_f32) and
  * <= 32768 with a fused lookup.                                                                                       */
 #define TT_MAX_TOWER_LAYERS 8

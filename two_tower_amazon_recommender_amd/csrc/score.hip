@@ -1264,6 +1264,13 @@ int dispatch_score_bx3(int32_t dim, const ScoreArgs& a, bool has_ids, hipStream_
   }
 }
 
+// the recomputing bf16x3 gradient passes are reachable at dim 256 only (TT_BX3_RECOMPUTE256, the A/B of keeping the dot products)
+template <int MODE>
+int dispatch_score_bx3_256(int32_t dim, const ScoreArgs& a, bool has_ids, hipStream_t stream) {
+  if (dim != 256) return tt::fail(TT_ERR_UNSUPPORTED, "retrieval (bf16x3, recomputing form): dim %d != 256", dim);
+  return launch_score<256, MODE, 1>(a, has_ids, stream);
+}
+
 template <int MODE>
 int dispatch_score(int32_t dim, const ScoreArgs& a, bool has_ids, hipStream_t stream) {
   switch (dim) {
@@ -1494,7 +1501,7 @@ static int retrieval_fwd_bwd(int prec, const float* q, const float* c, int64_t n
     // (bf16x3 at dim 128 keeps the dot products too: 134 + 89 us against 123 + 124 us recomputing - with the row-major buffer
     // it had been 200 + 127 us, the blocked layout is what makes it pay.)
     rc = prec == 1 ? (bx3_keep ? dispatch_score_bx3<MODE_FUSED_S>(dim, a, cand_ids != nullptr, stream)
-                               : dispatch_score_bx3<MODE_FUSED>(dim, a, cand_ids != nullptr, stream))
+                               : dispatch_score_bx3_256<MODE_FUSED>(dim, a, cand_ids != nullptr, stream))
                    : dispatch_score<MODE_FUSED_S>(dim, a, cand_ids != nullptr, stream);
     if (rc != TT_OK) return rc;
     {
@@ -1529,7 +1536,7 @@ static int retrieval_fwd_bwd(int prec, const float* q, const float* c, int64_t n
     a.slab = slab;
     a.S = smat; a.ldS = (nq + 31) / 32;
     rc = prec == 1 ? (bx3_keep ? dispatch_score_bx3<MODE_BWD_S>(dim, a, cand_ids != nullptr, stream)
-                                 : dispatch_score_bx3<MODE_BWD>(dim, a, cand_ids != nullptr, stream))
+                                 : dispatch_score_bx3_256<MODE_BWD>(dim, a, cand_ids != nullptr, stream))
                    : dispatch_score<MODE_BWD_S>(dim, a, cand_ids != nullptr, stream);
     if (rc != TT_OK) return rc;
     const int64_t n4 = nc * dim / 4;

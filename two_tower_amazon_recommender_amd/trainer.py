@@ -265,7 +265,7 @@ class TwoTowerTrainer:
         self.fuse_lookup = os.environ.get("TT_FUSE_LOOKUP", "1" if cfg.tower_dims[0] < 512 else "0") != "0"
         self.fuse_sort = os.environ.get("TT_FUSE_SORT", "1") != "0"   # the optimizer launch sorts the ids itself (no plan launch)
         self.fuse_optimizer = True               # sparse + dense optimizer in one launch (False: dense_update, sparse_update2 [, cat])
-        # the whole step behind ONE C call (tt_train_step_f32: the same nine launches, enqueued in C - one FFI crossing per step
+        # the whole step behind ONE C call (tt_train_step_f32: the same launches - eight at cfg3 -, enqueued in C - one FFI crossing per step
         # instead of nine; cfg1 is host-bound).  TT_COMPOSITE_STEP=0: the Python sequence of the separate entry points.
         self.use_composite = os.environ.get("TT_COMPOSITE_STEP", "1") != "0"
         self._cstep = None
