@@ -263,7 +263,10 @@ __device__ __forceinline__ void sparse_apply_body(const ApplyArgs& a, const int 
 // stamps) but issuing the touches costs the scan more than that - a load instruction occupies the address path for a whole
 // wave however few lanes are active, and the per-id broadcast / address arithmetic runs on every wave: launch 12.6 us ->
 // 14.1 (per lane and line, inside the classification loop: its in-order vmcnt waits then also wait for the touches),
-// 13.7 (same, after the loop), 13.25 us (one instruction per id, 12 lanes = the row's lines).  profiles/r03_optimizer_ab.txt
+// 13.7 (same, after the loop), 13.25 us (one instruction per id, 12 lanes = the row's lines); =2, one 4-byte touch of the
+// table row per id to start its address translation early: 12.8-13.0 -> 13.4 us (the touch returns no sooner than the row
+// loads issued 1 us later: the rows' 4.9 us is a burst of 17 MB of random 512-byte rows draining, not a page walk).
+// profiles/r03_optimizer_ab.txt
 #ifndef TT_OPT_PREFETCH
 #define TT_OPT_PREFETCH 0
 #endif
@@ -657,7 +660,26 @@ __global__ __launch_bounds__(1024) void optimizer_ids_kernel(ApplyArgs a, FusedT
     // 4-byte load nobody reads; inline asm, the destination is one scratch VGPR kept reserved until the apply phase has
     // waited for its own, later loads.)
     uint32_t sink = 0u;
-#if TT_OPT_PREFETCH
+#if TT_OPT_PREFETCH == 2
+    // form 4: ONE 4-byte touch per id, by the lane that holds it, of the first line of its TABLE (and accumulator) row only - the
+    // gradient rows are a contiguous [B, D] array, a handful of pages.  What it buys is the address translation: random rows of a
+    // multi-GB table miss the TLBs, and the page walk (several dependent memory reads) is most of the rows' 4.9 us round trip.
+    const char* pf_tab = reinterpret_cast<const char*>(a.table[ti]);
+    const char* pf_acc = reinterpret_cast<const char*>(a.accum[ti]);
+    const int row_bytes = dim4 * 16;
+    const int pf_lane = (int)(threadIdx.x & 63u);
+    auto prefetch = [&](uint64_t mask, uint32_t key, uint32_t) {
+      if ((mask >> pf_lane) & 1ull) {
+        const char* tr = pf_tab + (int64_t)key * row_bytes;
+        asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(tr) : "memory");
+        if constexpr (OPT != TT_OPT_SGD) {
+          const char* ar = pf_acc + (int64_t)key * row_bytes;
+          asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(ar) : "memory");
+        }
+      }
+    };
+    const uint32_t m = tt::part_scan_append<DBITS, JMAX, true>(t, g, ft.cap, smem, sc, offset, base_key, prefetch);
+#elif TT_OPT_PREFETCH
     const char* pf_tab = reinterpret_cast<const char*>(a.table[ti]);
     const char* pf_acc = reinterpret_cast<const char*>(a.accum[ti]);
     const char* pf_grd = reinterpret_cast<const char*>(a.grads[ti]);
