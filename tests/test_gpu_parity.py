@@ -570,6 +570,24 @@ def test_fused_tower_forward_is_bit_identical_to_two_layers(dev, m, k0, h, n1, l
         assert (ha[0] == 0).float().mean().item() > rate * 0.8
 
 
+def test_fused_tower_forward_without_biases_and_without_sign_bits(dev):
+    """NULL biases (the kernel reads the same index from the weight matrix and drops it) and NULL sign-bit outputs: still the
+    two per-layer launches bit for bit."""
+    m, k0, h, n1 = 300, 128, 256, 128
+    xs = [T(synth.uniform_f32(72, 10 + i, m * k0, -0.3, 0.6).reshape(m, k0), dev) for i in range(2)]
+    w0 = [T(synth.uniform_f32(72, 20 + i, k0 * h, -0.2, 0.4).reshape(k0, h), dev) for i in range(2)]
+    w1 = [T(synth.uniform_f32(72, 24 + i, h * n1, -0.2, 0.4).reshape(h, n1), dev) for i in range(2)]
+    b1 = [None, T(synth.uniform_f32(72, 27, n1, -0.1, 0.2), dev)]          # one tower with a layer-1 bias, one without
+    none2 = [None, None]
+    ha = [torch.full((m, h), 7.0, device=dev) for _ in range(2)]; ya = [torch.full((m, n1), 7.0, device=dev) for _ in range(2)]
+    hb = [torch.full((m, h), 7.0, device=dev) for _ in range(2)]; yb = [torch.full((m, n1), 7.0, device=dev) for _ in range(2)]
+    ops.tower_fwd2(xs, w0, none2, ha, none2, w1, b1, ya)
+    ops.dense_fwd2(xs, w0, none2, hb, relu=True)
+    ops.dense_fwd2(hb, w1, b1, yb, relu=False)
+    for i in range(2):
+        assert torch.equal(ha[i], hb[i]) and torch.equal(ya[i], yb[i]), i
+
+
 def test_fused_tower_forward_refuses_unsupported_shapes(dev):
     assert not ops.tower_fwd2_supported(128, 128, 512, 256) and not ops.tower_fwd2_supported(128, 36, 128, 128)
     x = [torch.zeros(64, 128, device=dev)] * 2
