@@ -21,9 +21,9 @@ for _ in range(5):
 torch.cuda.synchronize()
 buf = np.zeros(1024 * 8, dtype=np.uint64)
 assert lib.tt_debug_tower_stamps(buf.ctypes.data, buf.size) == 0
-s = buf.reshape(1024, 8)[:512, :7].astype(np.int64)
+s = buf.reshape(1024, 8)[:512, :8].astype(np.int64)
 t0 = s[:, 0].min()
 us = (s - t0) / 100.0
-names = ["start", "input tile", "layer-0 MFMAs", "hidden tile", "layer-1 MFMAs", "y stores issued", "stores landed"]
+names = ["start", "input tile", "layer-0 MFMAs", "hidden tile", "layer-1 MFMAs", "y stores issued", "stores landed", "hidden tile in LDS (before its barrier)"]
 print("512 workgroups; mean stamp (us):", ", ".join(f"{n} {us[:, k].mean():.2f}" for k, n in enumerate(names)))
 print("   max:", ", ".join(f"{n} {us[:, k].max():.2f}" for k, n in enumerate(names)), "| start spread", us[:, 0].max())

@@ -42,6 +42,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // C/D row of accumulator register `reg` for lane half h (32x32 MFMA): guide §3.
 __device__ __forceinline__ constexpr int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
+// dst's lane `lane` (a compile-time constant) = the wave-uniform value v (v_writelane_b32; this hipcc has no builtin for it).
+// s_nop 4: v usually is (half of) a lane mask a VALU compare has JUST written to an SGPR pair, and an SGPR written by the VALU
+// is not yet readable as a v_writelane source on the next cycles - without the wait states the lane got the PREVIOUS
+// compare's mask (r03: test_relu_sign_bits_are_the_activation_mask_bit_for_bit caught it); the compiler's hazard recogniser
+// does not look inside inline asm.
+__device__ __forceinline__ void writelane(uint32_t& dst, uint32_t v, int lane) {
+  asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %2" : "+v"(dst) : "s"(v), "n"(lane));
+}
+
 __device__ __forceinline__ uint64_t splitmix(uint64_t x) {
   uint64_t z = x + 0x9E3779B97F4A7C15ull;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;

@@ -395,8 +395,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int zsplit, c
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const uint64_t b = __builtin_amdgcn_ballot_w64(((posbits >> reg) & 1u) != 0u);
-        if (lane == tt::acc_row(reg, 0)) myword = (uint32_t)b;
-        if (lane == tt::acc_row(reg, 1)) myword = (uint32_t)(b >> 32);
+        tt::writelane(myword, (uint32_t)b, tt::acc_row(reg, 0));           // (see csrc/tower.hip)
+        tt::writelane(myword, (uint32_t)(b >> 32), tt::acc_row(reg, 1));
       }
       const int64_t m = m0 + wm * 32 + lane;
       const int64_t nw = (n0 + wn * 32) >> 5;

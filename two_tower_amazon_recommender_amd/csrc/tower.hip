@@ -16,6 +16,7 @@
 // The embedding lookup (a1) is fused into the input tile exactly as there (tt_dense_lookup).
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -247,31 +248,38 @@ __global__ __launch_bounds__(256, 2) void tower_fwd2_kernel(Tower2Batch pb) {
   for (int b = 0; b < HB; ++b) {
     const int col = wave * C1 + 32 * b + ln;
     const float bias = bias0[b];
-    uint32_t posbits = 0u;
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int row = tt::acc_row(reg, hh);
-      const int64_t m = m0 + row;
-      float v = fmaxf(acc[b][reg] + bias, 0.f);
-      if constexpr (DROP) {
-        const uint64_t hsh = tt::splitmix(p.drop_key + pb.drop_offset + (uint64_t)m * (uint64_t)H + (uint64_t)col);
-        v = ((uint32_t)(hsh >> 40) < pb.drop_p24) ? 0.f : v * pb.drop_scale;
-      }
-      XH[row * LH + col] = v;
-      if (m < pb.M) posbits |= (v > 0.f ? 1u : 0u) << reg;
-    }
-    if (p.h_bits != nullptr) {       // one ballot per register: low half = tile row acc_row(reg, 0), high half = acc_row(reg, 1)
-      uint32_t myword = 0u;
+    // sign bits: `v > 0` of register reg over the wave IS the two words (low half = tile row acc_row(reg, 0), high half =
+    // acc_row(reg, 1), bit = column) - the compare's lane mask goes straight into its lane with v_writelane.  (As
+    // `posbits |= ...; ... if (lane == k) myword = ballot` each of the 32 words cost a compare, selects and hazard nops: ~400 of
+    // this epilogue's ~670 instructions per wave, r03 ISA.  Rows past M get bits too; their words are never stored.)
+    uint32_t myword = 0u;
+    auto rows = [&](auto with_bits) {                        // (two copies of the loop: the test is uniform, not per register)
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
-        const uint64_t bal = __builtin_amdgcn_ballot_w64(((posbits >> reg) & 1u) != 0u);
-        if (lane == tt::acc_row(reg, 0)) myword = (uint32_t)bal;
-        if (lane == tt::acc_row(reg, 1)) myword = (uint32_t)(bal >> 32);
+        const int row = tt::acc_row(reg, hh);
+        [[maybe_unused]] const int64_t m = m0 + row;
+        float v = fmaxf(acc[b][reg] + bias, 0.f);
+        if constexpr (DROP) {
+          const uint64_t hsh = tt::splitmix(p.drop_key + pb.drop_offset + (uint64_t)m * (uint64_t)H + (uint64_t)col);
+          v = ((uint32_t)(hsh >> 40) < pb.drop_p24) ? 0.f : v * pb.drop_scale;
+        }
+        XH[row * LH + col] = v;
+        if constexpr (decltype(with_bits)::value) {
+          const uint64_t bal = __builtin_amdgcn_ballot_w64(v > 0.f);
+          tt::writelane(myword, (uint32_t)bal, tt::acc_row(reg, 0));
+          tt::writelane(myword, (uint32_t)(bal >> 32), tt::acc_row(reg, 1));
+        }
       }
-      const int64_t m = m0 + lane;
-      if (lane < 32 && m < pb.M) p.h_bits[m * (H / 32) + (wave * C1 + 32 * b) / 32] = myword;
+    };
+    if (p.h_bits != nullptr) {
+      rows(std::true_type{});
+      const int64_t mw = m0 + lane;
+      if (lane < 32 && mw < pb.M) p.h_bits[mw * (H / 32) + (wave * C1 + 32 * b) / 32] = myword;
+    } else {
+      rows(std::false_type{});
     }
   }
+  TSTAMP(7);
   __syncthreads();                                           // the hidden tile is complete
   // h to HBM (the backward pass reads it) FROM THE LDS TILE, 16 bytes per lane: a wave-instruction stores four whole 1 KB rows.
   // (Stored from the accumulators - 4 bytes per lane, two 128-byte row pieces per instruction, 32 instructions per wave -
