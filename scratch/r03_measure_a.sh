@@ -36,3 +36,10 @@ except Exception as e:
 PY
 done
 tail -14 $out/bench_cfg3_timeline.txt
+# (appended for the re-run after the last kernel change of the round: the per-workgroup stamps and the GEMM launch microbench)
+if [ -f scratch/variants/stamps.so ]; then
+  TT_LIB_PATH=$PWD/scratch/variants/stamps.so timeout -k 10 200 python scratch/opt_stamps.py 2>&1 | grep -v amdgpu.ids | cut -c1-600 > $out/optimizer_stamps.txt
+  TT_LIB_PATH=$PWD/scratch/variants/stamps.so timeout -k 10 200 python scratch/tower_stamps.py 2>&1 | grep -v amdgpu.ids | cut -c1-700 > $out/tower_stamps.txt
+fi
+timeout -k 10 100 python scratch/bench_gemm.py > $out/gemm_launches.json 2>/dev/null
+head -2 $out/tower_stamps.txt
