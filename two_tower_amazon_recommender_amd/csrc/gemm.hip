@@ -22,7 +22,10 @@ namespace {
 using tt::f32x4;
 using tt::f32x16;
 
-constexpr int BM = 64, BN = 64, BK = 32;
+#ifndef TT_GEMM_BK
+#define TT_GEMM_BK 32                     // k-tile depth (A/B hook: 64 halves the barrier rounds, doubles LDS and the register ring)
+#endif
+constexpr int BM = 64, BN = 64, BK = TT_GEMM_BK;
 // k-tiles of global loads in flight per thread.  r02 sweep of the four cfg3 tower launches (us): 1: 96.3, 2: 95.3, 3: 98.8,
 // 4 (3 for the forward orientation, the r01 setting): 98.2 - with four resident workgroups per CU the other waves cover a
 // tile's latency; the smaller ring leaves registers.
