@@ -41,3 +41,28 @@ def test_invalid_args_return_codes_without_gpu():
     assert rc == _lib.TT_ERR_INVALID_ARG
     rc = lib.tt_dense_fwd_f32(None, None, None, None, 8, 6, 8, 0, None)
     assert rc == _lib.TT_ERR_INVALID_ARG
+
+
+def test_train_step_struct_is_validated_before_any_launch():
+    """tt_train_step_f32 (the composite entry, ABI v8) refuses a malformed step description with TT_ERR_INVALID_ARG and a
+    message - layer count, batch, dropout rate, precision code, table / segment counts - before it touches the GPU; the
+    two query entries of the fused tower answer on the host."""
+    import ctypes as C
+    lib = _lib.load()
+    st = _lib.TrainStep()
+    assert lib.tt_train_step_f32(None, None) == _lib.TT_ERR_INVALID_ARG
+    assert lib.tt_train_step_f32(C.byref(st), None) == _lib.TT_ERR_INVALID_ARG and b"layers" in lib.tt_last_error()
+    st.n_layers, st.batch = 2, 0
+    assert lib.tt_train_step_f32(C.byref(st), None) == _lib.TT_ERR_INVALID_ARG and b"batch" in lib.tt_last_error()
+    st.batch, st.dropout_rate = 256, 1.5
+    assert lib.tt_train_step_f32(C.byref(st), None) == _lib.TT_ERR_INVALID_ARG and b"dropout" in lib.tt_last_error()
+    st.dropout_rate, st.scorer_precision = 0.0, 7
+    assert lib.tt_train_step_f32(C.byref(st), None) == _lib.TT_ERR_INVALID_ARG and b"precision" in lib.tt_last_error()
+    st.scorer_precision, st.n_tables = 1, 1
+    assert lib.tt_train_step_f32(C.byref(st), None) == _lib.TT_ERR_INVALID_ARG and b"tables" in lib.tt_last_error()
+    st.n_tables, st.n_segs = 2, 0
+    assert lib.tt_train_step_f32(C.byref(st), None) == _lib.TT_ERR_INVALID_ARG and b"segments" in lib.tt_last_error()
+    st.n_layers = _lib.TT_MAX_TOWER_LAYERS + 1
+    assert lib.tt_train_step_f32(C.byref(st), None) == _lib.TT_ERR_INVALID_ARG
+    assert lib.tt_tower_fwd2_supported(8192, 128, 256, 128) == 1 and lib.tt_tower_fwd2_supported(8192, 128, 512, 256) == 0
+    assert lib.tt_tower_fwd2_supported(8192, 36, 128, 128) == 0 and lib.tt_tower_fwd2_supported(8192, 1024, 128, 128) == 0
