@@ -81,23 +81,46 @@ __device__ __forceinline__ void part_local_sort(const PartTable& t, uint32_t* ke
     __syncthreads();                                        // the loads above / of the previous pass are done
     const int shift = p * DBITS;
     for (int j = lane; j < RADIX; j += 64) mycnt[j] = 0u;
-    uint32_t dg[RMAX], rk[RMAX], lead[RMAX], old[RMAX];
+    // SLIM (the 16-round instantiation: a hot row range of more than 6144 keys in a list of up to 16384): one element at a
+    // time from digit to slot - the LDS atomic's round trip is paid per element instead of once per pass, and the digit is
+    // recomputed where it is needed - so that only key / position / slot arrays are live across the pass: 48 VGPRs instead
+    // of 96 (with the three-loop form this instantiation spilled 92 B per lane inside the 128-VGPR budget of a 1024-thread
+    // workgroup).  The shorter instantiations keep the three loops: their atomics overlap.
+    constexpr bool SLIM = RMAX > 8;
+    auto digit = [&](int r) -> uint32_t { return (key[r] >> shift) & (RADIX - 1); };
+    uint32_t dg[SLIM ? 1 : RMAX], rk[SLIM ? 1 : RMAX], lead[SLIM ? 1 : RMAX], old[RMAX];
+    if constexpr (SLIM) {
 #pragma unroll
-    for (int r = 0; r < RMAX; ++r) {
-      if (r < rounds) {
-        dg[r] = (key[r] >> shift) & (RADIX - 1);
-        const uint64_t peers = match_any<DBITS>(dg[r]);
-        rk[r] = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
-        lead[r] = (uint32_t)__ffsll((unsigned long long)peers) - 1u;
-        old[r] = (uint32_t)__popcll(peers);
+      for (int r = 0; r < RMAX; ++r) {
+        old[r] = 0u;
+        if (r < rounds) {
+          const uint32_t d = digit(r);
+          const uint64_t peers = match_any<DBITS>(d);
+          const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+          uint32_t o = (uint32_t)__popcll(peers);
+          if (rank == 0u) o = atomicAdd(&mycnt[d], o);
+          old[r] = (uint32_t)__shfl((int)o, (int)((uint32_t)__ffsll((unsigned long long)peers) - 1u)) + rank;
+        }
       }
+    } else {
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r) {
+        if (r < rounds) {
+          dg[r] = digit(r);
+          const uint64_t peers = match_any<DBITS>(dg[r]);
+          rk[r] = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+          lead[r] = (uint32_t)__ffsll((unsigned long long)peers) - 1u;
+          old[r] = (uint32_t)__popcll(peers);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r)
+        if (r < rounds && rk[r] == 0u) old[r] = atomicAdd(&mycnt[dg[r]], old[r]);
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r)
+        if (r < rounds) old[r] = (uint32_t)__shfl((int)old[r], (int)lead[r]) + rk[r];
     }
-#pragma unroll
-    for (int r = 0; r < RMAX; ++r)
-      if (r < rounds && rk[r] == 0u) old[r] = atomicAdd(&mycnt[dg[r]], old[r]);
-#pragma unroll
-    for (int r = 0; r < RMAX; ++r)
-      if (r < rounds) old[r] = (uint32_t)__shfl((int)old[r], (int)lead[r]) + rk[r];
+    auto bucket = [&](int r) -> uint32_t { if constexpr (SLIM) return mycnt[digit(r)]; else return mycnt[dg[r]]; };
     __syncthreads();
     uint32_t v[W], total = 0u;
     if (tid < RADIX) {
@@ -129,7 +152,7 @@ __device__ __forceinline__ void part_local_sort(const PartTable& t, uint32_t* ke
 #pragma unroll
       for (int r = 0; r < RMAX; ++r)
         if (r < rounds) {
-          const uint32_t dst = mycnt[dg[r]] + old[r];
+          const uint32_t dst = bucket(r) + old[r];
           keys[dst] = key[r];
           poss[dst] = (uint16_t)pos[r];
         }
@@ -145,7 +168,7 @@ __device__ __forceinline__ void part_local_sort(const PartTable& t, uint32_t* ke
 #pragma unroll
       for (int r = 0; r < RMAX; ++r)
         if (r < rounds) {
-          const uint32_t dst = mycnt[dg[r]] + old[r];
+          const uint32_t dst = bucket(r) + old[r];
           if (dst < m) {
             t.sorted_ids[offset + dst] = (int64_t)(key[r] + base_key);
             t.order[offset + dst] = (int32_t)pos[r];
