@@ -686,7 +686,8 @@ def test_retrieval_baseline_configs(dev, b, d):
 
 @pytest.mark.parametrize("nq,nc,d,off", [(1, 1, 32, 0), (33, 33, 32, 0), (100, 131, 64, 0), (100, 131, 64, 31),
                                          (129, 1000, 128, 700), (1000, 1000, 128, 0), (2048, 16384, 128, 6144),
-                                         (257, 300, 256, 5)])
+                                         (257, 300, 256, 5), (512, 8192, 256, 1000), (256, 8192, 32, 0)])   # (the last two: 64 splits
+                                         # through the combine kernel's chunks of 8, at 64 and at 8 lanes per row)
 def test_retrieval_ragged_and_offset_slabs(dev, nq, nc, d, off):
     check_retrieval(dev, nq, nc, d, off=off)
 
