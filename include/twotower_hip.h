@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TT_ABI_VERSION 8
+#define TT_ABI_VERSION 9
 
 enum {
   TT_OK = 0,
@@ -245,10 +245,26 @@ int tt_dense_bwd_scaled_f32(const float* x, const float* w, const float* dz,
  * GEMM's LDS tiles by the forward pass (x @ w) and by the backward pass's dW = x^T @ dz.  Ids outside
  * [0, table_rows) give a zero row; -1 is a silent padding id, any other sets *oob_flag.  All-zero = no lookup.
  * Needs m <= 32768 (the ids of one dW split are staged in LDS).                                                  */
+/* Row-range id lists (ABI v9; optional - all-zero = none).  tt_optimizer_step_ids_f32 gives every sorting workgroup one row
+ * range [g*width, (g+1)*width) of a table, and each of them used to read ALL the batch's ids to find its own ~64.  The forward
+ * lookup reads every id anyway: with `buckets` it also appends (id - g*width, batch position) to range g's list - one
+ * returning atomic add on counts[g], one 8-byte store - and the optimizer launch of the SAME step, given the same descriptor,
+ * reads only its own list (and falls back to the scan for a range whose list overflowed `cap`: counts[g] keeps counting).
+ *   counts [groups][64] uint32, word 0 of each 256-byte line used (a counter per line: device-scope atomics on one line
+ *          serialise): entries appended; ZERO before the first step - the optimizer launch resets every counter it reads
+ *   pairs  [groups][cap] uint64: bits 0..31 local key, 32..47 batch position, 48..63 generation (entries of another
+ *          generation - a forward pass whose optimizer step never ran - are ignored)
+ * groups / width / cap must be the ones tt_optimizer_ids_geometry reports for the step (else the optimizer ignores the lists).
+ * Lists exist for n_ids <= 16384, dim <= 128.  One descriptor per table; tt_id_buckets_workspace_bytes() bytes hold one.   */
+typedef struct tt_id_buckets {
+  uint32_t* counts; uint64_t* pairs;
+  int32_t groups; uint32_t width; int32_t cap; uint32_t gen;
+} tt_id_buckets;
 typedef struct tt_dense_lookup {
   const float* table;  const int64_t* ids;  int64_t table_rows;
   const float* table2; const int64_t* ids2; int64_t table2_rows;     /* optional */
   int32_t* oob_flag;                                                 /* optional */
+  tt_id_buckets buckets;                                             /* optional: row-range lists of `ids` (forward pass only) */
 } tt_dense_lookup;
 /* ReLU sign bits (optional, n % 32 == 0): the forward pass can write, beside y, one bit per element — word
  * [row][col / 32] of a [m, n/32] uint32 array, bit col % 32 = (y[row][col] > 0) — and the backward pass of the NEXT layer
@@ -330,7 +346,13 @@ typedef struct tt_sparse_table_ids {
   const float* grads;                    /* [n_ids, dim] per-position gradient rows */
   const int64_t* ids;                    /* [n_ids] the batch's ids, unsorted       */
   void* apply_ws;                        /* tt_sparse_apply_workspace_bytes(n_ids, dim) */
+  tt_id_buckets buckets;                 /* optional (ABI v9): the row-range lists this step's forward lookup filled */
 } tt_sparse_table_ids;
+/* The row ranges tt_optimizer_step_ids_f32 will use for these tables (HOST outputs, [n_tables] each): table t is cut into
+ * groups[t] ranges of width[t] rows; *cap = entries per list (0: this shape takes no lists - dim > 128 or n_ids > 16384).   */
+int tt_optimizer_ids_geometry(const int64_t* table_rows, int32_t n_tables, int32_t dim, int64_t n_ids,
+                              const tt_dense_seg* segs, int32_t n_segs, int32_t* groups, uint32_t* width, int32_t* cap);
+int64_t tt_id_buckets_workspace_bytes(void);      /* one table's counts + pairs, 256-byte aligned inside */
 int tt_optimizer_step_ids_f32(int32_t opt, const tt_sparse_table_ids* tables, int32_t n_tables, int32_t dim, int64_t n_ids,
                               const tt_dense_seg* segs, int32_t n_segs, float lr, float eps, tt_stream_t stream);
 
@@ -373,6 +395,8 @@ typedef struct tt_train_step {
   int32_t n_segs;
   tt_dense_seg segs[TT_MAX_DENSE_SEGS];
   float lr, eps;
+  void* id_bucket_ws;                              /* optional (ABI v9): n_tables * tt_id_buckets_workspace_bytes() bytes, 256-byte   */
+  int64_t id_bucket_ws_bytes;                      /* aligned, ZEROED once: the forward lookup hands the optimizer launch its row-range id lists */
 } tt_train_step;
 int tt_train_step_f32(const tt_train_step* step, tt_stream_t stream);
 

@@ -2,7 +2,7 @@
 loop around each per-tile s_barrier close on a SCALAR condition?
 
     hipcc -O3 ... --save-temps -c csrc/score.hip       ->  score-hip-amdgcn-amd-amdhsa-gfx950.s
-    python scratch/audit_barriers.py score-hip-amdgcn-amd-amdhsa-gfx950.s [name-regex]
+    python tests/isa_audit/audit_barriers.py score-hip-amdgcn-amd-amdhsa-gfx950.s [name-regex]
 
 A barrier is safe when every wave of the workgroup reaches it the same number of times.  hipcc guarantees that only for
 control flow it KNOWS to be wave-uniform, which shows in the ISA as scalar loop control.  The listing's own loop

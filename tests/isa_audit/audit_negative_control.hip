@@ -1,4 +1,4 @@
-// Negative control for scratch/audit_barriers.py: a workgroup barrier inside a loop whose trip count is a PER-LANE value
+// Negative control for tests/isa_audit/audit_barriers.py: a workgroup barrier inside a loop whose trip count is a PER-LANE value
 // (what the r02 note described: the exit test is a vector compare).  The audit must flag it.  Never launched.
 #include <hip/hip_runtime.h>
 namespace {

@@ -2,7 +2,7 @@
 followed by `s_waitcnt vmcnt(0)` before any other global load is issued (a load whose latency nothing else overlaps), and report
 the longest run of such load->wait pairs in program order.  A run of k means k memory round trips back to back in one wave.
 
-    hipcc -O3 --offload-arch=gfx950 -S --cuda-device-only -o x.s csrc/x.hip ;  python scratch/audit_serial_loads.py x.s
+    hipcc -O3 --offload-arch=gfx950 -S --cuda-device-only -o x.s csrc/x.hip ;  python tests/isa_audit/audit_serial_loads.py x.s
 """
 import re
 import subprocess

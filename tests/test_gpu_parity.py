@@ -344,6 +344,96 @@ def test_optimizer_step_from_raw_ids_matches_plan_then_step_bit_for_bit(dev, opt
                                 [ops.make_dense_seg(wb, waccb, wslab, 4, 1e-6)], 0.01, 1e-7)
 
 
+@pytest.mark.parametrize("opt", ["sgd", "adagrad"])
+@pytest.mark.parametrize("n,dim,rows,kind", [(8192, 128, (5_000_000, 100_000), "U"), (8192, 128, (100_000, 3_000), "Z"),
+                                             (16384, 128, (1_000_000, 50_000), "Z"), (4096, 64, (20_000, 2_000), "U"),
+                                             (9000, 128, (1000, 1000), "heavy"), (1000, 32, (777, 40), "U")])
+def test_row_range_id_lists_from_the_forward_lookup_change_nothing(dev, opt, n, dim, rows, kind):
+    """r04 (ABI v9, tt_id_buckets): the fused tower forward appends every id it looks up to the list of the row range the
+    optimizer launch's sorting workgroup owns, and that launch reads its list instead of scanning all the ids.  Same tables,
+    accumulators and dense parameters, bit for bit, as the launch that scans - for uniform ids (every workgroup finishes
+    without ranks), Zipf and heavy-hitter ids (lists that overflow fall back to the scan; ranges with an id three times or
+    more take the ranked path, whose global slot offset is then counted from the ids), padding / out-of-range ids, and with
+    STALE entries in the lists (a forward pass of another generation whose optimizer step never ran).  The counters are
+    left at zero."""
+    rng = np.random.default_rng(11)
+    ids = []
+    for t, r in enumerate(rows):
+        if kind == "heavy":
+            x = np.concatenate([np.full(7000, 17 % r), np.full(129, 18 % r), np.full(64, 400 % r), rng.integers(0, r, n - 7000 - 129 - 64)])
+            rng.shuffle(x)
+        elif kind == "Z":
+            x = synth.ids_powerlaw(5, 3 + t, n, r)
+        else:
+            x = rng.integers(0, r, n)
+        x = x.astype(np.int64)
+        x[rng.integers(0, n, 5)] = -1
+        x[rng.integers(0, n, 5)] = r + 3
+        ids.append(T(x, dev))
+    grads = [T(synth.uniform_f32(6, 9 + t, n * dim, -1.0, 2.0).reshape(n, dim), dev) for t in range(2)]
+    wslab = T(synth.uniform_f32(6, 20, 4 * 1000, -1.0, 2.0).reshape(4, 1000), dev)
+    hdim = 128
+
+    def state():
+        tabs = [T(synth.embedding_table(7, 1 + t, r, dim), dev) for t, r in enumerate(rows)]
+        accs = [torch.full_like(x, 0.1) if opt == "adagrad" else None for x in tabs]
+        w = T(synth.uniform_f32(7, 30, 1000, -1.0, 2.0), dev)
+        wacc = torch.full_like(w, 0.1) if opt == "adagrad" else None
+        return tabs, accs, w, wacc
+
+    plans = [ops.SparsePlan(n, dev) for _ in range(2)]
+    ta, aa, wa, wacca = state()
+    segs_a = [ops.make_dense_seg(wa, wacca, wslab, 4, 1e-6)]
+    ops.optimizer_step_ids_(opt, [(ta[t], aa[t], grads[t], ids[t], plans[t]) for t in range(2)], segs_a, 0.01, 1e-7)
+
+    tb, ab, wb, waccb = state()
+    segs_b = [ops.make_dense_seg(wb, waccb, wslab, 4, 1e-6)]
+    bk = ops.IdBuckets(list(rows), dim, n, segs_b, dev)
+    assert bk.cap == min(256, 4 * (1024 // max(dim // 4, 1))) and all(g >= 1 for g in bk.groups)
+    # the forward pass that fills the lists: the fused two-layer tower forward with the lookup (its outputs are not looked at here)
+    w0 = [T(synth.uniform_f32(8, 40 + t, dim * hdim, -0.1, 0.2).reshape(dim, hdim), dev) for t in range(2)]
+    w1 = [T(synth.uniform_f32(8, 50 + t, hdim * hdim, -0.1, 0.2).reshape(hdim, hdim), dev) for t in range(2)]
+    b0 = [torch.zeros(hdim, device=dev) for _ in range(2)]
+    hs = [torch.empty(n, hdim, device=dev) for _ in range(2)]
+    ys = [torch.empty(n, hdim, device=dev) for _ in range(2)]
+    bits = [ops.relu_bits_like(n, hdim, dev) for _ in range(2)]
+    oob = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def forward(id_list, gen):
+        lks = [ops.make_lookup(tb[t], id_list[t], oob_flag=oob, buckets=bk.desc(t, gen)) for t in range(2)]
+        ops.tower_fwd2([None, None], w0, b0, hs, bits, w1, b0, ys, lookups=lks)
+
+    if kind == "U" and n <= 4096:
+        # a STALE generation first: a forward pass over other ids whose optimizer step never runs
+        stale = [torch.roll(x, 7) for x in ids]
+        forward(stale, 6)
+    forward(ids, 7)
+    filled = [int(bk.counts(t).sum().item()) for t in range(2)]
+    valid = [int(((x >= 0) & (x < r)).sum().item()) for x, r in zip(ids, rows)]
+    assert all(f >= v for f, v in zip(filled, valid))          # every in-range id was appended (stale entries on top)
+    ops.optimizer_step_ids_(opt, [(tb[t], ab[t], grads[t], ids[t], plans[t]) for t in range(2)], segs_b, 0.01, 1e-7,
+                            buckets=[bk.desc(t, 7) for t in range(2)])
+    for t in range(2):
+        assert torch.equal(ta[t], tb[t]), f"table {t}"
+        if opt == "adagrad":
+            assert torch.equal(aa[t], ab[t]), f"accumulator {t}"
+        assert int(bk.counts(t).abs().sum().item()) == 0, "counters must be left at zero"
+    assert torch.equal(wa, wb)
+    # the lists do not disturb the forward pass itself (tb == ta now: the same tables with and without a descriptor)
+    lks = [ops.make_lookup(ta[t], ids[t], oob_flag=oob) for t in range(2)]
+    ops.tower_fwd2([None, None], w0, b0, hs, bits, w1, b0, ys, lookups=lks)
+    y_plain = [y.clone() for y in ys]
+    forward(ids, 8)
+    assert torch.equal(y_plain[0], ys[0]) and torch.equal(y_plain[1], ys[1])
+    bk.ws.zero_()
+    # a descriptor cut differently from the launch's own row ranges is refused, not silently mis-read
+    bad = bk.desc(0, 9)
+    bad.width += 1
+    with pytest.raises(ValueError):
+        ops.optimizer_step_ids_(opt, [(tb[t], ab[t], grads[t], ids[t], plans[t]) for t in range(2)], segs_b, 0.01, 1e-7,
+                                buckets=[bad, bk.desc(1, 9)])
+
+
 def test_sparse_update_is_run_to_run_deterministic(dev):
     rows, dim, n = 1000, 128, 8192                     # heavy duplication
     table = synth.embedding_table(24, 1, rows, dim)

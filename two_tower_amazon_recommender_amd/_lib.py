@@ -15,7 +15,7 @@ import threading
 _PKG = pathlib.Path(__file__).resolve().parent
 # TT_LIB_PATH: load another build of the same C ABI (kernel A/B experiments); the product default is the in-tree library
 LIB_PATH = pathlib.Path(os.environ["TT_LIB_PATH"]) if os.environ.get("TT_LIB_PATH") else _PKG / "libtwotower_hip.so"
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 TT_OK, TT_ERR_INVALID_ARG, TT_ERR_LAUNCH, TT_ERR_UNSUPPORTED, TT_ERR_WORKSPACE = range(5)
 TT_OPT_SGD, TT_OPT_ADAGRAD = 0, 1
@@ -24,10 +24,17 @@ TT_MAX_DENSE_SEGS = 16
 TT_MAX_TOWER_LAYERS = 8
 
 
+class IdBuckets(C.Structure):
+    """Mirror of ``tt_id_buckets`` (ABI v9): the row-range id lists the forward lookup fills for the optimizer launch."""
+    _fields_ = [("counts", C.c_void_p), ("pairs", C.c_void_p), ("groups", C.c_int32), ("width", C.c_uint32),
+                ("cap", C.c_int32), ("gen", C.c_uint32)]
+
+
 class DenseLookup(C.Structure):
     """Mirror of ``tt_dense_lookup``: the embedding lookup fused into a tower's first Dense layer."""
     _fields_ = [("table", C.c_void_p), ("ids", C.c_void_p), ("table_rows", C.c_int64),
-                ("table2", C.c_void_p), ("ids2", C.c_void_p), ("table2_rows", C.c_int64), ("oob_flag", C.c_void_p)]
+                ("table2", C.c_void_p), ("ids2", C.c_void_p), ("table2_rows", C.c_int64), ("oob_flag", C.c_void_p),
+                ("buckets", IdBuckets)]
 
 
 class DenseFwdArgs(C.Structure):
@@ -62,7 +69,7 @@ class SparseTable(C.Structure):
 class SparseTableIds(C.Structure):
     """Mirror of ``tt_sparse_table_ids`` (one embedding table of the optimizer step that starts from the raw ids)."""
     _fields_ = [("table", C.c_void_p), ("accum", C.c_void_p), ("rows", C.c_int64), ("grads", C.c_void_p),
-                ("ids", C.c_void_p), ("apply_ws", C.c_void_p)]
+                ("ids", C.c_void_p), ("apply_ws", C.c_void_p), ("buckets", IdBuckets)]
 
 
 class DenseSeg(C.Structure):
@@ -85,6 +92,7 @@ class TrainStep(C.Structure):
         ("lse", C.c_void_p), ("per_row", C.c_void_p), ("loss", C.c_void_p),
         ("opt", C.c_int32), ("n_tables", C.c_int32), ("tables", SparseTableIds * 3),
         ("n_segs", C.c_int32), ("segs", DenseSeg * TT_MAX_DENSE_SEGS), ("lr", C.c_float), ("eps", C.c_float),
+        ("id_bucket_ws", C.c_void_p), ("id_bucket_ws_bytes", C.c_int64),
     ]
 
 
@@ -129,6 +137,9 @@ SIGNATURES = {
     "tt_dense_update_f32": (C.c_int, [C.POINTER(DenseSeg), _i32, _i32, _i32, _f, _f, _p]),
     "tt_optimizer_step_f32": (C.c_int, [_i32, C.POINTER(SparseTable), _i32, _i32, _i64, C.POINTER(DenseSeg), _i32, _f, _f, _p]),
     "tt_optimizer_step_ids_f32": (C.c_int, [_i32, C.POINTER(SparseTableIds), _i32, _i32, _i64, C.POINTER(DenseSeg), _i32, _f, _f, _p]),
+    "tt_optimizer_ids_geometry": (C.c_int, [C.POINTER(_i64), _i32, _i32, _i64, C.POINTER(DenseSeg), _i32, C.POINTER(_i32),
+                                            C.POINTER(C.c_uint32), C.POINTER(_i32)]),
+    "tt_id_buckets_workspace_bytes": (_i64, []),
     "tt_train_step_f32": (C.c_int, [C.POINTER(TrainStep), _p]),
     "tt_retrieval_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "tt_retrieval_fwd_workspace_bytes": (_i64, [_i64, _i64, _i32]),

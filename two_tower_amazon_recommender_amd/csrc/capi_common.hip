@@ -4,6 +4,7 @@
 #include <string>
 #include <vector>
 #include <cstring>
+#include <cstdlib>
 
 namespace tt {
 static thread_local char g_err[512] = "";
@@ -51,6 +52,35 @@ void prof_record(const char* tag, hipStream_t stream, bool end) {
     ++t->used;
     ++t->seen;
   }
+}
+
+// one kernel under a tag (tt::launch): the event pair the runtime fills with the dispatch's own begin / end timestamps
+bool prof_kernel_events(const char* tag, hipStream_t stream, hipEvent_t* start, hipEvent_t* stop, bool* bracket) {
+  static const bool brackets = std::getenv("TT_PROF_BRACKETS") != nullptr && std::atoi(std::getenv("TT_PROF_BRACKETS")) != 0;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  *bracket = false;
+  ProfTag* t = find_tag(tag);
+  if (t == nullptr) return false;
+  const bool skip = (g_prof_stride > 1 && t->seen % g_prof_stride != 0) || 2 * (t->used + 1) > (int)t->ev.size();
+  if (skip) { ++t->seen; return false; }
+  if (brackets) {
+    (void)hipEventRecord(t->ev[2 * t->used], stream);
+    *bracket = true;
+    return false;
+  }
+  *start = t->ev[2 * t->used];
+  *stop = t->ev[2 * t->used + 1];
+  ++t->used;
+  ++t->seen;
+  return true;
+}
+void prof_kernel_end(const char* tag, hipStream_t stream) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  ProfTag* t = find_tag(tag);
+  if (t == nullptr) return;
+  (void)hipEventRecord(t->ev[2 * t->used + 1], stream);
+  ++t->used;
+  ++t->seen;
 }
 }  // namespace tt
 

@@ -1,6 +1,7 @@
 // Shared host/device helpers for the gfx950 kernels behind include/twotower_hip.h.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
@@ -23,12 +24,39 @@ inline int check_launch(const char* what) {
 // built-in kernel timing (tt_profile_enable / tt_profile_read); see capi_common.hip
 extern bool g_prof_on;
 void prof_record(const char* tag, hipStream_t stream, bool end);
+// A scope of SEVERAL launches: a hipEventRecord pair around them (each record is a barrier packet: 4-7 us of stream time)
 struct ProfScope {
   const char* tag;
   hipStream_t stream;
   ProfScope(const char* t, hipStream_t s) : tag(t), stream(s) { if (g_prof_on) prof_record(tag, stream, false); }
   ~ProfScope() { if (g_prof_on) prof_record(tag, stream, true); }
 };
+// ONE kernel under a tag: launched through hipExtLaunchKernelGGL with a start / stop event pair, which the runtime fills with
+// the dispatch's own begin / end timestamps (the ones rocprofv3 --kernel-trace reports) - no barrier packet, nothing added to
+// the stream.  prof_kernel_events hands out the pair of the next sampled launch of `tag` (false: not enabled / not sampled /
+// capacity reached).  TT_PROF_BRACKETS=1 (environment, read once) restores the hipEventRecord brackets of r01-r03 for an A/B.
+bool prof_kernel_events(const char* tag, hipStream_t stream, hipEvent_t* start, hipEvent_t* stop, bool* bracket);
+void prof_kernel_end(const char* tag, hipStream_t stream);
+template <typename K, typename... Args>
+inline void launch(const char* tag, K kern, dim3 grid, dim3 block, unsigned lds, hipStream_t stream, Args... args) {
+  if (g_prof_on) {
+    hipEvent_t e0, e1;
+    bool bracket = false;
+    if (prof_kernel_events(tag, stream, &e0, &e1, &bracket)) {
+      hipExtLaunchKernelGGL(kern, grid, block, lds, stream, e0, e1, 0u, args...);
+      return;
+    }
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, args...);
+    if (bracket) prof_kernel_end(tag, stream);
+    return;
+  }
+  hipLaunchKernelGGL(kern, grid, block, lds, stream, args...);
+}
+
+// row-range id lists (tt_id_buckets): uint32 words between two ranges' counters - one counter per 256-byte line, so that the
+// forward pass's atomics on different ranges never serialise on a shared line
+constexpr int kBucketCountStride = 64;
+constexpr int kBucketGroupsMax = 256;      // counters / lists per table in the workspace
 
 int gemm_nt(const float* a, const float* b, float* c, int64_t m, int64_t n, int64_t k, hipStream_t stream);   // gemm.hip
 

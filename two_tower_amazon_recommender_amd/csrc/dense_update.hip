@@ -34,12 +34,11 @@ extern "C" int tt_dense_update_f32(const tt_dense_seg* segs, int32_t n_segs, int
   }
   int64_t bx = (max_count + 255) / 256;
   if (bx > 512) bx = 512;
-  tt::ProfScope prof("dense_update", tt::as_stream(stream));
   if (opt == TT_OPT_SGD)
-    hipLaunchKernelGGL(dense_update_kernel<TT_OPT_SGD>, dim3((unsigned)bx, (unsigned)n_segs), dim3(256), 0,
+    tt::launch("dense_update", dense_update_kernel<TT_OPT_SGD>, dim3((unsigned)bx, (unsigned)n_segs), dim3(256), 0,
                        tt::as_stream(stream), tbl, apply, lr, eps);
   else
-    hipLaunchKernelGGL(dense_update_kernel<TT_OPT_ADAGRAD>, dim3((unsigned)bx, (unsigned)n_segs), dim3(256), 0,
+    tt::launch("dense_update", dense_update_kernel<TT_OPT_ADAGRAD>, dim3((unsigned)bx, (unsigned)n_segs), dim3(256), 0,
                        tt::as_stream(stream), tbl, apply, lr, eps);
   return tt::check_launch("tt_dense_update_f32");
 }

@@ -88,12 +88,11 @@ int launch(const GatherArgs& a, int n_tables, int32_t dim, int64_t n_ids, int32_
   const int64_t rows_per_block = (int64_t)groups * UNROLL;
   const int64_t blocks = (n_ids + rows_per_block - 1) / rows_per_block;
   TT_REQUIRE(blocks <= 0x7fffffff, "%s: n_ids too large", what);
-  tt::ProfScope prof("gather", stream);
   if (accumulate)
-    hipLaunchKernelGGL((gather_kernel<UNROLL, true>), dim3((unsigned)blocks, n_tables), dim3(256), 0, stream, a, dim4, lpr_log2,
+    tt::launch("gather", (gather_kernel<UNROLL, true>), dim3((unsigned)blocks, n_tables), dim3(256), 0, stream, a, dim4, lpr_log2,
                        n_ids, oob_flag);
   else
-    hipLaunchKernelGGL((gather_kernel<UNROLL, false>), dim3((unsigned)blocks, n_tables), dim3(256), 0, stream, a, dim4, lpr_log2,
+    tt::launch("gather", (gather_kernel<UNROLL, false>), dim3((unsigned)blocks, n_tables), dim3(256), 0, stream, a, dim4, lpr_log2,
                        n_ids, oob_flag);
   return tt::check_launch(what);
 }
@@ -145,7 +144,6 @@ extern "C" int tt_hash_bucket_u8(const uint8_t* rows, int64_t n, int32_t width, 
   const int64_t blocks = (n + 255) / 256;
   TT_REQUIRE(blocks <= 0x7fffffff, "tt_hash_bucket_u8: n too large");
   hipStream_t stream = tt::as_stream(stream_);
-  tt::ProfScope prof("hash_bucket", stream);
-  hipLaunchKernelGGL(hash_bucket_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, rows, n, width, (uint64_t)n_buckets, out);
+  tt::launch("hash_bucket", hash_bucket_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, rows, n, width, (uint64_t)n_buckets, out);
   return tt::check_launch("tt_hash_bucket_u8");
 }

@@ -487,8 +487,7 @@ int launch(const GemmArgs* probs, int nprob, int splits, hipStream_t stream, con
   GemmBatch pb{};
   for (int i = 0; i < nprob; ++i) pb.a[i] = probs[i];
   pb.splits = splits;
-  tt::ProfScope prof(tag, stream);
-  hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, COLSUM, GK, DROP>), dim3((unsigned)gm, (unsigned)gn, (unsigned)(splits * nprob)), dim3(256), 0,
+  tt::launch(tag, (gemm_kernel<A_KC, B_KC, COLSUM, GK, DROP>), dim3((unsigned)gm, (unsigned)gn, (unsigned)(splits * nprob)), dim3(256), 0,
                      stream, pb);
   return tt::check_launch(what);
 }
@@ -644,10 +643,9 @@ extern "C" int tt_dense_bwd_batched_f32(const tt_dense_bwd_args* probs, int32_t 
     if (const char* e = std::getenv("TT_GEMM_DX_PAIR")) pb.dx_pair = (std::atoi(e) != 0 && pb.dx_gn % 2 == 0) ? 1 : 0;
     const int64_t blocks = (int64_t)n_probs * (dx_tiles / (pb.dx_pair ? 2 : 1) + dw_tiles);
     TT_REQUIRE(blocks <= 0x7fffffff && (ax[0].M + BM - 1) / BM <= 0x3fffffff, "tt_dense_bwd_f32: grid too large");
-    tt::ProfScope prof("dense_bwd", stream);
-    if (gather && aw[0].k_per_split <= 256) hipLaunchKernelGGL(gemm_bwd_kernel<256>, dim3((unsigned)blocks), dim3(256), 0, stream, pb);
-    else if (gather) hipLaunchKernelGGL(gemm_bwd_kernel<kMaxGatherK>, dim3((unsigned)blocks), dim3(256), 0, stream, pb);
-    else hipLaunchKernelGGL(gemm_bwd_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, stream, pb);
+    if (gather && aw[0].k_per_split <= 256) tt::launch("dense_bwd", gemm_bwd_kernel<256>, dim3((unsigned)blocks), dim3(256), 0, stream, pb);
+    else if (gather) tt::launch("dense_bwd", gemm_bwd_kernel<kMaxGatherK>, dim3((unsigned)blocks), dim3(256), 0, stream, pb);
+    else tt::launch("dense_bwd", gemm_bwd_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, stream, pb);
     return tt::check_launch("tt_dense_bwd_f32(dx+dw)");
   }
   if (want_dx && (rc = launch<true, true, false>(ax, n_probs, 1, stream, "tt_dense_bwd_f32(dx)", "dense_bwd_dx")) != TT_OK) return rc;

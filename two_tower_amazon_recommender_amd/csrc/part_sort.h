@@ -321,6 +321,36 @@ __device__ __forceinline__ uint32_t part_scan_append(const PartTable& t, const i
   return m;
 }
 
+// The number of the table's ids that sort below `base_key` (= the first sorted slot of the row range that starts there), counted
+// from the ids by the whole workgroup: what part_scan_append returns as `offset`, for a workgroup that got its own keys from
+// the forward pass's row-range list (csrc/sparse.hip) and finds it needs the ranked path after all.  Out-of-range ids sort last.
+template <int JMAX>
+__device__ __forceinline__ uint32_t part_count_below(const PartTable& t, const uint32_t base_key, uint32_t* s_word) {
+  constexpr int T = 1024;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const __attribute__((address_space(1))) int64_t* ids = (const __attribute__((address_space(1))) int64_t*)t.ids;
+  const int64_t num_rows = t.num_rows;
+  const int n = t.n, last = n - 1;
+  int64_t raw[JMAX];
+#pragma unroll
+  for (int j = 0; j < JMAX; ++j) {
+    const int i = j * T + tid;
+    raw[j] = ids[i < last ? i : last];
+  }
+  if (tid == 0) *s_word = 0u;
+  uint32_t below = 0u;
+#pragma unroll
+  for (int j = 0; j < JMAX; ++j) {
+    const int i = j * T + tid;
+    const bool b = i < n && raw[j] >= 0 && raw[j] < num_rows && (uint32_t)raw[j] < base_key;
+    below += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(b));
+  }
+  __syncthreads();
+  if (lane == 0 && below != 0u) atomicAdd(s_word, below);
+  __syncthreads();
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)*s_word);
+}
+
 // Workgroup barrier for LDS traffic only: waits for this wave's LDS operations, NOT for its global loads in flight
 // (__syncthreads() is a fence + barrier: `s_waitcnt vmcnt(0)` first, which would park the rows the fused optimizer has
 // just requested in front of the ranking instead of letting them land under it).

@@ -144,11 +144,10 @@ extern "C" int tt_route_tables_by_owner_i64(const tt_route_table* tables, int32_
     tabs.t[t] = tables[t];
   }
   hipStream_t stream = tt::as_stream(stream_);
-  tt::ProfScope prof("route", stream);
   switch (world) {
 #define TT_ROUTE_CASE(W)                                                                                                   \
   case W:                                                                                                                  \
-    hipLaunchKernelGGL(route_kernel<W>, dim3(n_tables), dim3(1024), 0, stream, tabs, n_tables, n_ids, cap, send_ids, flags); \
+    tt::launch("route", route_kernel<W>, dim3(n_tables), dim3(1024), 0, stream, tabs, n_tables, n_ids, cap, send_ids, flags); \
     break;
     TT_ROUTE_CASE(1) TT_ROUTE_CASE(2) TT_ROUTE_CASE(3) TT_ROUTE_CASE(4) TT_ROUTE_CASE(5) TT_ROUTE_CASE(6) TT_ROUTE_CASE(7)
     TT_ROUTE_CASE(8) TT_ROUTE_CASE(9) TT_ROUTE_CASE(10) TT_ROUTE_CASE(11) TT_ROUTE_CASE(12) TT_ROUTE_CASE(13)
@@ -178,8 +177,7 @@ extern "C" int tt_scatter_rows_f32(const float* src, const int64_t* idx, int64_t
   const int64_t blocks = (n + groups - 1) / groups;
   TT_REQUIRE(blocks <= 0x7fffffff, "tt_scatter_rows_f32: n too large");
   hipStream_t stream = tt::as_stream(stream_);
-  tt::ProfScope prof("scatter_rows", stream);
-  hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<const tt::f32x4*>(src),
+  tt::launch("scatter_rows", scatter_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<const tt::f32x4*>(src),
                      idx, n, dim4, lpr_log2, reinterpret_cast<tt::f32x4*>(dst), dst_rows);
   return tt::check_launch("tt_scatter_rows_f32");
 }

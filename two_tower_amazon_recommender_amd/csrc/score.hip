@@ -182,7 +182,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? ((MODE ==
   // the row block and, below, the tile count.  They depend on blockIdx and kernel arguments only, but hipcc divides on the
   // vector ALU; whether the quotient comes back to an SGPR is its choice, and a trip count left in VGPRs turns the tile
   // loop's exit test into a vector compare with the barrier inside a loop the compiler treats as divergent.
-  // scratch/audit_barriers.py checks the built ISA: in all instantiations every barrier loop closes on scalar branches.
+  // tests/isa_audit/audit_barriers.py checks the built ISA: in all instantiations every barrier loop closes on scalar branches.
   const int split = __builtin_amdgcn_readfirstlane((int)(blockIdx.x % (unsigned)p.nsplit));
   const int64_t rblk = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / (unsigned)p.nsplit));
   const int hw = SPLIT ? (wave & 1) : 0;             // SPLIT: the half of the embedding dimension this wave owns
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? ((MODE ==
     // `ntiles` / `t` (the quotient blockIdx / nsplit is computed on the vector ALU) that the compiler no longer proves uniform
     // once the loop body is large enough to spill or re-materialise it (D = 256: 240+ VGPRs).  The fix is by construction:
     // split, row block and ntiles go through readfirstlane (top of the kernel), so in EVERY loop form the compiler sees
-    // scalar control, and scratch/audit_barriers.py verifies on the built ISA - for all 112 instantiations, both loop forms -
+    // scalar control, and tests/isa_audit/audit_barriers.py verifies on the built ISA - for all 112 instantiations, both loop forms -
     // that each barrier loop closes and exits on scalar branches and that no barrier can be skipped under a lane mask (the
     // script's negative control, a barrier loop on a per-lane trip count, is flagged).  The shipping BWD_S loop above
     // satisfies the same condition.  tests: test_retrieval_baseline_configs[1024-256], test_retrieval_is_deterministic
@@ -1244,8 +1244,7 @@ int launch_score(const ScoreArgs& a_in, bool has_ids, hipStream_t stream) {
     }
     constexpr const char* tag = MODE == MODE_FWD ? "score_fwd" : ((MODE == MODE_BWD || MODE == MODE_BWD_S) ? "score_bwd"
                                 : ((MODE == MODE_FUSED || MODE == MODE_FUSED_S) ? "score_fused" : "score_rank"));
-    tt::ProfScope prof(tag, stream);
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(W * 64), lds, stream, a);
+    tt::launch(tag, kern, dim3((unsigned)blocks), dim3(W * 64), (unsigned)lds, stream, a);
     return tt::check_launch(tag);
   };
   if (has_ids && has_hn) return go(score_kernel<D, MODE, true, true, W, PREC>);
@@ -1421,11 +1420,8 @@ extern "C" int tt_retrieval_bwd_f32(const float* q, const float* c, int64_t nq, 
     if ((rc = dispatch_score<MODE_BWD>(dim, a, cand_ids != nullptr, stream)) != TT_OK) return rc;
     const int64_t n4 = nq * dim / 4;
     const int64_t blocks = (n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048;
-    {
-      tt::ProfScope prof("score_aux", stream);
-      hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
-                         reinterpret_cast<const f32x4*>(slab), reinterpret_cast<f32x4*>(dq), n4, a.nsplit, nullptr, 0, nullptr);
-    }
+    tt::launch("score_aux", reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
+               reinterpret_cast<const f32x4*>(slab), reinterpret_cast<f32x4*>(dq), n4, a.nsplit, (const float*)nullptr, (int64_t)0, (float*)nullptr);
     if ((rc = tt::check_launch("reduce_slabs(dq)")) != TT_OK) return rc;
   }
   // dc: stationary c, stream q.  Candidates beyond nq + diag_offset have no positive: diag never matches.
@@ -1443,11 +1439,8 @@ extern "C" int tt_retrieval_bwd_f32(const float* q, const float* c, int64_t nq, 
     if ((rc = dispatch_score<MODE_BWD>(dim, a, cand_ids != nullptr, stream)) != TT_OK) return rc;
     const int64_t n4 = nc * dim / 4;
     const int64_t blocks = (n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048;
-    {
-      tt::ProfScope prof("score_aux", stream);
-      hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
-                         reinterpret_cast<const f32x4*>(slab), reinterpret_cast<f32x4*>(dc), n4, a.nsplit, nullptr, 0, nullptr);
-    }
+    tt::launch("score_aux", reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
+               reinterpret_cast<const f32x4*>(slab), reinterpret_cast<f32x4*>(dc), n4, a.nsplit, (const float*)nullptr, (int64_t)0, (float*)nullptr);
     if ((rc = tt::check_launch("reduce_slabs(dc)")) != TT_OK) return rc;
   }
   return TT_OK;
@@ -1505,11 +1498,10 @@ static int retrieval_fwd_bwd(int prec, const float* q, const float* c, int64_t n
                    : dispatch_score<MODE_FUSED_S>(dim, a, cand_ids != nullptr, stream);
     if (rc != TT_OK) return rc;
     {
-      tt::ProfScope prof("score_aux", stream);
       int lpr_log2 = 3;                              // dim/4 lanes per row: 8 (dim 32) .. 64 (dim 256)
       while ((1 << lpr_log2) < dim / 4) ++lpr_log2;
       const int rpb = 256 >> lpr_log2;
-      hipLaunchKernelGGL(fused_combine_kernel, dim3((unsigned)((nq + rpb - 1) / rpb)), dim3(256), 0, stream, a.part_m, a.part_l, a.pos2,
+      tt::launch("score_aux", fused_combine_kernel, dim3((unsigned)((nq + rpb - 1) / rpb)), dim3(256), 0, stream, a.part_m, a.part_l, a.pos2,
                          sample_weight, reinterpret_cast<const f32x4*>(slab),
                          reinterpret_cast<const f32x4*>(c + diag_offset * dim), nq, dim / 4, lpr_log2, a.nsplit,
                          inv_temperature * grad_scale, lse, per_row, aq, sq, reinterpret_cast<f32x4*>(dq));
@@ -1541,8 +1533,7 @@ static int retrieval_fwd_bwd(int prec, const float* q, const float* c, int64_t n
     if (rc != TT_OK) return rc;
     const int64_t n4 = nc * dim / 4;
     const int64_t blocks = (n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048;
-    tt::ProfScope prof("score_aux", stream);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks + 1), dim3(256), 0, stream,
+    tt::launch("score_aux", reduce_slabs_kernel, dim3((unsigned)blocks + 1), dim3(256), 0, stream,
                        reinterpret_cast<const f32x4*>(slab), reinterpret_cast<f32x4*>(dc), n4, a.nsplit, per_row, nq, loss);
     if ((rc = tt::check_launch("reduce_slabs(dc)")) != TT_OK) return rc;
   }
@@ -1700,8 +1691,7 @@ extern "C" int tt_retrieval_hard_negative_thresholds_f32(const float* q, const f
     if ((rc = tt::check_launch("prob_bias")) != TT_OK) return rc;
   }
   if ((rc = tt::gemm_nt(q, c, scratch, nq, nc, dim, stream)) != TT_OK) return rc;
-  tt::ProfScope prof("score_aux", stream);
-  hipLaunchKernelGGL(hardneg_select_kernel, dim3((unsigned)nq), dim3(256), 0, stream, scratch, nc, kLog2e * inv_temperature,
+  tt::launch("score_aux", hardneg_select_kernel, dim3((unsigned)nq), dim3(256), 0, stream, scratch, nc, kLog2e * inv_temperature,
                      cand_prob != nullptr ? bias : nullptr, cand_ids, diag_offset, num_hard_negatives, thr);
   return tt::check_launch("hardneg_select");
 }

@@ -228,8 +228,7 @@ int launch_lds_sort(const SortBatch& b, int n_tables, int threads, hipStream_t s
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
     return tt::fail(TT_ERR_LAUNCH, "tt_sparse_plan: hipFuncSetAttribute(LDS %d) failed", lds);
-  tt::ProfScope prof("sparse_plan", stream);
-  hipLaunchKernelGGL(kern, dim3((unsigned)n_tables), dim3((unsigned)threads), lds, stream, b);
+  tt::launch("sparse_plan", kern, dim3((unsigned)n_tables), dim3((unsigned)threads), lds, stream, b);
   return tt::check_launch("tt_sparse_plan");
 }
 
@@ -298,8 +297,7 @@ int launch_part(PartBatch& b, int nb, int max_n, int max_groups, int max_lbits, 
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
     return tt::fail(TT_ERR_LAUNCH, "tt_sparse_plan: hipFuncSetAttribute(LDS %d) failed", lds);
-  tt::ProfScope prof("sparse_plan", stream);
-  hipLaunchKernelGGL(kern, dim3((unsigned)max_groups, (unsigned)nb), dim3(1024), lds, stream, b);
+  tt::launch("sparse_plan", kern, dim3((unsigned)max_groups, (unsigned)nb), dim3(1024), lds, stream, b);
   return tt::check_launch("tt_sparse_plan(partitioned)");
 }
 

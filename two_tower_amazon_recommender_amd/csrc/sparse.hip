@@ -306,6 +306,11 @@ struct FusedTables {
   int32_t cap;
   int32_t first[kMaxSparseTables + 1];        // flat workgroup index of table t's group 0; first[n_tables] = first dense block
   int32_t seg_first[TT_MAX_DENSE_SEGS + 1];   // flat index (from first[n_tables]) of segment s's block 0
+  // row-range id lists filled by this step's forward lookup (tt_id_buckets, include/twotower_hip.h); bk_pairs[t] NULL = scan
+  uint32_t* bk_counts[kMaxSparseTables];
+  const uint64_t* bk_pairs[kMaxSparseTables];
+  int32_t bk_cap;
+  uint32_t bk_gen;
 };
 
 // Rows requested per lane group before any of them is finished (one memory round trip for the usual 2-3 slots per group)
@@ -619,6 +624,7 @@ __global__ __launch_bounds__(1024) void optimizer_ids_kernel(ApplyArgs a, FusedT
                                                               tt::SegTable tbl, int dense_blocks, int n_dense, float lr, float eps) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   __shared__ int s_multi, s_slow;
+  __shared__ uint32_t s_below;
   // flat grid: exactly the dense blocks each segment needs FIRST (a sorting workgroup fills a CU - 16 waves at up to 128
   // VGPRs - so dense blocks dispatched behind 256 of them would only start when those retire: r02 stamps, 10 us late),
   // then the sorting workgroups of table 0, 1, (2); the host keeps the total at one workgroup per CU
@@ -654,6 +660,57 @@ __global__ __launch_bounds__(1024) void optimizer_ids_kernel(ApplyArgs a, FusedT
     if (threadIdx.x == 0) { s_multi = 0; s_slow = 0; }
     uint32_t offset, base_key;
     const int g = b - (ti == 2 ? ft.first[2] : (ti == 1 ? ft.first[1] : 0));
+    // ---- r04: the range's ids from the list this step's FORWARD LOOKUP appended them to (tt_id_buckets) - one round trip for
+    // the count and the <= bk_cap entries instead of reading and classifying all n ids of the table (r03 stamps: ids landed
+    // 1.4 us, classified 2.4, appended 3.0, barrier 3.5 -> entries landed, barrier).  The list is in NO particular order
+    // (arrival order of the forward pass's atomics): fast_apply needs none, and the ranked path ranks by (key, position).
+    // An entry of another generation (a forward pass whose optimizer step never ran) becomes the all-ones key, which every
+    // path skips and the ranking sorts last.  A list that overflowed (count > cap: a hot range) falls back to the scan. ----
+    uint32_t* reset_count = nullptr;                                     // an overflowed list: reset behind the scan's first barrier
+    {
+      uint32_t* c0 = ft.bk_counts[0]; uint32_t* c1 = ft.bk_counts[1]; uint32_t* c2 = ft.bk_counts[2];
+      const uint64_t *p0 = ft.bk_pairs[0], *p1 = ft.bk_pairs[1], *p2 = ft.bk_pairs[2];
+      asm volatile("" : "+s"(c0), "+s"(c1), "+s"(c2), "+s"(p0), "+s"(p1), "+s"(p2));
+      uint32_t* bc = ti == 2 ? c2 : (ti == 1 ? c1 : c0);
+      const uint64_t* bp = ti == 2 ? p2 : (ti == 1 ? p1 : p0);
+      if (bp != nullptr) {                                               // (workgroup-uniform)
+        const uint32_t bcap = (uint32_t)ft.bk_cap, tid = threadIdx.x;
+        const __attribute__((address_space(1))) uint32_t* bcg = (const __attribute__((address_space(1))) uint32_t*)(bc + (size_t)g * tt::kBucketCountStride);
+        const __attribute__((address_space(1))) uint64_t* bpg = (const __attribute__((address_space(1))) uint64_t*)(bp + (size_t)g * bcap);
+        const uint32_t cnt_v = *bcg;
+        const uint64_t pr = bpg[tid < bcap ? tid : bcap - 1u];           // unconditional, clamped: one batch of loads
+        const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt_v);
+        SSTAMP(0);
+        if (cnt == 0u) return;                                           // (uniform: nobody writes the counter before the barrier below)
+        reset_count = bc + (size_t)g * tt::kBucketCountStride;
+        if (cnt <= bcap) {
+          uint32_t* Kw = tt::part_keys(smem);
+          uint16_t* Pw = tt::part_poss<DBITS>(smem, ft.cap);
+          if (tid < cnt) {
+            const bool fresh = (uint32_t)(pr >> 48) == (ft.bk_gen & 0xffffu);
+            Kw[tid] = fresh ? (uint32_t)pr : 0xffffffffu;
+            Pw[tid] = (uint16_t)(pr >> 32);
+          }
+          __syncthreads();
+          if (tid == 0) *reset_count = 0u;                               // every wave has read it: zeroed for the next step's forward pass
+          SSTAMP(2);
+          const uint32_t m = cnt;
+          base_key = (uint32_t)g * t.width;
+          const uint32_t todo = fast_apply<OPT>(a, ti, Kw, Pw, m, base_key, dim4, lpr_log2, lr, eps, &s_slow);
+          SSTAMP(3);
+          if (s_slow == 0) { SSTAMP(5); SSTAMP(6); return; }
+          // some id of the range occurs three times or more: the ranked path needs the range's position in the table's sorted
+          // list (the 64-slot pieces of the sums are cut at GLOBAL slots) = the ids below the range, counted from the ids
+          offset = tt::part_count_below<JMAX>(t, base_key, &s_below);
+          tt::part_rank_small<DBITS, false>(t, ft.cap, smem, m, offset, base_key);
+          const RowsAhead none_l{};
+          apply_from_lds<OPT, DBITS, true, false>(a, ti, Kw, Pw, tt::part_ranks(smem, ft.cap), m, offset, base_key, dim4, lpr_log2, lr, eps,
+                                                  &s_multi, none_l, todo);
+          SSTAMP(6);
+          return;
+        }
+      }
+    }
     tt::PartScan<JMAX> sc;
     // (TT_OPT_PREFETCH, off - see the top of the file: the rows' trip from HBM started at the scan.  A wave that finds an id of
     // this workgroup's range touches every 128-byte line of that id's table (accumulator) row and of its gradient row with a
@@ -712,6 +769,7 @@ __global__ __launch_bounds__(1024) void optimizer_ids_kernel(ApplyArgs a, FusedT
 #else
     const uint32_t m = tt::part_scan_append<DBITS, JMAX, true>(t, g, ft.cap, smem, sc, offset, base_key);
 #endif
+    if (reset_count != nullptr && threadIdx.x == 0) *reset_count = 0u;
     if (m == 0u) return;
     const uint32_t* K = tt::part_keys(smem);
     const uint16_t* P = tt::part_poss<DBITS>(smem, ft.cap);
@@ -795,12 +853,11 @@ int launch_apply(int opt, ApplyArgs a, void* const ws[2], int n_tables, int32_t 
     a.p_sum[t] = reinterpret_cast<float*>(base + w.off_p);
     a.s_sum[t] = reinterpret_cast<float*>(base + w.off_s);
   }
-  tt::ProfScope prof("sparse_apply", stream);
   if (opt == TT_OPT_SGD)
-    hipLaunchKernelGGL(sparse_apply_kernel<TT_OPT_SGD>, dim3((unsigned)blocks, n_tables), dim3(256), 0, stream, a, dim4,
+    tt::launch("sparse_apply", sparse_apply_kernel<TT_OPT_SGD>, dim3((unsigned)blocks, n_tables), dim3(256), 0, stream, a, dim4,
                        lpr_log2, n_ids, lr, eps);
   else
-    hipLaunchKernelGGL(sparse_apply_kernel<TT_OPT_ADAGRAD>, dim3((unsigned)blocks, n_tables), dim3(256), 0, stream, a,
+    tt::launch("sparse_apply", sparse_apply_kernel<TT_OPT_ADAGRAD>, dim3((unsigned)blocks, n_tables), dim3(256), 0, stream, a,
                        dim4, lpr_log2, n_ids, lr, eps);
   return tt::check_launch(what);
 }
@@ -898,14 +955,74 @@ extern "C" int tt_optimizer_step_f32(int32_t opt, const tt_sparse_table* tables,
   const int64_t gx = sparse_blocks > dense_blocks ? sparse_blocks : dense_blocks;
   TT_REQUIRE(gx <= 0x7fffffff, "tt_optimizer_step_f32: n_ids too large");
   hipStream_t stream = tt::as_stream(stream_);
-  tt::ProfScope prof("optimizer", stream);
   if (opt == TT_OPT_SGD)
-    hipLaunchKernelGGL(optimizer_kernel<TT_OPT_SGD>, dim3((unsigned)gx, (unsigned)(n_tables + n_segs)), dim3(256), 0, stream, a,
+    tt::launch("optimizer", optimizer_kernel<TT_OPT_SGD>, dim3((unsigned)gx, (unsigned)(n_tables + n_segs)), dim3(256), 0, stream, a,
                        n_tables, dim4, lpr_log2, n_ids, sparse_blocks, tbl, (int)dense_blocks, lr, eps);
   else
-    hipLaunchKernelGGL(optimizer_kernel<TT_OPT_ADAGRAD>, dim3((unsigned)gx, (unsigned)(n_tables + n_segs)), dim3(256), 0, stream, a,
+    tt::launch("optimizer", optimizer_kernel<TT_OPT_ADAGRAD>, dim3((unsigned)gx, (unsigned)(n_tables + n_segs)), dim3(256), 0, stream, a,
                        n_tables, dim4, lpr_log2, n_ids, sparse_blocks, tbl, (int)dense_blocks, lr, eps);
   return tt::check_launch("tt_optimizer_step_f32");
+}
+
+// The row ranges of the fused launch: exactly the dense blocks each segment needs, then ~64 ids per sorting workgroup and no
+// more workgroups than fit beside the dense blocks at one per CU.  Shared by the launcher and tt_optimizer_ids_geometry (the
+// forward lookup that fills the row-range id lists must cut the tables the same way).
+namespace {
+struct IdsGeometry {
+  int32_t seg_first[TT_MAX_DENSE_SEGS + 1];
+  int32_t groups[kMaxSparseTables];
+  uint32_t width[kMaxSparseTables];
+};
+void ids_geometry(const int64_t* rows, int n_tables, int64_t n_ids, const tt_dense_seg* segs, int n_segs, IdsGeometry& ge) {
+  ge.seg_first[0] = 0;
+  for (int i = 0; i < n_segs; ++i) {                      // one thread per 4 elements, at most 16 blocks per segment
+    int64_t nb = (segs[i].count / 4 + 1023) / 1024;
+    if (nb < 1) nb = 1;
+    if (nb > 16) nb = 16;
+    ge.seg_first[i + 1] = ge.seg_first[i] + (int32_t)nb;
+  }
+  int64_t group_cap = (256 - ge.seg_first[n_segs]) / n_tables;
+  if (group_cap < 16) group_cap = 16;
+  for (int t = 0; t < n_tables; ++t) {
+    int64_t g = (n_ids + 63) / 64;
+    if (g > group_cap) g = group_cap;              // (one table - a sharded owner's combined shard - takes all the CUs the dense blocks leave)
+    if (g > rows[t] / 2) g = rows[t] / 2;
+    ge.groups[t] = g < 1 ? 1 : (int32_t)g;
+    ge.width[t] = (uint32_t)((rows[t] + ge.groups[t] - 1) / ge.groups[t]);
+    if (ge.width[t] < 2u) ge.width[t] = 2u;
+  }
+}
+int lanes_per_row_log2(int dim4) {
+  int l = 0;
+  while ((1 << l) < dim4 && l < 6) ++l;
+  return l;
+}
+// entries per row-range id list: what fast_apply finishes without ranks (kRowsAhead pairs per lane group), at most 256
+int bucket_cap(int32_t dim, int64_t n_ids) {
+  const int l = lanes_per_row_log2(dim / 4);
+  if (l > 5 || n_ids > tt::kPartSortMaxIds) return 0;
+  const int c = kRowsAhead * (1024 >> l);
+  return c < 256 ? c : 256;
+}
+using tt::kBucketGroupsMax;
+}  // namespace
+
+extern "C" int64_t tt_id_buckets_workspace_bytes(void) {
+  return (int64_t)kBucketGroupsMax * tt::kBucketCountStride * 4 + (int64_t)kBucketGroupsMax * 256 * 8;      // counters (a line each) + lists
+}
+
+extern "C" int tt_optimizer_ids_geometry(const int64_t* table_rows, int32_t n_tables, int32_t dim, int64_t n_ids,
+                                         const tt_dense_seg* segs, int32_t n_segs, int32_t* groups, uint32_t* width, int32_t* cap) {
+  TT_REQUIRE(table_rows && groups && width && cap, "tt_optimizer_ids_geometry: null pointer");
+  TT_REQUIRE(n_tables >= 1 && n_tables <= kMaxSparseTables, "tt_optimizer_ids_geometry: 1..%d sparse tables", kMaxSparseTables);
+  TT_REQUIRE(segs != nullptr && n_segs >= 1 && n_segs <= TT_MAX_DENSE_SEGS, "tt_optimizer_ids_geometry: 1..%d dense segments", TT_MAX_DENSE_SEGS);
+  TT_REQUIRE(n_ids > 0 && dim > 0 && dim % 4 == 0, "tt_optimizer_ids_geometry: bad n_ids/dim");
+  for (int t = 0; t < n_tables; ++t) TT_REQUIRE(table_rows[t] > 0, "tt_optimizer_ids_geometry: table %d: bad rows", t);
+  IdsGeometry ge{};
+  ids_geometry(table_rows, n_tables, n_ids, segs, n_segs, ge);
+  for (int t = 0; t < n_tables; ++t) { groups[t] = ge.groups[t]; width[t] = ge.width[t]; }
+  *cap = bucket_cap(dim, n_ids);
+  return TT_OK;
 }
 
 // The same optimizer step from the RAW ids: no tt_sparse_plan launch, no sorted ids / positions in HBM.  One launch: the
@@ -925,16 +1042,17 @@ extern "C" int tt_optimizer_step_ids_f32(int32_t opt, const tt_sparse_table_ids*
   FusedTables ft{};
   void* ws[kMaxSparseTables] = {};
   int max_groups = 0, max_lbits = 1;
-  for (int i = 0; i < n_segs; ++i) {                      // one thread per 4 elements, at most 16 blocks per segment
-    int64_t nb = (segs[i].count / 4 + 1023) / 1024;
-    if (nb < 1) nb = 1;
-    if (nb > 16) nb = 16;
-    ft.seg_first[i + 1] = ft.seg_first[i] + (int32_t)nb;
+  IdsGeometry ge{};
+  {
+    int64_t rows[kMaxSparseTables] = {1, 1, 1};
+    for (int t = 0; t < n_tables; ++t) {
+      TT_REQUIRE(tables[t].rows > 0, "tt_optimizer_step_ids_f32: table %d: null pointer / bad rows", t);
+      rows[t] = tables[t].rows;
+    }
+    ids_geometry(rows, n_tables, n_ids, segs, n_segs, ge);
   }
-  // sorting workgroups: ~64 ids each (two rounds of the apply's 32 lane groups), and no more than fit beside the dense
-  // blocks at one workgroup per CU
-  int64_t group_cap = (256 - ft.seg_first[n_segs]) / n_tables;
-  if (group_cap < 16) group_cap = 16;
+  for (int i = 0; i <= n_segs; ++i) ft.seg_first[i] = ge.seg_first[i];
+  ft.bk_cap = bucket_cap(dim, n_ids);
   for (int t = 0; t < n_tables; ++t) {
     const tt_sparse_table_ids& s = tables[t];
     TT_REQUIRE(s.table && s.grads && s.ids && s.rows > 0, "tt_optimizer_step_ids_f32: table %d: null pointer / bad rows", t);
@@ -947,12 +1065,8 @@ extern "C" int tt_optimizer_step_ids_f32(int32_t opt, const tt_sparse_table_ids*
     while (bits < 63 && ((int64_t)1 << bits) < s.rows + 1) ++bits;
     tt::PartTable& p = ft.part[t];
     p.ids = s.ids; p.sorted_ids = nullptr; p.order = nullptr; p.num_rows = s.rows; p.n = (int32_t)n_ids;
-    int64_t g = (n_ids + 63) / 64;
-    if (g > group_cap) g = group_cap;              // (one table - a sharded owner's combined shard - takes all the CUs the dense blocks leave)
-    if (g > s.rows / 2) g = s.rows / 2;
-    p.groups = g < 1 ? 1 : (int32_t)g;
-    p.width = (uint32_t)((s.rows + p.groups - 1) / p.groups);
-    if (p.width < 2u) p.width = 2u;
+    p.groups = ge.groups[t];
+    p.width = ge.width[t];
     p.magic = (uint32_t)((((uint64_t)1 << 32) / p.width) + 1u);
     p.sentinel = (uint32_t)(((uint64_t)1 << bits) - 1);
     int lb = 1;
@@ -960,6 +1074,17 @@ extern "C" int tt_optimizer_step_ids_f32(int32_t opt, const tt_sparse_table_ids*
     if (lb > max_lbits) max_lbits = lb;
     if (p.groups > max_groups) max_groups = p.groups;
     ft.first[t + 1] = ft.first[t] + p.groups;
+    // the row-range id lists of this step's forward lookup: taken only when they were cut exactly like this launch's ranges
+    const tt_id_buckets& bk = s.buckets;
+    if (bk.pairs != nullptr) {
+      TT_REQUIRE(bk.counts != nullptr, "tt_optimizer_step_ids_f32: table %d: buckets.pairs without buckets.counts", t);
+      TT_REQUIRE(ft.bk_cap > 0 && bk.groups == p.groups && bk.width == p.width && bk.cap == ft.bk_cap && p.groups <= kBucketGroupsMax,
+                 "tt_optimizer_step_ids_f32: table %d: id buckets (groups %d width %u cap %d) do not match this step's row ranges "
+                 "(groups %d width %u cap %d: tt_optimizer_ids_geometry)", t, bk.groups, bk.width, bk.cap, p.groups, p.width, ft.bk_cap);
+      TT_REQUIRE(t == 0 || tables[0].buckets.pairs == nullptr || tables[0].buckets.gen == bk.gen,
+                 "tt_optimizer_step_ids_f32: the tables' id buckets must carry one generation");
+      ft.bk_counts[t] = bk.counts; ft.bk_pairs[t] = bk.pairs; ft.bk_gen = bk.gen;
+    }
   }
   int rc = prepare_ws(a, ws, n_tables, dim, n_ids, "tt_optimizer_step_ids_f32");
   if (rc != TT_OK) return rc;
@@ -986,8 +1111,7 @@ extern "C" int tt_optimizer_step_ids_f32(int32_t opt, const tt_sparse_table_ids*
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return tt::fail(TT_ERR_LAUNCH, "tt_optimizer_step_ids_f32: hipFuncSetAttribute(LDS %d) failed", lds);
-    tt::ProfScope prof("optimizer", stream);
-    hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(1024), lds, stream, a, ft, n_tables, dim4, lpr_log2, tbl, n_segs, (int)ft.seg_first[n_segs], lr, eps);
+    tt::launch("optimizer", kern, dim3((unsigned)gx), dim3(1024), lds, stream, a, ft, n_tables, dim4, lpr_log2, tbl, n_segs, (int)ft.seg_first[n_segs], lr, eps);
     return tt::check_launch("tt_optimizer_step_ids_f32");
   };
   if (opt == TT_OPT_SGD) {

@@ -34,6 +34,11 @@ struct Tower2Args {
   const float* table2; const int64_t* ids2; int64_t table2_rows;
   int32_t* oob_flag;
   uint64_t drop_key;              // counter stream of this tower's hidden-layer dropout mask
+  // row-range id lists for the optimizer launch of the same step (tt_id_buckets): every in-range id of `ids` is appended to the
+  // list of the row range it falls in - (id - g*width) | position << 32 | generation << 48 at pairs[g*cap + slot], slot drawn
+  // from counts[g] - so that launch's sorting workgroups read ~64 entries each instead of all the batch's ids
+  uint32_t* bk_counts; uint64_t* bk_pairs;
+  uint32_t bk_width, bk_magic, bk_groups, bk_cap, bk_gen;
 };
 struct Tower2Batch {
   Tower2Args a[2];
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void tower_fwd2_kernel(Tower2Batch pb) {
   // the round's ids, then its rows, then the LDS stores.  Every load of a phase is UNCONDITIONAL, from a clamped (valid)
   // address: written as `if (live) { id = ids[r]; if (in range) ... }` per float4, hipcc put each id load in its own branch
   // with `s_waitcnt vmcnt(0)` behind it - four dependent round trips in front of the rows (r03 ISA audit,
-  // scratch/audit_serial_loads.py).  Rows that do not exist / ids out of range read row 0 and are zeroed afterwards.
+  // tests/isa_audit/audit_serial_loads.py).  Rows that do not exist / ids out of range read row 0 and are zeroed afterwards.
   // The ids of round 0 are the FIRST loads of the kernel - they head its longest dependency chain (ids -> rows -> LDS ->
   // barrier -> first MFMA); the bias and weight prefetches are issued behind them, the rows behind those. ----
   const int c4n = K0 / 4;                                    // float4 per row
@@ -149,6 +154,10 @@ __global__ __launch_bounds__(256, 2) void tower_fwd2_kernel(Tower2Batch pb) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) id2[j] = idp2[rr[j]];
   };
+  // row-range id lists (r04): slot / range / local key / position of the <= 4 rows whose float4 0 this lane holds in round 0
+  uint32_t bslot[4] = {0u, 0u, 0u, 0u}, bgrp[4] = {0u, 0u, 0u, 0u}, blk[4] = {0u, 0u, 0u, 0u}, bpos[4] = {0u, 0u, 0u, 0u};
+  bool emit[4] = {false, false, false, false};
+  const bool lists = has_ids && p.bk_pairs != nullptr && K0 <= 128;           // (uniform)
   auto fetch_rows = [&](int f0) {
     bool ok1[4], ok2[4];
     f32x4 v[4], v2[4];
@@ -157,6 +166,29 @@ __global__ __launch_bounds__(256, 2) void tower_fwd2_kernel(Tower2Batch pb) {
     for (int j = 0; j < 4; ++j) {
       ok1[j] = live[j] && (!has_ids || (id1[j] >= 0 && id1[j] < p.table_rows));
       ok2[j] = live[j] && has2 && id2[j] >= 0 && id2[j] < p.table2_rows;
+    }
+    // the row-range lists (r04): the lane that holds float4 0 of a row draws the id's slot in its range's list - a returning
+    // atomic issued IN FRONT of the row loads: memory operations return in order, so by the time the rows (younger, and a trip to
+    // HBM) have landed the slots are there and nothing waits for them.  One counter per 256-byte line (kBucketCountStride): the
+    // first version packed a table's ~220 counters into 7 lines and the forward launch took 25 us longer - device-scope atomics
+    // on one LINE serialise (~11 ns each), whatever the word.
+    if (lists && f0 == 0) {                                                    // (dim <= 128: round 0 holds every row's id)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        emit[j] = ok1[j] && c4s[j] == 0;
+        if (emit[j]) {
+          const uint32_t key = (uint32_t)id1[j];
+          uint32_t q = __umulhi(key, p.bk_magic);
+          q -= (q * p.bk_width > key) ? 1u : 0u;
+          bgrp[j] = q < p.bk_groups ? q : p.bk_groups - 1u;
+          bslot[j] = __hip_atomic_fetch_add(p.bk_counts + (size_t)bgrp[j] * tt::kBucketCountStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          blk[j] = key - bgrp[j] * p.bk_width;
+          bpos[j] = (uint32_t)rr[j] & 0xffffu;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
       const int64_t row1 = has_ids ? (ok1[j] ? id1[j] : 0) : rr[j];
       v[j] = ldg4(src + row1 * K0 + 4 * c4s[j]);
     }
@@ -206,6 +238,17 @@ __global__ __launch_bounds__(256, 2) void tower_fwd2_kernel(Tower2Batch pb) {
   }
   __syncthreads();                                           // the input tile is complete
   TSTAMP(1);
+  // the list entries leave BEHIND the barrier (in front of it its fence would wait for their acknowledgement: a memory round trip
+  // on the kernel's longest dependency chain); nothing below waits for them - the weight tiles in the ring are older
+  if (lists) {
+    // ONE wait for all four slots, on every path: left to the per-store branches the compiler re-waits `vmcnt(0)` in front of
+    // each store - i.e. for the previous store's acknowledgement, four round trips in a row (r04 ISA)
+    asm volatile("" :: "v"(bslot[0] | bslot[1] | bslot[2] | bslot[3]));
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (emit[j] && bslot[j] < p.bk_cap)                    // (a full list keeps counting: the optimizer falls back to its scan)
+        p.bk_pairs[(size_t)bgrp[j] * p.bk_cap + bslot[j]] = (uint64_t)blk[j] | ((uint64_t)bpos[j] << 32) | ((uint64_t)(p.bk_gen & 0xffffu) << 48);
+  }
 
   // ================= layer 0: h[32, H] = x[32, K0] @ W0[K0, H] =================
   f32x16 acc[HB > NB ? HB : NB];
@@ -396,6 +439,14 @@ extern "C" int tt_tower_fwd2_batched_f32(const tt_dense_fwd_args* layer0, const 
       TT_REQUIRE((lk.table2 == nullptr) == (lk.ids2 == nullptr), "tt_tower_fwd2_batched_f32: lookup.table2 and lookup.ids2 go together");
       t.table = lk.table; t.ids = lk.ids; t.table_rows = lk.table_rows;
       t.table2 = lk.table2; t.ids2 = lk.ids2; t.table2_rows = lk.table2_rows; t.oob_flag = lk.oob_flag;
+      const tt_id_buckets& bk = lk.buckets;
+      if (bk.pairs != nullptr) {
+        TT_REQUIRE(bk.counts != nullptr && bk.groups >= 1 && bk.width >= 1u && bk.cap >= 1 && m <= 65536,
+                   "tt_tower_fwd2_batched_f32: lookup.buckets: counts / groups / width / cap must be set (and m <= 65536)");
+        t.bk_counts = bk.counts; t.bk_pairs = bk.pairs; t.bk_width = bk.width; t.bk_groups = (uint32_t)bk.groups;
+        t.bk_cap = (uint32_t)bk.cap; t.bk_gen = bk.gen;
+        t.bk_magic = (uint32_t)((((uint64_t)1 << 32) / bk.width) + 1u);
+      }
     } else {
       TT_REQUIRE(a.x != nullptr, "tt_tower_fwd2_batched_f32: null input x (and no lookup)");
     }
@@ -421,8 +472,7 @@ extern "C" int tt_tower_fwd2_batched_f32(const tt_dense_fwd_args* layer0, const 
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return tt::fail(TT_ERR_LAUNCH, "tt_tower_fwd2_batched_f32: hipFuncSetAttribute(LDS %d) failed", lds);
-    tt::ProfScope prof("dense_fwd", stream);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, stream, pb);
+    tt::launch("dense_fwd", kern, dim3(blocks), dim3(256), lds, stream, pb);
     return tt::check_launch("tt_tower_fwd2_batched_f32");
   };
   const int hb = h / 128, nb = n1 / 128;

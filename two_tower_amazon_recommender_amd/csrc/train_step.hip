@@ -1,6 +1,7 @@
 // tt_train_step_f32 - the whole train step behind ONE C entry (include/twotower_hip.h, ABI v8).  Host code only: it calls the
 // library's own entry points in the order a caller would, so the arithmetic and the launches are theirs, bit for bit.
 #include "common.h"
+#include <atomic>
 #include <cstdlib>
 
 extern "C" int tt_train_step_f32(const tt_train_step* s, tt_stream_t stream) {
@@ -16,9 +17,38 @@ extern "C" int tt_train_step_f32(const tt_train_step* s, tt_stream_t stream) {
   // two-layer towers: both layers of both towers in one launch (csrc/tower.hip); TT_FUSED_TOWER=0 keeps the two launches (A/B)
   static const bool fused_tower = std::getenv("TT_FUSED_TOWER") == nullptr || std::atoi(std::getenv("TT_FUSED_TOWER")) != 0;
   const bool fwd2 = fused_tower && L == 2 && tt_tower_fwd2_supported(s->batch, s->dims[0], s->dims[1], s->dims[2]);
+  // r04: the forward lookup hands the optimizer launch its row-range id lists (tt_id_buckets): with a bucket workspace, a fused
+  // tower forward (the lookup that can fill them) and a shape that takes lists, both launches get the same descriptors - cut by
+  // tt_optimizer_ids_geometry, one generation per step.  TT_ID_BUCKETS=0 keeps the optimizer's own id scan (A/B).
+  static const bool want_lists = std::getenv("TT_ID_BUCKETS") == nullptr || std::atoi(std::getenv("TT_ID_BUCKETS")) != 0;
+  static std::atomic<uint32_t> generation{0};
+  tt_dense_fwd_args f0[2] = {s->fwd[0][0], s->fwd[0][1]};
+  tt_sparse_table_ids tabs[3] = {s->tables[0], s->tables[1], s->tables[2]};
+  if (want_lists && fwd2 && s->id_bucket_ws != nullptr && f0[0].lookup.ids != nullptr && f0[1].lookup.ids != nullptr &&
+      f0[0].lookup.ids == tabs[0].ids && f0[1].lookup.ids == tabs[1].ids && f0[0].lookup.table_rows == tabs[0].rows &&
+      f0[1].lookup.table_rows == tabs[1].rows) {
+    const int64_t per = tt_id_buckets_workspace_bytes();
+    TT_REQUIRE((reinterpret_cast<uintptr_t>(s->id_bucket_ws) & 255u) == 0 && s->id_bucket_ws_bytes >= 2 * per,
+               "tt_train_step_f32: id_bucket_ws must be 256-byte aligned and hold 2 * tt_id_buckets_workspace_bytes() = %lld bytes",
+               (long long)(2 * per));
+    int64_t rows[3] = {tabs[0].rows, tabs[1].rows, s->n_tables > 2 ? tabs[2].rows : 1};
+    int32_t groups[3] = {0, 0, 0}, cap = 0;
+    uint32_t width[3] = {0, 0, 0};
+    rc = tt_optimizer_ids_geometry(rows, s->n_tables, s->dims[0], s->batch, s->segs, s->n_segs, groups, width, &cap);
+    if (rc != TT_OK) return rc;
+    if (cap > 0 && groups[0] <= 256 && groups[1] <= 256) {
+      const uint32_t gen = generation.fetch_add(1u) + 1u;
+      for (int t = 0; t < 2; ++t) {
+        char* base = static_cast<char*>(s->id_bucket_ws) + t * per;
+        tt_id_buckets bk{reinterpret_cast<uint32_t*>(base), reinterpret_cast<uint64_t*>(base + (size_t)tt::kBucketGroupsMax * tt::kBucketCountStride * 4), groups[t], width[t], cap, gen};
+        f0[t].lookup.buckets = bk;
+        tabs[t].buckets = bk;
+      }
+    }
+  }
   if (fwd2) {
     const bool drop = s->dropout_rate > 0.f;
-    rc = tt_tower_fwd2_batched_f32(s->fwd[0], s->fwd[1], 2, s->batch, s->dims[0], s->dims[1], s->dims[2], drop ? s->dropout_rate : 0.f,
+    rc = tt_tower_fwd2_batched_f32(f0, s->fwd[1], 2, s->batch, s->dims[0], s->dims[1], s->dims[2], drop ? s->dropout_rate : 0.f,
                                    s->dropout_seed, drop ? s->dropout_row0 * (uint64_t)s->dims[1] : 0ull, stream);
     if (rc != TT_OK) return rc;
   }
@@ -46,5 +76,5 @@ extern "C" int tt_train_step_f32(const tt_train_step* s, tt_stream_t stream) {
     rc = tt_dense_bwd_batched_f32(s->bwd[l], 2, l > 0 ? dx_scale : 1.0f, s->batch, s->dims[l], s->dims[l + 1], stream);
     if (rc != TT_OK) return rc;
   }
-  return tt_optimizer_step_ids_f32(s->opt, s->tables, s->n_tables, s->dims[0], s->batch, s->segs, s->n_segs, s->lr, s->eps, stream);
+  return tt_optimizer_step_ids_f32(s->opt, tabs, s->n_tables, s->dims[0], s->batch, s->segs, s->n_segs, s->lr, s->eps, stream);
 }

@@ -284,7 +284,35 @@ def sparse_update2_(opt: str, table_a, accum_a, grads_a, plan_a: SparsePlan,
 MAX_FUSED_LOOKUP_ROWS = 32768       # tt_dense_lookup: the ids of one dW split are staged in LDS
 
 
-def make_lookup(table, ids, table2=None, ids2=None, oob_flag=None) -> "_lib.DenseLookup":
+class IdBuckets:
+    """Row-range id lists (``tt_id_buckets``, ABI v9) for one train step's tables: the forward lookup (``make_lookup(...,
+    buckets=b.desc(t, gen))``) appends every id to the list of the row range the optimizer launch's sorting workgroup owns, and
+    ``optimizer_step_ids_(..., buckets=[...])`` of the same step reads ~64 entries per workgroup instead of all the ids.
+    ``cap == 0``: the shape takes no lists (dim > 128 or more than 16384 ids)."""
+
+    def __init__(self, table_rows, dim: int, n_ids: int, segs, device):
+        lib = _lib.load()
+        n = len(table_rows)
+        rows = (_lib.C.c_int64 * n)(*table_rows)
+        groups, width, cap = (_lib.C.c_int32 * n)(), (_lib.C.c_uint32 * n)(), _lib.C.c_int32(0)
+        arr_s = (DenseSeg * len(segs))(*segs)
+        _lib.check(lib.tt_optimizer_ids_geometry(rows, n, dim, n_ids, arr_s, len(segs), groups, width, _lib.C.byref(cap)),
+                   "tt_optimizer_ids_geometry")
+        self.groups, self.width, self.cap = list(groups), list(width), int(cap.value)
+        self.per = int(lib.tt_id_buckets_workspace_bytes())
+        self.ws = torch.zeros(n * self.per, dtype=torch.uint8, device=device)
+
+    def desc(self, t: int, gen: int) -> "_lib.IdBuckets":
+        base = self.ws.data_ptr() + t * self.per
+        return _lib.IdBuckets(base, base + self.COUNT_BYTES, self.groups[t], self.width[t], self.cap, gen & 0xFFFFFFFF)
+
+    COUNT_BYTES = 256 * 256          # one counter per 256-byte line (csrc/common.h: kBucketGroupsMax * kBucketCountStride * 4)
+
+    def counts(self, t: int) -> torch.Tensor:
+        return self.ws[t * self.per: t * self.per + self.COUNT_BYTES].view(torch.int32)[:: 64][: self.groups[t]]
+
+
+def make_lookup(table, ids, table2=None, ids2=None, oob_flag=None, buckets=None) -> "_lib.DenseLookup":
     """The embedding lookup fused into a tower's FIRST Dense layer (``tt_dense_lookup``): the layer's input row r is
     ``table[ids[r]]`` (+ ``table2[ids2[r]]``), read straight into the GEMM tiles — never written to HBM."""
     _chk(table, torch.float32, "lookup table", 2)
@@ -302,6 +330,8 @@ def make_lookup(table, ids, table2=None, ids2=None, oob_flag=None) -> "_lib.Dens
         raise RuntimeError(f"make_lookup: at most {MAX_FUSED_LOOKUP_ROWS} rows per fused lookup")
     lk = _lib.DenseLookup(_p(table), _p(ids), table.shape[0], _p(table2), _p(ids2), 0 if table2 is None else table2.shape[0],
                           _p(oob_flag))
+    if buckets is not None:
+        lk.buckets = buckets
     lk._keep = (table, ids, table2, ids2, oob_flag)      # the struct holds raw pointers: keep the tensors alive with it
     lk._mk = (ids.numel(), table.shape[1])
     return lk
@@ -474,7 +504,7 @@ def sparse_plan_max_lds_ids() -> int:
     return int(_lib.load().tt_sparse_plan_max_lds_ids())
 
 
-def optimizer_step_ids_(opt: str, tables, segs: list[DenseSeg], lr: float, eps: float = 1e-7):
+def optimizer_step_ids_(opt: str, tables, segs: list[DenseSeg], lr: float, eps: float = 1e-7, buckets=None):
     """The same step from the RAW ids, no sort-plan launch: ``tables`` = [(table, accum or None, grads, ids, plan), ...]
     (``plan`` only lends its apply workspace); n_ids <= sparse_plan_max_lds_ids().  Bit-identical to
     ``sparse_plan_batched`` + ``optimizer_step_``."""
@@ -491,6 +521,8 @@ def optimizer_step_ids_(opt: str, tables, segs: list[DenseSeg], lr: float, eps: 
         if table.shape[1] != dim or ids.numel() != n_ids or plan.n_ids != n_ids or tuple(grads.shape) != (n_ids, dim):
             raise RuntimeError("optimizer_step_ids_: every table needs the same dim, the same number of ids and [n_ids, dim] gradients")
         arr_t[i] = _lib.SparseTableIds(_p(table), _p(accum), table.shape[0], _p(grads), _p(ids), _p(plan.apply_ws(dim)))
+        if buckets is not None and buckets[i] is not None:       # the row-range lists this step's forward lookup filled
+            arr_t[i].buckets = buckets[i]
     arr_s = (DenseSeg * len(segs))(*segs)
     _lib.check(_lib.load().tt_optimizer_step_ids_f32(_OPT[opt], arr_t, len(tables), dim, n_ids, arr_s, len(segs), lr, eps, _stream()),
                "tt_optimizer_step_ids_f32")

@@ -269,6 +269,7 @@ class TwoTowerTrainer:
         # instead of nine; cfg1 is host-bound).  TT_COMPOSITE_STEP=0: the Python sequence of the separate entry points.
         self.use_composite = os.environ.get("TT_COMPOSITE_STEP", "1") != "0"
         self._cstep = None
+        self._id_bucket_ws = None
         self.flag_poll_every = 50                # steps between asynchronous polls of the out-of-range flag (0 = never)
         self._oob_host = self._oob_event = None
         self._oob_step = -1
@@ -483,6 +484,12 @@ class TwoTowerTrainer:
         for i, seg in enumerate(self._segs):
             st.segs[i] = seg
         st.lr, st.eps = cfg.learning_rate, cfg.adagrad_epsilon
+        # r04: the forward lookup hands the optimizer launch its row-range id lists (tt_id_buckets, ABI v9): a zeroed workspace
+        # is all the caller supplies, tt_train_step_f32 cuts the ranges and stamps a generation per step
+        if self._id_bucket_ws is None:
+            per = int(_lib.load().tt_id_buckets_workspace_bytes())
+            self._id_bucket_ws = torch.zeros(2 * per, dtype=torch.uint8, device=self.dev)
+        st.id_bucket_ws, st.id_bucket_ws_bytes = p(self._id_bucket_ws), self._id_bucket_ws.numel()
         return st
 
     def _step_composite(self, ids, sample_weight=None, candidate_sampling_probability=None, candidate_ids=None,
@@ -517,7 +524,8 @@ class TwoTowerTrainer:
         st.dropout_seed = self.dropout_seed
         st.dropout_row0 = self.step_index * self.cfg.batch_size
         st.scorer_precision = ops.SCORER_PRECISIONS.index(self.cfg.scorer_precision)   # (may be switched between steps: bench's second line)
-        st.lr = self.cfg.learning_rate
+        st.lr, st.eps = self.cfg.learning_rate, self.cfg.adagrad_epsilon                 # (re-read every step, like the Python sequence)
+        st.inv_temperature, st.dropout_rate = 1.0 / self.cfg.temperature, self.cfg.dropout_rate
         st.sample_weight, st.cand_prob, st.cand_ids = p(sample_weight), p(candidate_sampling_probability), p(candidate_ids)
         _lib.check(_lib.load().tt_train_step_f32(st, ops._stream()), "tt_train_step_f32")
         self.step_index += 1
