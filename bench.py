@@ -10,9 +10,17 @@ temperature 0.1, SGD lr 0.001, uniform ids, synthetic counter-based data (SURVEY
 
 Inputs (tables, weights, id batches) are resident in HBM before the timed region.  A step is one
 pass of the hot path over one batch.  The `roofline` object is measured live, inside the timed
-steps, with hipEvents recorded around every launch of the dominant kernel on its own stream
-(tt_profile_enable); `cpu_baseline` times the torch-CPU restatement (oracle/torch_cpu.py, kind
-"port") on a bounded sample of the same batches, rank 0, N=1 only.
+steps: sampled launches of the dominant kernel go out through hipExtLaunchKernelGGL with a HIP event
+pair that the runtime fills with the dispatch's own begin / end timestamps on its stream
+(tt_profile_enable; r04 - the figures rocprofv3 --kernel-trace reports, no barrier packets; through
+r03 hipEventRecord brackets, ~3 us longer per launch); `cpu_baseline` times the torch-CPU
+restatement (oracle/torch_cpu.py, kind "port") on a bounded sample of the same batches, rank 0, N=1.
+
+Extra, separately labelled lines for profiles/ (never the headline): `--config ref` = the only
+configuration the reference writes down (/root/reference/configs/data_config.yaml:54-71:
+embedding_dim 128, towers [512, 256, 128], batch 1024, dropout 0.1; table sizes are cfg3's - the
+reference names none; Adagrad); `--engine ops` = the same step through the boundary north_star
+names: tasks.Retrieval + torch.ops.twotower.* + torch.autograd instead of the explicit trainer.
 """
 import argparse
 import json
@@ -32,7 +40,10 @@ CONFIGS = {
     # also fit ONE MI355X (288 GB), so N=1 measures them un-sharded
     "cfg4": (5_000_000, 100_000_000, 128, [256, 128], 16384),
     "cfg5": (54_000_000, 48_000_000, 256, [512, 256], 32768),
+    # the reference's own `model:` block (configs/data_config.yaml:54-71); it names no table sizes: cfg3's
+    "ref": (5_000_000, 10_000_000, 128, [512, 256, 128], 1024),
 }
+REF_DROPOUT = 0.1                   # configs/data_config.yaml:58
 CATEGORY_BUCKETS = {"cfg5": 30}     # BASELINE configs[4]: "30 categories as hash features" (summed into the item tower input)
 MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32-input MFMA dense peak
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
@@ -47,6 +58,9 @@ def parse():
     ap.add_argument("--optimizer", default=None, choices=["sgd", "adagrad"],
                     help="default: sgd (cfg5: adagrad — BASELINE configs[4] names the fused sparse Adagrad)")
     ap.add_argument("--ids", default="U", choices=["U", "Z"], help="uniform / power-law id batches")
+    ap.add_argument("--engine", default="trainer", choices=["trainer", "ops"],
+                    help="trainer: the explicit engine behind tt_train_step_f32 (headline); ops: tasks.Retrieval + "
+                         "torch.ops.twotower.* + autograd (the boundary north_star names; an extra line, never the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
@@ -97,19 +111,20 @@ def cpu_share() -> int:
 
 
 # rocprofv3 --pmc passes (scratch/prof_pmc.sh + pmc_summary.py) of the newest round that committed one
-PMC_FILE = next((f for f in ("profiles/r03_pmc_cfg3_sgd.json", "profiles/r02_pmc_cfg3_sgd.json")
+PMC_FILE = next((f for f in ("profiles/r04_pmc_cfg3_sgd.json", "profiles/r03_pmc_cfg3_sgd.json", "profiles/r02_pmc_cfg3_sgd.json")
                  if os.path.exists(os.path.join(ROOT, f))), "profiles/r02_pmc_cfg3_sgd.json")
 
 
 # rocprofv3 --kernel-trace --stats of `bench.py --steps 200 --warmup 20` (scratch/prof.sh), newest committed round
-KSTATS_FILE = next((f for f in ("profiles/r03_bench_cfg3_kernel_stats.csv", "profiles/r02_bench_cfg3_kernel_stats.csv")
+KSTATS_FILE = next((f for f in ("profiles/r04_bench_cfg3_kernel_stats.csv", "profiles/r03_bench_cfg3_kernel_stats.csv",
+                                "profiles/r02_bench_cfg3_kernel_stats.csv")
                     if os.path.exists(os.path.join(ROOT, f))), None)
 
 
 def rocprof_avg_us(*needles):
     """Sum of the average durations (us) of the kernels whose name contains one of `needles`, from the COMMITTED rocprofv3
-    kernel stats of the cfg3 / sgd step - not measured in this run (hipEvent brackets add ~3 us to launches this short; the
-    profiler's begin / end timestamps do not).  None when the file or a kernel is missing."""
+    kernel stats of the cfg3 / sgd step - not measured in this run; since r04 the live figures are the same dispatch
+    timestamps, so this is a cross-check only.  None when the file or a kernel is missing."""
     try:
         import csv
         rows = list(csv.DictReader(open(os.path.join(ROOT, KSTATS_FILE))))
@@ -157,6 +172,85 @@ def cpu_baseline(trainer, cfg, seed, args, batch):
                       f"{sec * 1e3:.1f} ms/step; restatement, not reference code"}
 
 
+def run_ops_engine(args, cfg, seed, dev):
+    """The train step through the boundary `north_star` names (an EXTRA line for profiles/, never the headline):
+    torch.ops.twotower.embedding_gather -> torch.ops.twotower.dense_fwd (autograd: dense_bwd) -> tasks.Retrieval
+    (torch.ops.twotower.retrieval_loss, gradients saved for autograd) -> loss.backward() -> torch.ops.twotower.sparse_update_
+    on the embedding-row gradients + a stock torch optimizer on the Dense parameters.  What a user of tfrs.tasks.Retrieval
+    would write around the custom ops; every launch is its own FFI crossing, outputs are allocated per call."""
+    from two_tower_amazon_recommender_amd import _lib
+    from two_tower_amazon_recommender_amd.tasks import Retrieval
+    from two_tower_amazon_recommender_amd.trainer import TwoTowerTrainer
+    tr = TwoTowerTrainer(cfg, dev, seed=seed)              # (the same initial state and id batches as the trainer engine)
+    batch, dims = cfg.batch_size, [cfg.embedding_dim] + list(cfg.user_dims)
+    towers = []
+    for tw in (tr.user_tower, tr.item_tower):
+        towers.append(([w.detach().clone().requires_grad_(True) for w in tw.w], [b.detach().clone().requires_grad_(True) for b in tw.b]))
+    params = [p for ws, bs in towers for p in ws + bs]
+    dense_opt = (torch.optim.Adagrad(params, lr=cfg.learning_rate, initial_accumulator_value=cfg.adagrad_initial_accumulator,
+                                     eps=cfg.adagrad_epsilon)
+                 if cfg.optimizer == "adagrad" else torch.optim.SGD(params, lr=cfg.learning_rate))
+    tables = (tr.user_table, tr.item_table)
+    accums = (tr.user_accum, tr.item_accum) if cfg.optimizer == "adagrad" else (None, None)
+    task = Retrieval(temperature=cfg.temperature)
+    total = args.warmup + args.steps
+    ids = [tr.synthetic_batch(seed, s, args.ids) for s in range(min(total, 64))]
+    torch.cuda.synchronize()
+
+    def tower(x, ws, bs):
+        for l, (w, b) in enumerate(zip(ws, bs)):
+            hidden = l < len(ws) - 1
+            x = torch.ops.twotower.dense_fwd(x, w, b, hidden)
+            if hidden and cfg.dropout_rate > 0:
+                x = torch.nn.functional.dropout(x, cfg.dropout_rate)
+        return x
+
+    def step(s):
+        u, i = ids[s % len(ids)]
+        embs = [torch.ops.twotower.embedding_gather(tables[t], (u, i)[t]).requires_grad_(True) for t in range(2)]
+        q, c = tower(embs[0], *towers[0]), tower(embs[1], *towers[1])
+        loss = task(q, c, compute_metrics=False)
+        dense_opt.zero_grad(set_to_none=True)
+        loss.backward()
+        dense_opt.step()                                   # (no l2 term here: the boundary leaves regularisation to the caller)
+        for t in range(2):
+            torch.ops.twotower.sparse_update_(tables[t], accums[t], embs[t].grad, (u, i)[t], cfg.optimizer, cfg.learning_rate,
+                                              cfg.adagrad_epsilon)
+        return loss
+
+    for s in range(args.warmup):
+        step(s)
+    torch.cuda.synchronize()
+    _lib.profile_set_stride(4 if args.steps >= 8 else 1)
+    _lib.profile_enable("score_fused", capacity=2 * args.steps + 8)
+    t0 = time.perf_counter()
+    for s in range(args.warmup, total):
+        loss = step(s)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tf_ = mean(_lib.profile_read("score_fused", 2 * args.steps + 8)[0]) * 1e-3
+    _lib.profile_set_stride(1)
+    _lib.profile_enable("")
+    sd = dims[-1]
+    a = 4.0 * batch * batch * sd / tf_ / 1e12 if tf_ > 0 else None
+    print(json.dumps({
+        "metric": "user-item pairs/sec (train step) + embedding-gather HBM GB/s, 1/2/4/8 MI355X",
+        "value": batch / (dt / args.steps), "unit": "pairs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{args.config}: {cfg.n_users} users x {cfg.n_items} items, emb_dim {cfg.embedding_dim}, towers "
+                               f"{'->'.join(map(str, dims))}, batch {batch}, in-batch sampled softmax T={cfg.temperature}, "
+                               f"{cfg.optimizer} lr {cfg.learning_rate}, dropout {cfg.dropout_rate}, ids {args.ids}",
+                   "engine": "ops: tasks.Retrieval + torch.ops.twotower.* + torch.autograd (embedding_gather, dense_fwd / dense_bwd, "
+                             "retrieval_loss, sparse_update_) + a stock torch optimizer on the Dense parameters",
+                   "global_batch": batch, "parallelism": "single GPU"},
+        "note": "EXTRA line (the boundary itself), not the headline: the headline engine is the explicit trainer behind tt_train_step_f32",
+        "roofline": {"bound": "mfma", "kernel": f"score_kernel<{sd},FUSED_S> (loss + dq pass of torch.ops.twotower.retrieval_loss)",
+                     "achieved": a, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": (a / MFMA_F32_PEAK_TFLOPS) if a else None,
+                     "traffic": None, "avg_launch_us": tf_ * 1e6},
+        "loss_per_pair": float(loss.item()) / batch}))
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:       # not under a launcher: become one
@@ -164,7 +258,7 @@ def main():
     import torch                        # (imported here, not at module level: the self-launching parent never loads it)
     globals()["torch"] = torch
     if args.optimizer is None:
-        args.optimizer = "adagrad" if args.config == "cfg5" else "sgd"
+        args.optimizer = "adagrad" if args.config in ("cfg5", "ref") else "sgd"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -181,11 +275,14 @@ def main():
         return run_distributed(args, rank, world, dev)
 
     n_users, n_items, dim, tower_dims, batch = CONFIGS[args.config]
-    seed = 1000 + int(args.config[3:])
+    seed = 1000 + (9 if args.config == "ref" else int(args.config[3:]))
     cfg = TwoTowerConfig(n_users=n_users, n_items=n_items, embedding_dim=dim, tower_dims=tower_dims,
                          temperature=0.1, l2_regularization=1e-6, learning_rate=0.001,
                          optimizer=args.optimizer, batch_size=batch,
+                         dropout_rate=REF_DROPOUT if args.config == "ref" else 0.0,
                          n_category_buckets=CATEGORY_BUCKETS.get(args.config, 0))
+    if args.engine == "ops":
+        return run_ops_engine(args, cfg, seed, dev)
     trainer = TwoTowerTrainer(cfg, dev, seed=seed)
     total = args.warmup + args.steps
     uids = torch.empty(total, batch, dtype=torch.int64, device=dev)
@@ -220,9 +317,10 @@ def main():
     torch.cuda.synchronize()
     trainer.check_ids()
 
-    # Timed region: only the DOMINANT kernel carries hipEvent brackets (each event record is a barrier packet that
-    # costs the stream ~4-7 us: bracketing all five kernel families inflated the step by 33 us = 4 %).  The other
-    # kernels' durations come from an untimed detail pass of the same steps right after it.
+    # Timed region: only the DOMINANT kernel is timestamped (hipExtLaunchKernelGGL with an event pair: the dispatch's own begin /
+    # end timestamps - no barrier packets, but a timestamped dispatch still costs the stream ~4 us: with all five kernel families
+    # on at stride 4 the step was 0.5642 ms against 0.5584, r04 call 1).  The other kernels' durations come from an untimed detail
+    # pass of the same steps right after it.
     all_tags = "score_fused,score_bwd,gather,sparse_plan,sparse_apply,optimizer,dense_fwd,dense_bwd".split(",")
     timed_tags = os.environ.get("TT_BENCH_TAGS", "score_fused")
     # the dominant kernel is bracketed on every 4th step only, whatever --steps is: with a bracket on EVERY launch the two
@@ -238,7 +336,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof = {t: _lib.profile_read(t, 2 * args.steps + 8)[0] for t in timed_tags.split(",") if t in all_tags}
-    detail_steps = min(args.steps, 50)
+    detail_steps = min(args.steps, 100)
     rest = [t for t in all_tags if t not in prof]
     _lib.profile_set_stride(1)
     _lib.profile_enable(",".join(rest), capacity=2 * detail_steps + 8)
@@ -298,6 +396,9 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     sd = tower_dims[-1]
     b2d = float(batch) * batch * sd
+    if args.config == "ref":
+        out_note_ref = ("the reference's own model block (configs/data_config.yaml:54-71): 3-layer towers run per-layer launches "
+                        "(the fused two-layer tower forward does not apply), dropout 0.1 in the GEMM epilogues; an EXTRA line, not the headline")
     # The scorer+loss runs as two launches of one kernel template per step:
     #   score_kernel<D,FUSED_S>: loss + dq — algorithmic 4*B^2*D (fwd 2 + dq 2), executed 4*B^2*D; also writes the raw
     #                                        dot products [B][B] f32 to the workspace (4*B^2 bytes)
@@ -309,7 +410,7 @@ def main():
     def roof(name, alg_flops, t, exec_flops=None):
         exec_flops = alg_flops if exec_flops is None else exec_flops
         if t <= 0:
-            return {"bound": "mfma", "kernel": name, "achieved": None, "note": "no hipEvent samples (graph replay)"}
+            return {"bound": "mfma", "kernel": name, "achieved": None, "note": "no timestamp samples (graph replay)"}
         a = alg_flops / t / 1e12
         return {"bound": "mfma", "kernel": name, "achieved": a, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": a / MFMA_F32_PEAK_TFLOPS, "traffic": None,
@@ -367,9 +468,10 @@ def main():
                                + (f", + {cfg.n_category_buckets}-bucket hashed category feature summed into the item input"
                                   if cfg.n_category_buckets else ""),
                    "global_batch": batch, "parallelism": "single GPU"},
-        "timing_note": f"hipEvent brackets inside the timed region: {timed_tags} only, every {stride}th step "
-                       f"({len(prof['score_fused'])} samples); score_bwd / gather / sparse_* durations "
-                       f"from an untimed detail pass of {detail_steps} further steps",
+        "timing_note": f"kernel durations = the dispatch's own begin/end timestamps (hipExtLaunchKernelGGL event pair: what "
+                       f"rocprofv3 --kernel-trace reports; no barrier packets). Inside the timed region: {timed_tags} only, every "
+                       f"{stride}th step ({len(prof['score_fused'])} samples: a timestamped dispatch still costs the stream ~4 us); "
+                       f"every other kernel from an untimed detail pass of {detail_steps} further steps",
         "roofline": dominant,
         "roofline_hbm": {"bound": "hbm",
                          "kernel": "K1 + K2 on the critical path: "
@@ -389,8 +491,11 @@ def main():
                                          "of the forward pass). " if plan_on_main else
                                          "EXCLUDED and reported beside it: part_sort_kernel (the plan: one launch for all tables on "
                                          "a side stream, concurrent with the forward pass; TT_PLAN_STREAM=side). "))
-                                   + "Each hipEvent bracket adds ~3 us to kernels this short (frac is a lower bound); rocprof "
-                                     "durations of the same kernels: profiles/",
+                                   + ("Row-range id lists (r04): the forward lookup appends every id to the list of the row range "
+                                      "its sorting workgroup owns; the optimizer launch reads its ~64 entries instead of scanning all ids. "
+                                      if (fused_sort and lookup_fused and os.environ.get("TT_ID_BUCKETS", "1") != "0") else "")
+                                   + "Durations are dispatch timestamps (= rocprofv3's); an EMPTY kernel takes 4.0 us by the same "
+                                     "clock on this system (profiles/r04_launch_floor.txt)",
                          "achieved": gs_bytes / t_gs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": gs_bytes / t_gs / 1e9 / HBM_PEAK_GBS,
                          "traffic": None,
@@ -412,7 +517,7 @@ def main():
         "loss_per_pair": loss / batch,
     }
     # the tower GEMMs (K3): forward + dx + dw of every layer of both towers = 3 * 2*B*sum(in*out) * 2 FLOPs,
-    # over the hipEvent-bracketed launches of the untimed detail pass (each bracket adds ~3 us: rocprof figures in profiles/)
+    # over the timestamped launches of the untimed detail pass
     dims_all = [dim] + list(cfg.user_dims)
     gemm_flops = 3.0 * 2.0 * batch * sum(a * b for a, b in zip(dims_all[:-1], dims_all[1:])) * 2.0
     t_gemm = (per_step("dense_fwd") + per_step("dense_bwd")) * 1e-3
@@ -430,8 +535,11 @@ def main():
             rp = rocprof_avg_us("tower_fwd2_kernel", "gemm_bwd_kernel<0>", "gemm_bwd_kernel<256>")
             if rp:
                 out["roofline_gemm"].update({"rocprof_us_per_step": rp, "rocprof_frac": gemm_flops / (rp * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                                             "rocprof_source": f"{KSTATS_FILE} (committed; not re-measured in this run - the live figure "
-                                                               "carries ~3 us of hipEvent bracket per launch)"})
+                                             "rocprof_source": f"{KSTATS_FILE} (committed; not re-measured in this run - a cross-check of the live "
+                                                               "dispatch-timestamp figure)"})
+    if args.config == "ref":
+        out["note"] = out_note_ref
+        out["config"]["dropout_rate"] = REF_DROPOUT
     if alt is not None:
         alt_steps, dta, tf_, tb_, aloss = alt
         # per launch of the FUSED pass: GEMM1 = 2*B^2*D algorithmic FLOPs at 6 bf16 products each, GEMM2 = 2*B^2*D at 3

@@ -320,6 +320,14 @@ typedef struct tt_dense_seg {
 } tt_dense_seg;
 int tt_dense_update_f32(const tt_dense_seg* segs, int32_t n_segs, int32_t opt, int32_t apply,
                         float lr, float eps, tt_stream_t stream);
+/* tt_dense_bwd_batched_f32 with a dense parameter update RIDING in the same launch (ABI v9): `segs` (apply = 1 semantics of
+ * tt_dense_update_f32) must belong to ANOTHER layer - in a backward pass, the layer above, whose gradient slabs the previous
+ * backward launch completed; a segment whose slabs this launch writes or whose weights it reads is refused.  The update's
+ * blocks are the first workgroups of the dx+dw launch: no launch of their own, and their slab traffic (cfg3: 9 of the step's
+ * 18 MB) leaves the optimizer launch, whose HBM burst is the embedding rows'.  Same arithmetic, bit for bit.  With dx or dw
+ * alone (two launches anyway) the update runs as its own launch behind them.                                            */
+int tt_dense_bwd_batched_update_f32(const tt_dense_bwd_args* probs, int32_t n_probs, float dx_scale, int64_t m, int32_t k, int32_t n,
+                                    const tt_dense_seg* segs, int32_t n_segs, int32_t opt, float lr, float eps, tt_stream_t stream);
 
 /* The whole optimizer of a train step in ONE launch: the fused sparse update of up to 3 embedding tables (user, item,
  * hashed category; same dim and n_ids, each with its own sort plan and apply workspace) AND the dense update of every

@@ -448,6 +448,48 @@ def test_sparse_update_is_run_to_run_deterministic(dev):
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
 
 
+@pytest.mark.parametrize("opt", ["sgd", "adagrad"])
+def test_dense_update_riding_in_a_backward_launch_is_bit_identical(dev, opt):
+    """tt_dense_bwd_batched_update_f32 (ABI v9): the dense update of another layer's segments as the first workgroups of the
+    dx+dw launch - same dx / dw slabs and same updated parameters (and accumulators) as the launch followed by
+    tt_dense_update_f32; a segment of the launch's OWN layer is refused.  (Built, measured and left off in the train step:
+    profiles/r04_optimizer_ab.txt.)"""
+    m, k, n = 2048, 128, 256
+    xs = [T(synth.uniform_f32(61, 1 + t, m * k, -1.0, 2.0).reshape(m, k), dev) for t in range(2)]
+    ws = [T(synth.uniform_f32(61, 3 + t, k * n, -0.2, 0.4).reshape(k, n), dev) for t in range(2)]
+    dzs = [T(synth.uniform_f32(61, 5 + t, m * n, -1.0, 2.0).reshape(m, n), dev) for t in range(2)]
+    ns = ops.dense_bwd_num_slabs(m)
+    other = 5000                                                           # the "layer above": 2 kernels + 2 biases, 7 slabs
+    slabs = [T(synth.uniform_f32(61, 10 + i, 7 * c, -1.0, 2.0).reshape(7, c), dev) for i, c in enumerate((other, 256, other, 256))]
+
+    def run(ride):
+        dxs = [torch.empty(m, k, device=dev) for _ in range(2)]
+        dws = [torch.empty(ns, k, n, device=dev) for _ in range(2)]
+        dbs = [torch.empty(ns, n, device=dev) for _ in range(2)]
+        params = [T(synth.uniform_f32(61, 20 + i, c, -1.0, 2.0), dev) for i, c in enumerate((other, 256, other, 256))]
+        accs = [torch.full_like(p, 0.1) if opt == "adagrad" else None for p in params]
+        segs = [ops.make_dense_seg(params[i], accs[i], slabs[i], 7, 1e-6 if i % 2 == 0 else 0.0) for i in range(4)]
+        if ride:
+            ops.dense_bwd2(xs, ws, dzs, dxs, [None, None], dws, dbs, riders=(segs, opt, 0.01, 1e-7))
+        else:
+            ops.dense_bwd2(xs, ws, dzs, dxs, [None, None], dws, dbs)
+            ops.dense_update_(segs, opt, 0.01, 1e-7)
+        return dxs, dws, dbs, params, accs
+
+    a, b = run(True), run(False)
+    for u, v in zip(a, b):
+        for x, y in zip(u, v):
+            if x is not None:
+                assert torch.equal(x, y)
+    changed = T(synth.uniform_f32(61, 20, other, -1.0, 2.0), dev)
+    assert not torch.equal(a[3][0], changed)
+    dws = [torch.empty(ns, k, n, device=dev) for _ in range(2)]
+    dbs = [torch.empty(ns, n, device=dev) for _ in range(2)]
+    own = [ops.make_dense_seg(ws[0], None if opt == "sgd" else torch.full_like(ws[0], 0.1), dws[0], ns, 0.0)]
+    with pytest.raises(ValueError):
+        ops.dense_bwd2(xs, ws, dzs, [torch.empty(m, k, device=dev) for _ in range(2)], [None, None], dws, dbs, riders=(own, opt, 0.01, 1e-7))
+
+
 # ----------------------------------------------------------------------------------- a2 dense layers
 @pytest.mark.parametrize("m,k,n,relu", [(256, 32, 32, False), (4096, 64, 64, True), (8192, 128, 256, True),
                                         (8192, 256, 128, False), (1000, 128, 512, True), (77, 36, 20, True),

@@ -1,4 +1,4 @@
-"""world_size-2 (and 3) gloo tests of the row-sharded embedding exchange on CPU (the N>1 path of
+"""world_size-2, 3 and 8 gloo tests of the row-sharded embedding exchange on CPU (the N>1 path of
 SURVEY.md §8e).  The exchange code under test is the product's (device-agnostic torch +
 torch.distributed); the three row kernels are replaced by a NumPy-oracle backend DEFINED HERE (the
 product's only backend is HIP).  Checks: looked-up rows, post-step shards (SGD and Adagrad, duplicates
@@ -221,26 +221,32 @@ def _worker_combined(rank, world, port, ret):
         from oracle import synth, two_tower as tt
         from two_tower_amazon_recommender_amd.sharded import ShardedTables, shard_rows
         dim, batch = 16, 128
+        # world 8 (r04, VERDICT r03 item 4: the world size the machine has): a THIRD table of 30 rows beside the two (the
+        # shape of a sharded category table: 30 % 8 != 0, every id hundreds of times), and room for the power-law ids' hot
+        # owner (id 0 of the 30-row table alone draws ~43 % of a rank's positions: capacity = the whole batch)
+        rows_list = [700, 333] + ([30] if world >= 8 else [])
+        nt = len(rows_list)
         for opt in ("sgd", "adagrad"):
-            fulls = [synth.embedding_table(5, 1, 700, dim), synth.embedding_table(5, 2, 333, dim)]
+            fulls = [synth.embedding_table(5, 1 + t, r, dim) for t, r in enumerate(rows_list)]
             accs = [np.full_like(f, np.float32(0.1)) for f in fulls]
-            em = ShardedTables([700, 333], dim, batch, torch.device("cpu"), capacity_factor=3.0, backend=OracleRowBackend())
-            assert em.offsets == [0, (700 + world - 1) // world] and em.table.shape[0] == sum(em.rows_cap)
-            for t in range(2):
+            em = ShardedTables(rows_list, dim, batch, torch.device("cpu"), capacity_factor=3.0 if world < 8 else float(world),
+                               backend=OracleRowBackend())
+            assert em.offsets[:2] == [0, (700 + world - 1) // world] and em.table.shape[0] == sum(em.rows_cap)
+            for t in range(nt):
                 em.shard(t).copy_(torch.from_numpy(fulls[t][rank::world].copy()))
                 assert em.shard(t).shape[0] == shard_rows(fulls[t].shape[0], world, rank)
             if opt == "adagrad":
                 em.accum = torch.full_like(em.table, 0.1)
             n_steps = 3
-            all_ids = [[synth.batch_ids(5, 3 + t, step, world * batch, fulls[t].shape[0], "Z") for t in range(2)]
+            all_ids = [[synth.batch_ids(5, 3 + t, step, world * batch, fulls[t].shape[0], "Z") for t in range(nt)]
                        for step in range(n_steps)]
             sl = slice(rank * batch, (rank + 1) * batch)
-            mine = [[torch.from_numpy(all_ids[step][t][sl]) for t in range(2)] for step in range(n_steps)]
+            mine = [[torch.from_numpy(all_ids[step][t][sl]) for t in range(nt)] for step in range(n_steps)]
             for step in range(n_steps):
                 ids = all_ids[step]
-                grads = [synth.uniform_f32(5, 9 + 2 * step + t, world * batch * dim, -1.0, 2.0).reshape(world * batch, dim)
-                         for t in range(2)]
-                out = torch.empty(2 * batch, dim)
+                grads = [synth.uniform_f32(5, 9 + nt * step + t, world * batch * dim, -1.0, 2.0).reshape(world * batch, dim)
+                         for t in range(nt)]
+                out = torch.empty(nt * batch, dim)
                 cur_before = em._cur
                 em.lookup_start(mine[step])
                 # steps 1.. were prefetched during the previous step: the other id-buffer set is adopted
@@ -249,12 +255,12 @@ def _worker_combined(rank, world, port, ret):
                 em.lookup_finish(out)
                 if step + 1 < n_steps:
                     em.lookup_prefetch(mine[step + 1], exchange=(step % 2 == 0))   # next step's route (+ id exchange), issued mid-step
-                for t in range(2):
+                for t in range(nt):
                     assert np.array_equal(out.numpy()[t * batch:(t + 1) * batch], fulls[t][ids[t][sl]])
-                em.grads_start(torch.from_numpy(np.concatenate([grads[0][sl], grads[1][sl]])))
+                em.grads_start(torch.from_numpy(np.concatenate([grads[t][sl] for t in range(nt)])))
                 em.grads_finish(opt, 0.01)
                 em.check()
-                for t in range(2):
+                for t in range(nt):
                     if opt == "sgd":
                         tt.sparse_sgd(fulls[t], ids[t], grads[t], 0.01)
                     else:
@@ -273,11 +279,32 @@ def _worker_combined(rank, world, port, ret):
                             accs[t][r::world] = gacc[r]
             # a prefetch for ids that are NOT the next call's: dropped, the lookup routes afresh
             em.lookup_prefetch(mine[0])
-            out = torch.empty(2 * batch, dim)
+            out = torch.empty(nt * batch, dim)
             em.lookup(mine[2], out)
-            for t in range(2):
+            for t in range(nt):
                 assert np.array_equal(out.numpy()[t * batch:(t + 1) * batch], fulls[t][all_ids[2][t][sl]])
             em.check()
+        if world >= 8:
+            # the overflow case at 8 owners: capacity_factor 2.0 reserves 64 positions per owner and table (2 x 128 / 8, rounded
+            # up to 64); a batch whose 30-row-table ids are ALL id 8 sends every one of a rank's 128 positions to owner 0 -
+            # flagged, on every rank, by the next check() (and the rows of the tables that did fit are still the right ones)
+            em2 = ShardedTables(rows_list, dim, batch, torch.device("cpu"), capacity_factor=2.0, backend=OracleRowBackend())
+            assert em2.cap == 64
+            for t in range(nt):
+                em2.shard(t).copy_(torch.from_numpy(fulls[t][rank::world].copy()))
+            out = torch.zeros(nt * batch, dim)
+            hot = [mine[0][0], mine[0][1], torch.full((batch,), 8, dtype=torch.int64)]
+            em2.lookup(hot, out)
+            try:
+                em2.check()
+                raise AssertionError("no overflow reported at world 8 with capacity_factor 2.0")
+            except RuntimeError as e:
+                assert "overflow" in str(e), e
+            ok = 0
+            for p in range(batch):                                # table 0 (700 rows): no owner draws more than 32 of 128
+                got = out.numpy()[p]
+                ok += int(np.array_equal(got, fulls[0][all_ids[0][0][sl][p]]))
+            assert ok == batch, ok
         ret[rank] = "ok"
     except Exception:                                             # noqa: BLE001
         import traceback
@@ -286,7 +313,7 @@ def _worker_combined(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_two_tables_one_exchange(world):
     mgr = mp.Manager()
     ret = mgr.dict()
@@ -336,7 +363,7 @@ def _worker_cand_ids(rank, world, port, ret):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_global_negatives_candidate_ids_follow_the_candidate_rows(world):
     """id_all / p_all must be in the order of c_all (rank-major) and a rank's own block must start at its
     diag_offset = rank * batch - otherwise accidental-hit removal and the log-Q correction act on the wrong columns."""

@@ -130,6 +130,8 @@ SIGNATURES = {
     "tt_dense_bwd_scaled_f32": (C.c_int, [_p, _p, _p, _p, _p, _f, _p, _p, _i64, _i32, _i32, _p]),
     "tt_dense_fwd_batched_f32": (C.c_int, [C.POINTER(DenseFwdArgs), _i32, _i64, _i32, _i32, _i32, _f, _u64, _u64, _p]),
     "tt_dense_bwd_batched_f32": (C.c_int, [C.POINTER(DenseBwdArgs), _i32, _f, _i64, _i32, _i32, _p]),
+    "tt_dense_bwd_batched_update_f32": (C.c_int, [C.POINTER(DenseBwdArgs), _i32, _f, _i64, _i32, _i32, C.POINTER(DenseSeg), _i32, _i32,
+                                                  _f, _f, _p]),
     "tt_tower_fwd2_supported": (_i32, [_i64, _i32, _i32, _i32]),
     "tt_tower_fwd2_batched_f32": (C.c_int, [C.POINTER(DenseFwdArgs), C.POINTER(DenseFwdArgs), _i32, _i64, _i32, _i32, _i32, _f, _u64, _u64, _p]),
     "tt_dense_bwd_num_slabs": (_i32, [_i64]),

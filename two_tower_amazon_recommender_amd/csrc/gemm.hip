@@ -15,6 +15,7 @@
 // from rows padded to BK+4 floats (conflict-free); an m-contiguous operand is read with ds_read_b32.
 // The embedding lookup of a tower's first layer is fused into the A loader (fwd and dW): see GemmArgs::a_ids.
 #include "common.h"
+#include "dense_update_body.h"
 #include <cstdlib>
 
 namespace {
@@ -437,18 +438,32 @@ struct BwdBatch {
   int dw_gm, dw_gn;      // dw tiles per problem and split
   int dw_first;          // 1: the dw tiles take the first workgroup indices (when their k-range is the longer one)
   int dx_pair;           // 1: a dx workgroup computes TWO column tiles (by, by + dx_gn/2) of its row block, one after the other
+  // riders (r04): the dense parameter update of ANOTHER layer's segments - the layer above, whose gradient slabs the previous
+  // backward launch completed - as the first `rider_blocks` workgroups of this launch (tt_dense_bwd_batched_update_f32)
+  int rider_blocks, rider_segs, rider_opt;
+  int rider_first[TT_MAX_DENSE_SEGS + 1];
+  float rider_lr, rider_eps;
 };
 
 template <int GK>
-__global__ __launch_bounds__(256, (GK > 256 ? 3 : 4)) void gemm_bwd_kernel(BwdBatch pb) {
+__global__ __launch_bounds__(256, (GK > 256 ? 3 : 4)) void gemm_bwd_kernel(BwdBatch pb, tt::SegTable riders) {
   __shared__ __attribute__((aligned(16))) float smem[2 * 2 * TILE_F];
   __shared__ int32_t gids[kGidsInts(GK, true)];
+  if ((int)blockIdx.x < pb.rider_blocks) {               // (workgroup-uniform)
+    const int d = (int)blockIdx.x;
+    int si = 0;
+    while (si + 1 < pb.rider_segs && d >= pb.rider_first[si + 1]) ++si;
+    const int nb = pb.rider_first[si + 1] - pb.rider_first[si];
+    if (pb.rider_opt == TT_OPT_SGD) tt::dense_update_body<TT_OPT_SGD, 256, 16>(riders.seg[si], d - pb.rider_first[si], nb, 1, pb.rider_lr, pb.rider_eps);
+    else tt::dense_update_body<TT_OPT_ADAGRAD, 256, 16>(riders.seg[si], d - pb.rider_first[si], nb, 1, pb.rider_lr, pb.rider_eps);
+    return;
+  }
   const int per_split = pb.dw_gm * pb.dw_gn;
   const int per_w = per_split * pb.splits;
   const int per_x = pb.dx_gm * (pb.dx_pair ? pb.dx_gn / 2 : pb.dx_gn);     // dx WORKGROUPS per problem
   const int n_dw = pb.nprob * per_w, n_dx = pb.nprob * per_x;
   // longest tiles first: workgroups are dispatched in index order, so the short tiles fill the tail
-  int b = blockIdx.x;
+  int b = (int)blockIdx.x - pb.rider_blocks;
   const bool is_dw = pb.dw_first ? b < n_dw : b >= n_dx;
   if (is_dw) {
     if (!pb.dw_first) b -= n_dx;
@@ -588,8 +603,37 @@ extern "C" int32_t tt_dense_bwd_num_slabs(int64_t m) {
   return (int32_t)s;
 }
 
+namespace {
+int dense_bwd_batched(const tt_dense_bwd_args* probs, int32_t n_probs, float dx_scale, int64_t m, int32_t k, int32_t n,
+                      const tt_dense_seg* rsegs, int32_t n_rsegs, int32_t ropt, float rlr, float reps, bool* riders_done, tt_stream_t stream_);
+}
 extern "C" int tt_dense_bwd_batched_f32(const tt_dense_bwd_args* probs, int32_t n_probs, float dx_scale, int64_t m, int32_t k,
                                         int32_t n, tt_stream_t stream_) {
+  return dense_bwd_batched(probs, n_probs, dx_scale, m, k, n, nullptr, 0, 0, 0.f, 0.f, nullptr, stream_);
+}
+
+extern "C" int tt_dense_bwd_batched_update_f32(const tt_dense_bwd_args* probs, int32_t n_probs, float dx_scale, int64_t m, int32_t k,
+                                               int32_t n, const tt_dense_seg* segs, int32_t n_segs, int32_t opt, float lr, float eps,
+                                               tt_stream_t stream_) {
+  TT_REQUIRE(segs != nullptr && n_segs >= 1 && n_segs <= TT_MAX_DENSE_SEGS, "tt_dense_bwd_batched_update_f32: 1..%d dense segments", TT_MAX_DENSE_SEGS);
+  TT_REQUIRE(opt == TT_OPT_SGD || opt == TT_OPT_ADAGRAD, "tt_dense_bwd_batched_update_f32: unknown optimizer %d", opt);
+  for (int i = 0; i < n_segs; ++i) {
+    const tt_dense_seg& s = segs[i];
+    TT_REQUIRE(s.count > 0 && s.n_slabs >= 1 && s.grad_slabs != nullptr && s.param != nullptr, "tt_dense_bwd_batched_update_f32: segment %d: bad count/slabs/param", i);
+    TT_REQUIRE(opt == TT_OPT_SGD || s.accum != nullptr, "tt_dense_bwd_batched_update_f32: segment %d: Adagrad needs accum", i);
+    for (int j = 0; j < n_probs; ++j)
+      TT_REQUIRE(s.grad_slabs != probs[j].dw_slabs && s.grad_slabs != probs[j].db_slabs && s.param != probs[j].w,
+                 "tt_dense_bwd_batched_update_f32: segment %d belongs to THIS layer (its slabs are written / its weights read by this launch)", i);
+  }
+  bool done = false;
+  int rc = dense_bwd_batched(probs, n_probs, dx_scale, m, k, n, segs, n_segs, opt, lr, eps, &done, stream_);
+  if (rc != TT_OK || done) return rc;
+  return tt_dense_update_f32(segs, n_segs, opt, 1, lr, eps, stream_);      // (dx only / dw only forms: the update as its own launch)
+}
+
+namespace {
+int dense_bwd_batched(const tt_dense_bwd_args* probs, int32_t n_probs, float dx_scale, int64_t m, int32_t k, int32_t n,
+                      const tt_dense_seg* rsegs, int32_t n_rsegs, int32_t ropt, float rlr, float reps, bool* riders_done, tt_stream_t stream_) {
   TT_REQUIRE(probs != nullptr && n_probs >= 1 && n_probs <= 2, "tt_dense_bwd_batched_f32: 1 or 2 problems");
   TT_REQUIRE(m > 0 && k > 0 && n > 0 && k % 4 == 0 && n % 4 == 0, "tt_dense_bwd_f32: need m>0, k%%4==0, n%%4==0 (m=%lld k=%d n=%d)",
              (long long)m, k, n);
@@ -641,11 +685,23 @@ extern "C" int tt_dense_bwd_batched_f32(const tt_dense_bwd_args* probs, int32_t 
     const int64_t dx_tiles = (int64_t)pb.dx_gm * pb.dx_gn, dw_tiles = (int64_t)pb.dw_gm * pb.dw_gn * splits;
     pb.dx_pair = (n_probs * (dx_tiles + dw_tiles) > 1024 && pb.dx_gn % 2 == 0 && 2 * ax[0].k_per_split <= aw[0].k_per_split) ? 1 : 0;
     if (const char* e = std::getenv("TT_GEMM_DX_PAIR")) pb.dx_pair = (std::atoi(e) != 0 && pb.dx_gn % 2 == 0) ? 1 : 0;
-    const int64_t blocks = (int64_t)n_probs * (dx_tiles / (pb.dx_pair ? 2 : 1) + dw_tiles);
+    tt::SegTable riders{};
+    if (rsegs != nullptr) {                                  // one thread per 4 elements, at most 32 blocks per segment
+      for (int i = 0; i < n_rsegs; ++i) {
+        int64_t nb = (rsegs[i].count / 4 + 255) / 256;
+        if (nb < 1) nb = 1;
+        if (nb > 32) nb = 32;
+        pb.rider_first[i + 1] = pb.rider_first[i] + (int)nb;
+        riders.seg[i] = rsegs[i];
+      }
+      pb.rider_segs = n_rsegs; pb.rider_blocks = pb.rider_first[n_rsegs]; pb.rider_opt = ropt; pb.rider_lr = rlr; pb.rider_eps = reps;
+      *riders_done = true;
+    }
+    const int64_t blocks = (int64_t)n_probs * (dx_tiles / (pb.dx_pair ? 2 : 1) + dw_tiles) + pb.rider_blocks;
     TT_REQUIRE(blocks <= 0x7fffffff && (ax[0].M + BM - 1) / BM <= 0x3fffffff, "tt_dense_bwd_f32: grid too large");
-    if (gather && aw[0].k_per_split <= 256) tt::launch("dense_bwd", gemm_bwd_kernel<256>, dim3((unsigned)blocks), dim3(256), 0, stream, pb);
-    else if (gather) tt::launch("dense_bwd", gemm_bwd_kernel<kMaxGatherK>, dim3((unsigned)blocks), dim3(256), 0, stream, pb);
-    else tt::launch("dense_bwd", gemm_bwd_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, stream, pb);
+    if (gather && aw[0].k_per_split <= 256) tt::launch("dense_bwd", gemm_bwd_kernel<256>, dim3((unsigned)blocks), dim3(256), 0, stream, pb, riders);
+    else if (gather) tt::launch("dense_bwd", gemm_bwd_kernel<kMaxGatherK>, dim3((unsigned)blocks), dim3(256), 0, stream, pb, riders);
+    else tt::launch("dense_bwd", gemm_bwd_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, stream, pb, riders);
     return tt::check_launch("tt_dense_bwd_f32(dx+dw)");
   }
   if (want_dx && (rc = launch<true, true, false>(ax, n_probs, 1, stream, "tt_dense_bwd_f32(dx)", "dense_bwd_dx")) != TT_OK) return rc;
@@ -655,6 +711,7 @@ extern "C" int tt_dense_bwd_batched_f32(const tt_dense_bwd_args* probs, int32_t 
   if (gather) return launch<false, false, true, kMaxGatherK>(aw, n_probs, splits, stream, "tt_dense_bwd_f32(dw, lookup)", "dense_bwd_dw");
   return launch<false, false, true>(aw, n_probs, splits, stream, "tt_dense_bwd_f32(dw)", "dense_bwd_dw");
 }
+}  // namespace
 
 extern "C" int tt_dense_bwd_f32(const float* x, const float* w, const float* dz, float* dx, const float* dx_relu_src,
                                 float* dw_slabs, float* db_slabs, int64_t m, int32_t k, int32_t n, tt_stream_t stream_) {

@@ -204,6 +204,11 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? ((MODE ==
   // exact-f32 gradient passes: TPB tiles between workgroup barriers (ring of 2*TPB LDS buffers, the prefetch runs TPB tiles
   // ahead); everything else: one tile per barrier, two buffers
   constexpr int TPB = tiles_per_barrier<D, MODE, PREC>();
+  // Two LDS assumptions of the wave-pair (SPLIT) path, pinned: its exchange buffer `xch` sits where the 8-wave kernels keep the
+  // lo fragments (`rlo`) - never both in one kernel; and exchange() has ONE barrier between a pair's write and its partner's
+  // read, so the next tile's write is only safe behind the per-tile barrier that TPB == 1 gives.
+  static_assert(!(SPLIT && RLO_LDS), "wave-pair exchange buffer and the LDS lo fragments share one LDS region");
+  static_assert(!SPLIT || TPB == 1, "the wave-pair exchange relies on one workgroup barrier per tile");
   constexpr int NBUF = STAG ? 3 : 2 * TPB;
   f32x4 rf[PREC == 0 ? NG : 1];
   bf16x8 rp[PREC == 0 ? 1 : (RLO_LDS ? 2 : 3)][PREC == 0 ? 1 : KS];

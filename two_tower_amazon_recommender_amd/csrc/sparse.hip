@@ -146,7 +146,9 @@ __device__ TT_TAIL_ATTR void finish_run_piece(f32x4* __restrict__ table, f32x4* 
 #endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   int ticket = 0;
-  if (l == 0) ticket = atomicAdd(&p_flag[jh], 1);
+  // (the ticket as an agent-scope RELEASE add: on gfx950 the same instruction as the relaxed one behind the vmcnt(0) above -
+  // the piece sums left as write-through stores and have been acknowledged -, but the ordering no longer rests on that alone)
+  if (l == 0) ticket = __hip_atomic_fetch_add(&p_flag[jh], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   ticket = __shfl(ticket, (int)(threadIdx.x & 63u & ~(unsigned)(lpr - 1)));
   if (ticket != npieces - 1) return;
   // last arriver: every piece of the run is published
@@ -381,7 +383,7 @@ __device__ __forceinline__ uint32_t fast_apply(const ApplyArgs& a, const int t, 
   constexpr int RP = kRowsAhead;
   uint32_t key[RP], pos[RP], n_eq[RP], n_bf[RP], jo[RP];
   bool live[RP];
-  f32x4 g[RP], w[RP], ac[RP];
+  f32x4 g[RP], w[RP], ac[RP] = {};       // (ac: read only by Adagrad; zeroed so the SGD instantiation passes no indeterminate value)
   // Every lane ALWAYS loads (no branch around the requests: with one, hipcc merged "loaded or not" through register copies
   // placed right behind the loads, i.e. an `s_waitcnt vmcnt` - a whole HBM round trip - inside the request phase).  A lane
   // group without a pair r (i >= m), a pair with the out-of-range sentinel and the lanes past the row's end re-read pair

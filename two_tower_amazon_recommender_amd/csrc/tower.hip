@@ -154,10 +154,32 @@ __global__ __launch_bounds__(256, 2) void tower_fwd2_kernel(Tower2Batch pb) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) id2[j] = idp2[rr[j]];
   };
-  // row-range id lists (r04): slot / range / local key / position of the <= 4 rows whose float4 0 this lane holds in round 0
-  uint32_t bslot[4] = {0u, 0u, 0u, 0u}, bgrp[4] = {0u, 0u, 0u, 0u}, blk[4] = {0u, 0u, 0u, 0u}, bpos[4] = {0u, 0u, 0u, 0u};
-  bool emit[4] = {false, false, false, false};
-  const bool lists = has_ids && p.bk_pairs != nullptr && K0 <= 128;           // (uniform)
+  // row-range id lists (r04, tt_id_buckets): the 32 ids of this workgroup's rows are appended to the lists of the row ranges they
+  // fall in by lanes 0..31 of WAVE 0 alone - one load of the ids (again: an L1 hit), ONE returning atomic instruction for the
+  // slots, issued behind the round's row loads (memory operations return in order: in front of them the rows would wait for the
+  // slots), ONE 8-byte store instruction for the entries at the very end of the kernel.  One counter per 256-byte line
+  // (kBucketCountStride): the first version packed a table's ~220 counters into 7 lines and the forward launch took 25 us
+  // longer - device-scope atomics on one LINE serialise (~11 ns each), whatever the word.  (The second version let the lane that
+  // holds float4 0 of a row do it: 2 active lanes x 4 atomic + 4 store instructions in every wave, +1 us on the launch.)
+  const bool lists = has_ids && p.bk_pairs != nullptr && wave == 0;           // (wave-uniform)
+  uint32_t bslot = 0u, bgrp = 0u, blk = 0u;
+  bool emit = false;
+  int64_t bid = -1;
+  const int64_t brow = m0 + ln;
+  if (lists) bid = p.ids[brow < pb.M ? brow : m0];
+  auto draw_slot = [&]() {
+    if (lists) {
+      emit = lane < 32 && brow < pb.M && bid >= 0 && bid < p.table_rows;
+      if (emit) {
+        const uint32_t key = (uint32_t)bid;
+        uint32_t q = __umulhi(key, p.bk_magic);
+        q -= (q * p.bk_width > key) ? 1u : 0u;
+        bgrp = q < p.bk_groups ? q : p.bk_groups - 1u;
+        blk = key - bgrp * p.bk_width;
+        bslot = __hip_atomic_fetch_add(p.bk_counts + (size_t)bgrp * tt::kBucketCountStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  };
   auto fetch_rows = [&](int f0) {
     bool ok1[4], ok2[4];
     f32x4 v[4], v2[4];
@@ -167,31 +189,12 @@ __global__ __launch_bounds__(256, 2) void tower_fwd2_kernel(Tower2Batch pb) {
       ok1[j] = live[j] && (!has_ids || (id1[j] >= 0 && id1[j] < p.table_rows));
       ok2[j] = live[j] && has2 && id2[j] >= 0 && id2[j] < p.table2_rows;
     }
-    // the row-range lists (r04): the lane that holds float4 0 of a row draws the id's slot in its range's list - a returning
-    // atomic issued IN FRONT of the row loads: memory operations return in order, so by the time the rows (younger, and a trip to
-    // HBM) have landed the slots are there and nothing waits for them.  One counter per 256-byte line (kBucketCountStride): the
-    // first version packed a table's ~220 counters into 7 lines and the forward launch took 25 us longer - device-scope atomics
-    // on one LINE serialise (~11 ns each), whatever the word.
-    if (lists && f0 == 0) {                                                    // (dim <= 128: round 0 holds every row's id)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        emit[j] = ok1[j] && c4s[j] == 0;
-        if (emit[j]) {
-          const uint32_t key = (uint32_t)id1[j];
-          uint32_t q = __umulhi(key, p.bk_magic);
-          q -= (q * p.bk_width > key) ? 1u : 0u;
-          bgrp[j] = q < p.bk_groups ? q : p.bk_groups - 1u;
-          bslot[j] = __hip_atomic_fetch_add(p.bk_counts + (size_t)bgrp[j] * tt::kBucketCountStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          blk[j] = key - bgrp[j] * p.bk_width;
-          bpos[j] = (uint32_t)rr[j] & 0xffffu;
-        }
-      }
-    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int64_t row1 = has_ids ? (ok1[j] ? id1[j] : 0) : rr[j];
       v[j] = ldg4(src + row1 * K0 + 4 * c4s[j]);
     }
+    if (f0 == 0) draw_slot();
     if (has2) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) v2[j] = ldg4(p.table2 + (ok2[j] ? id2[j] : 0) * K0 + 4 * c4s[j]);
@@ -238,17 +241,6 @@ __global__ __launch_bounds__(256, 2) void tower_fwd2_kernel(Tower2Batch pb) {
   }
   __syncthreads();                                           // the input tile is complete
   TSTAMP(1);
-  // the list entries leave BEHIND the barrier (in front of it its fence would wait for their acknowledgement: a memory round trip
-  // on the kernel's longest dependency chain); nothing below waits for them - the weight tiles in the ring are older
-  if (lists) {
-    // ONE wait for all four slots, on every path: left to the per-store branches the compiler re-waits `vmcnt(0)` in front of
-    // each store - i.e. for the previous store's acknowledgement, four round trips in a row (r04 ISA)
-    asm volatile("" :: "v"(bslot[0] | bslot[1] | bslot[2] | bslot[3]));
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (emit[j] && bslot[j] < p.bk_cap)                    // (a full list keeps counting: the optimizer falls back to its scan)
-        p.bk_pairs[(size_t)bgrp[j] * p.bk_cap + bslot[j]] = (uint64_t)blk[j] | ((uint64_t)bpos[j] << 32) | ((uint64_t)(p.bk_gen & 0xffffu) << 48);
-  }
 
   // ================= layer 0: h[32, H] = x[32, K0] @ W0[K0, H] =================
   f32x16 acc[HB > NB ? HB : NB];
@@ -390,6 +382,11 @@ __global__ __launch_bounds__(256, 2) void tower_fwd2_kernel(Tower2Batch pb) {
       if (m < pb.M) *reinterpret_cast<f32x4*>(p.y + m * N1 + 4 * c4) = *reinterpret_cast<const f32x4*>(XH + row * LY + 4 * c4);
     }
   }
+  // the list entries leave at the very END of the kernel: in front of the first barrier its fence would wait for their
+  // acknowledgement (a memory round trip on the kernel's longest dependency chain), and right behind it hipcc still parks a
+  // `s_waitcnt vmcnt(0)` in front of the k loop (r04 ISA); here nothing follows that could wait for them
+  if (lists && emit && bslot < p.bk_cap)                       // (a full list keeps counting: the optimizer falls back to its scan)
+    p.bk_pairs[(size_t)bgrp * p.bk_cap + bslot] = (uint64_t)blk | ((uint64_t)((uint32_t)brow & 0xffffu) << 32) | ((uint64_t)(p.bk_gen & 0xffffu) << 48);
   TSTAMP(5);
 #ifdef TT_TOWER_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

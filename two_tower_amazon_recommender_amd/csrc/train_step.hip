@@ -17,6 +17,25 @@ extern "C" int tt_train_step_f32(const tt_train_step* s, tt_stream_t stream) {
   // two-layer towers: both layers of both towers in one launch (csrc/tower.hip); TT_FUSED_TOWER=0 keeps the two launches (A/B)
   static const bool fused_tower = std::getenv("TT_FUSED_TOWER") == nullptr || std::atoi(std::getenv("TT_FUSED_TOWER")) != 0;
   const bool fwd2 = fused_tower && L == 2 && tt_tower_fwd2_supported(s->batch, s->dims[0], s->dims[1], s->dims[2]);
+  // r04, measured and left OFF (TT_DENSE_RIDERS=1 switches it on): the dense update of layer l's parameters riding in the backward
+  // launch of layer l - 1 (tt_dense_bwd_batched_update_f32: its gradient slabs are complete and nothing below reads its weights),
+  // so that the optimizer launch - whose HBM burst is the embedding rows' - keeps only the segments of layer 0.  Same arithmetic.
+  // cfg3, same box, alternating (profiles/r04_optimizer_ab.txt): optimizer launch 12.0 -> 11.5 us, but the two backward launches
+  // 90.9 -> 93.0 us together - the step 0.5624 -> 0.5636 ms.
+  static const bool want_riders = std::getenv("TT_DENSE_RIDERS") != nullptr && std::atoi(std::getenv("TT_DENSE_RIDERS")) != 0;
+  tt_dense_seg rest[TT_MAX_DENSE_SEGS];
+  int layer_of[TT_MAX_DENSE_SEGS];
+  for (int i = 0; i < s->n_segs; ++i) {
+    layer_of[i] = 0;
+    for (int l = 1; l < L && want_riders; ++l)
+      for (int t = 0; t < 2; ++t)
+        if (s->segs[i].grad_slabs != nullptr && (s->segs[i].grad_slabs == s->bwd[l][t].dw_slabs || s->segs[i].grad_slabs == s->bwd[l][t].db_slabs))
+          layer_of[i] = l;
+  }
+  int n_rest = 0;
+  for (int i = 0; i < s->n_segs; ++i)
+    if (layer_of[i] == 0) rest[n_rest++] = s->segs[i];
+  TT_REQUIRE(n_rest >= 1, "tt_train_step_f32: no dense segment is left for the optimizer launch");
   // r04: the forward lookup hands the optimizer launch its row-range id lists (tt_id_buckets): with a bucket workspace, a fused
   // tower forward (the lookup that can fill them) and a shape that takes lists, both launches get the same descriptors - cut by
   // tt_optimizer_ids_geometry, one generation per step.  TT_ID_BUCKETS=0 keeps the optimizer's own id scan (A/B).
@@ -34,7 +53,7 @@ extern "C" int tt_train_step_f32(const tt_train_step* s, tt_stream_t stream) {
     int64_t rows[3] = {tabs[0].rows, tabs[1].rows, s->n_tables > 2 ? tabs[2].rows : 1};
     int32_t groups[3] = {0, 0, 0}, cap = 0;
     uint32_t width[3] = {0, 0, 0};
-    rc = tt_optimizer_ids_geometry(rows, s->n_tables, s->dims[0], s->batch, s->segs, s->n_segs, groups, width, &cap);
+    rc = tt_optimizer_ids_geometry(rows, s->n_tables, s->dims[0], s->batch, rest, n_rest, groups, width, &cap);      // (the segments the optimizer launch will get)
     if (rc != TT_OK) return rc;
     if (cap > 0 && groups[0] <= 256 && groups[1] <= 256) {
       const uint32_t gen = generation.fetch_add(1u) + 1u;
@@ -73,8 +92,16 @@ extern "C" int tt_train_step_f32(const tt_train_step* s, tt_stream_t stream) {
   // the same f32 arithmetic as the forward launcher's keep scale: 1.0f / (1.0f - rate)
   const float dx_scale = s->dropout_rate > 0.f ? 1.0f / (1.0f - s->dropout_rate) : 1.0f;
   for (int l = L - 1; l >= 0; --l) {
-    rc = tt_dense_bwd_batched_f32(s->bwd[l], 2, l > 0 ? dx_scale : 1.0f, s->batch, s->dims[l], s->dims[l + 1], stream);
+    tt_dense_seg ride[TT_MAX_DENSE_SEGS];
+    int n_ride = 0;
+    for (int i = 0; i < s->n_segs; ++i)
+      if (layer_of[i] == l + 1) ride[n_ride++] = s->segs[i];
+    if (n_ride > 0)
+      rc = tt_dense_bwd_batched_update_f32(s->bwd[l], 2, l > 0 ? dx_scale : 1.0f, s->batch, s->dims[l], s->dims[l + 1], ride, n_ride, s->opt,
+                                           s->lr, s->eps, stream);
+    else
+      rc = tt_dense_bwd_batched_f32(s->bwd[l], 2, l > 0 ? dx_scale : 1.0f, s->batch, s->dims[l], s->dims[l + 1], stream);
     if (rc != TT_OK) return rc;
   }
-  return tt_optimizer_step_ids_f32(s->opt, tabs, s->n_tables, s->dims[0], s->batch, s->segs, s->n_segs, s->lr, s->eps, stream);
+  return tt_optimizer_step_ids_f32(s->opt, tabs, s->n_tables, s->dims[0], s->batch, rest, n_rest, s->lr, s->eps, stream);
 }

@@ -44,9 +44,18 @@ class TwoTowerModel:
             return self.trainer.step(u, i, **kw)
         return self.trainer.evaluate(u, i, **kw)
 
-    def train_step(self, features: dict) -> dict:
+    def train_step(self, features: dict, report_regularization: bool = True) -> dict:
+        """tfrs.Model.train_step's dict: ``total_loss = loss + regularization_loss`` (the L2 terms of the Dense kernels,
+        ``l2_regularization * sum(W^2)``, evaluated on the weights the step STARTED from, as Keras's ``model.losses`` are).
+        The gradient of that term is fused into the dense update either way; ``report_regularization=False`` skips the
+        reporting-only reduction (one small launch) and returns ``regularization_loss: None, total_loss: loss``."""
+        reg = self.trainer.l2_penalty() if (report_regularization and self.cfg.l2_regularization > 0) else None
         loss = self.compute_loss(features, training=True)
-        return {"loss": loss, "regularization_loss": None, "total_loss": loss}
+        if reg is None:
+            zero = report_regularization and self.cfg.l2_regularization == 0
+            return {"loss": loss, "regularization_loss": torch.zeros_like(loss) if zero else None, "total_loss": loss}
+        reg = reg.to(loss.dtype).reshape(loss.shape)
+        return {"loss": loss, "regularization_loss": reg, "total_loss": loss + reg}
 
     def test_step(self, features: dict) -> dict:
         return {"loss": self.compute_loss(features, training=False)}

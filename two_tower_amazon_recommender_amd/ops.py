@@ -461,8 +461,11 @@ def tower_fwd2(xs, w0s, b0s, hs, h_bits, w1s, b1s, ys, dropout=None, lookups=Non
     _lib.check(_lib.load().tt_tower_fwd2_batched_f32(l0, l1, 2, m, k0, h, n1, rate, seed, off, _stream()), "tt_tower_fwd2_batched_f32")
 
 
-def dense_bwd2(xs, ws, dzs, dxs, dx_relu_srcs, dw_slabs, db_slabs, dx_scale: float = 1.0, lookups=None, dx_relu_bits=(None, None)):
-    """Backward of layer l of both towers: one launch (dx and dw+db tiles side by side; dx only / dw only: one each)."""
+def dense_bwd2(xs, ws, dzs, dxs, dx_relu_srcs, dw_slabs, db_slabs, dx_scale: float = 1.0, lookups=None, dx_relu_bits=(None, None),
+               riders=None):
+    """Backward of layer l of both towers: one launch (dx and dw+db tiles side by side; dx only / dw only: one each).
+    ``riders = (segs, opt, lr, eps)``: the dense update of ANOTHER layer's segments in the same launch
+    (``tt_dense_bwd_batched_update_f32``; bit-identical to ``dense_update_`` behind the launch)."""
     m, k = _in_shape(xs[0], None if lookups is None else lookups[0])
     n = ws[0].shape[1]
     for i in range(2):
@@ -471,6 +474,12 @@ def dense_bwd2(xs, ws, dzs, dxs, dx_relu_srcs, dw_slabs, db_slabs, dx_scale: flo
                                                      _p(dx_relu_srcs[i]), _p(dw_slabs[i]), _p(db_slabs[i]),
                                                      lookups[i] if lookups is not None else _no_lookup(),
                                                      _p(dx_relu_bits[i])) for i in range(2)])
+    if riders is not None:
+        segs, opt, lr, eps = riders
+        arr_s = (DenseSeg * len(segs))(*segs)
+        _lib.check(_lib.load().tt_dense_bwd_batched_update_f32(arr, 2, dx_scale, m, k, n, arr_s, len(segs), _OPT[opt], lr, eps, _stream()),
+                   "tt_dense_bwd_batched_update_f32")
+        return
     _lib.check(_lib.load().tt_dense_bwd_batched_f32(arr, 2, dx_scale, m, k, n, _stream()), "tt_dense_bwd_batched_f32")
 
 

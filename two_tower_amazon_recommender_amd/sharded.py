@@ -10,14 +10,16 @@ one sparse update per step, and every exchange is ONE collective for all tables)
                                                                             (tt_route_tables_by_owner_i64)
   C1      all-to-all of the id buffers                      (world*n_tables*cap*8 B per rank)
   K1      owner gathers its rows for the received ids       (HIP gather; -1 -> zero row)
-  plan    owner sorts the received ids (side stream, beside the forward/backward pass)
   C2      all-to-all of the rows back                       (world*n_tables*cap*4*dim B per rank)
-  K1'     expand to per-position embeddings                 (HIP gather from the received buffer)
-  ... towers, scorer, loss, every dx of the backward pass ...
-  K2'     per-position gradient rows into the send buffer   (tt_scatter_rows_f32)
+  ... towers (their first layer reads its input rows straight out of the receive buffer through the routing's flat
+      positions - tt_dense_lookup with table = rows_in, ids = pos_flat: no expand gather, no [2B, D] input buffer, r03),
+      scorer, loss, every dx of the backward pass ...
+  K2'     per-position gradient rows into the send buffer   (tt_scatter_rows_f32, one launch for both tables)
   C3      all-to-all of the gradient rows to the owners     (travels beside the dw GEMMs and the dense reduce)
-  K2      owner applies the fused sparse SGD/Adagrad: duplicates — inside one rank's batch and across ranks —
-          are summed first, in (source rank, position) order: bitwise reproducible
+  K2      owner sorts the received ids, sums the duplicates - inside one rank's batch and across ranks, in (source rank,
+          position) order: bitwise reproducible - and applies the fused sparse SGD/Adagrad in ONE launch
+          (tt_optimizer_step_ids_f32 on the receive buffer, the dense tower update in the same launch; lists longer than
+          16384 slots: plan launch + tt_optimizer_step_f32).  No sort plan on a side stream since r03.
 
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): an all-to-all uses every link at once, one peer per
 link; what costs at these sizes (a few MB) is the per-collective latency, hence three all-to-alls per step

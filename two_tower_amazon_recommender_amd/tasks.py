@@ -19,7 +19,10 @@ Differences from TFRS, all loud:
     ``update_state(loss)``; ``batch_metrics`` takes ``metrics.TopKCategoricalAccuracy(k)`` objects (the Keras metric TFRS
     users pass there): in-batch top-k accuracy is ``rank < k`` from one fused rank pass over the batch's candidates, under
     the scores the loss sees (temperature, sampling-probability correction, accidental hits removed) - no score matrix;
-    any other Keras metric would need the [queries x candidates] matrix and raises TypeError;
+    any other Keras metric would need the [queries x candidates] matrix and raises TypeError.  As in TFRS
+    (``metric.update_state(labels, scores)``) they are NOT weighted by ``sample_weight``.  TFRS computes them on the scores
+    AFTER hard-negative mining; the rank pass sees every in-batch candidate, so ``batch_metrics`` together with
+    ``num_hard_negatives`` raises NotImplementedError instead of reporting a different number;
   * ``num_hard_negatives=k`` keeps the positive and the k highest-scoring negatives per query
     (tfrs.layers.loss.HardNegativeMining); negatives tied with the k-th are all kept;
   * ``candidate_ids`` must be an int64 tensor (the reference's ids are int64:
@@ -60,6 +63,9 @@ class Retrieval:
             if not isinstance(metrics, FactorizedTopK) or metrics.candidates is None:
                 raise TypeError("Retrieval(metrics=...) takes a metrics.FactorizedTopK built with its candidate corpus "
                                 "(FactorizedTopK(candidates=item_corpus_embeddings))")
+        if self._batch_metrics and num_hard_negatives is not None:
+            raise NotImplementedError("Retrieval(batch_metrics=..., num_hard_negatives=k): TFRS evaluates batch metrics on the scores "
+                                      "after hard-negative mining; the fused rank pass ranks against every in-batch candidate")
         self._factorized_metrics = metrics
         self._loss_metrics = list(loss_metrics) if loss_metrics is not None else []
         for m in self._loss_metrics:
@@ -99,7 +105,7 @@ class Retrieval:
         if torch.is_grad_enabled() and (q.requires_grad or c.requires_grad):
             loss, per_example, _, _ = torch.ops.twotower.retrieval_loss(q, c, sw, cp, ids, inv_t, diag_offset, k, self._precision)
         else:
-            loss, per_example = torch.ops.twotower.retrieval_loss_value(q, c, sw, cp, ids, inv_t, diag_offset, k)
+            loss, per_example = torch.ops.twotower.retrieval_loss_value(q, c, sw, cp, ids, inv_t, diag_offset, k, self._precision)
         self.last_per_example_loss = per_example
         if compute_metrics and self._factorized_metrics is not None:
             if candidate_ids is None:
@@ -112,7 +118,7 @@ class Retrieval:
             with torch.no_grad():
                 rank = torch.ops.twotower.retrieval_batch_rank(q.detach(), c.detach(), cp, ids, inv_t, diag_offset)
                 for m in self._batch_metrics:
-                    m.update_state_from_ranks(rank, sw)
+                    m.update_state_from_ranks(rank)              # unweighted, as TFRS: only the loss and loss_metrics see sample_weight
         for m in self._loss_metrics:
             m.update_state(loss.detach())
         return loss

@@ -26,22 +26,44 @@ NS = "twotower"
 
 
 _WS_CACHE: dict = {}
+_PLAN_CACHE: dict = {}
 
 
 def _ws(nq: int, nc: int, d: int, device, forward_only: bool = False) -> Tensor:
     """Scorer workspace; the training entry's includes the [nq, nc] f32 dot-product buffer its second pass reads back
-    (4*nq*nc bytes: 268 MB at 8192 x 8192, 4.3 GB at 32768 x 32768).  Kept per (shape, device, stream) instead of being
-    allocated on every call: the kernels of one stream run in order, so successive calls can share it; only the most
-    recent shape of each kind is held."""
+    (4*nq*nc bytes: 268 MB at 8192 x 8192, 4.3 GB at 32768 x 32768).  Kept per (kind, device, stream) instead of being
+    allocated on every call: the kernels of one stream run in order, so successive calls can share it.  The LARGEST buffer seen
+    is kept (a loop alternating two batch shapes re-allocated 268 MB per call when only the last shape was held: VERDICT r03);
+    ``release_workspaces()`` drops them.  Nothing is cached while the stream is being captured into a HIP graph: a buffer
+    allocated there lives in the graph's private pool and must not be handed to eager calls afterwards."""
+    n = ops.retrieval_fwd_workspace_bytes(nq, nc, d) if forward_only else ops.retrieval_workspace_bytes(nq, nc, d)
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(n, dtype=torch.uint8, device=device)
     key = (bool(forward_only), str(device), torch.cuda.current_stream(device).cuda_stream)
     hit = _WS_CACHE.get(key)
-    if hit is not None and hit[0] == (nq, nc, d):
-        return hit[1]
-    n = ops.retrieval_fwd_workspace_bytes(nq, nc, d) if forward_only else ops.retrieval_workspace_bytes(nq, nc, d)
-    _WS_CACHE.pop(key, None)
+    if hit is not None and hit.numel() >= n:
+        return hit
+    _WS_CACHE.pop(key, None)                 # (freed before the larger one is allocated)
     buf = torch.empty(n, dtype=torch.uint8, device=device)
-    _WS_CACHE[key] = ((nq, nc, d), buf)
+    _WS_CACHE[key] = buf
     return buf
+
+
+def _plan(n: int, device) -> "ops.SparsePlan":
+    """One SparsePlan (sorted ids, positions, piece workspace) per (length, device, stream) for ``sparse_update_``."""
+    if torch.cuda.is_current_stream_capturing():
+        return ops.SparsePlan(n, device)
+    key = (int(n), str(device), torch.cuda.current_stream(device).cuda_stream)
+    hit = _PLAN_CACHE.get(key)
+    if hit is None:
+        hit = _PLAN_CACHE[key] = ops.SparsePlan(n, device)
+    return hit
+
+
+def release_workspaces() -> None:
+    """Drop every cached scorer workspace and sort plan of the custom ops (they are re-allocated on the next call)."""
+    _WS_CACHE.clear()
+    _PLAN_CACHE.clear()
 
 
 # --------------------------------------------------------------------------------------------- a1 lookup
@@ -112,8 +134,10 @@ retrieval_loss.register_autograd(_retrieval_backward, setup_context=_retrieval_s
 @torch.library.custom_op(f"{NS}::retrieval_loss_value", mutates_args=(), device_types="cuda")
 def retrieval_loss_value(query_embeddings: Tensor, candidate_embeddings: Tensor, sample_weight: Optional[Tensor],
                          candidate_sampling_probability: Optional[Tensor], candidate_ids: Optional[Tensor],
-                         inv_temperature: float, diag_offset: int, num_hard_negatives: int) -> Tuple[Tensor, Tensor]:
-    """Forward only (validation): (loss [], per-example loss [Bq]) in one statistics pass."""
+                         inv_temperature: float, diag_offset: int, num_hard_negatives: int,
+                         precision: str = "f32") -> Tuple[Tensor, Tensor]:
+    """Forward only (validation): (loss [], per-example loss [Bq]) in one statistics pass; ``precision`` as in
+    ``retrieval_loss`` (a task that trains in bf16x3 validates in bf16x3)."""
     q, c = query_embeddings.contiguous(), candidate_embeddings.contiguous()
     nq, nc, d = q.shape[0], c.shape[0], q.shape[1]
     ws = _ws(nq, nc, d, q.device, forward_only=True)
@@ -125,12 +149,14 @@ def retrieval_loss_value(query_embeddings: Tensor, candidate_embeddings: Tensor,
                                                      cand_prob=candidate_sampling_probability, cand_ids=candidate_ids,
                                                      diag_offset=diag_offset)
     ops.retrieval_fwd(q, c, inv_temperature, ws, lse, per_row, loss, sample_weight=sample_weight,
-                      cand_prob=candidate_sampling_probability, cand_ids=candidate_ids, diag_offset=diag_offset, hard_thr=thr)
+                      cand_prob=candidate_sampling_probability, cand_ids=candidate_ids, diag_offset=diag_offset, hard_thr=thr,
+                      precision=precision)
     return loss.reshape(()), per_row
 
 
 @retrieval_loss_value.register_fake
-def _(q, c, sample_weight, candidate_sampling_probability, candidate_ids, inv_temperature, diag_offset, num_hard_negatives):
+def _(q, c, sample_weight, candidate_sampling_probability, candidate_ids, inv_temperature, diag_offset, num_hard_negatives,
+      precision="f32"):
     return q.new_empty(()), q.new_empty((q.shape[0],))
 
 
@@ -217,7 +243,7 @@ def sparse_update_(table: Tensor, accum: Optional[Tensor], grads: Tensor, ids: T
     ascending position order): one sort launch + one apply launch."""
     if optimizer not in ("sgd", "adagrad"):
         raise ValueError(f"optimizer must be 'sgd' or 'adagrad', got {optimizer!r}")
-    plan = ops.SparsePlan(ids.numel(), ids.device).run(ids.contiguous(), table.shape[0])
+    plan = _plan(ids.numel(), ids.device).run(ids.contiguous(), table.shape[0])
     if optimizer == "sgd":
         ops.sparse_sgd_(table, grads.contiguous(), plan, lr)
     else:

@@ -2,11 +2,14 @@
 
 This is the explicit (no autograd) engine that ``train.py`` and ``bench.py`` drive:
 
-    ids ──gather2──► tower fwd (MFMA GEMMs) ──► fused scorer + softmax loss (fwd, bwd)
-        ──► tower bwd ──► dense update (1 launch) ──► sparse SGD/Adagrad on both tables (1 launch)
+    ids ──► tower fwd, the embedding lookup fused into its input tile (both layers of both towers: 1 launch)
+        ──► fused scorer + softmax loss (pass 1: loss + dq, combine, pass 2: dc, slab reduction: 4 launches)
+        ──► tower bwd (dx + dw + db per layer: 2 launches)
+        ──► optimizer (sort of the ids, duplicate sums, sparse SGD/Adagrad of all tables, dense update: 1 launch)
 
-All buffers are allocated once for a fixed batch size; ``step`` enqueues ~25 kernels on the
-current stream and never synchronises (it can be captured in a HIP graph).
+All buffers are allocated once for a fixed batch size; ``step`` enqueues those 8 launches (cfg3; one more per extra tower
+layer) through ONE C call (``tt_train_step_f32``) on the current stream and never synchronises (it can be captured in a
+HIP graph).
 
 Reference anchors: hyper-parameters are the ``model:`` block of
 ``/root/reference/configs/data_config.yaml:54-71`` (embedding_dim, *_tower_dims, l2_regularization,
@@ -607,7 +610,7 @@ class TwoTowerTrainer:
 
     # ------------------------------------------------------------------ HIP graph replay of the whole step
     def capture_graph(self):
-        """Capture one train step (all ~25 launches, both streams) into a HIP graph.  ``step_graph(u, i)`` then
+        """Capture one train step (its 8-9 launches, one stream) into a HIP graph.  ``step_graph(u, i)`` then
         copies the ids into the captured buffers and replays: one host call per step, no launch gaps."""
         if self.cfg.dropout_rate > 0.0:
             raise NotImplementedError("graph replay with dropout: the per-step counter is a kernel argument")
