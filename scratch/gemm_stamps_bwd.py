@@ -38,6 +38,11 @@ def run(name, fn, nwg):
     ph = np.stack([us[:, 0], us[:, 1] - us[:, 0], us[:, 2] - us[:, 1], us[:, 3] - us[:, 2]], 1)
     pc = lambda a: " ".join(f"{np.percentile(a, q):.1f}" for q in (0, 10, 50, 90, 100))
     print(f"{name}: {len(s)} WGs; start p0/10/50/90/100 {pc(us[:, 0])} | load->LDS {pc(ph[:, 1])} | MFMA loop {pc(ph[:, 2])} | store drain {pc(ph[:, 3])} | end {pc(us[:, 3])}")
+    # by kind (r04): workgroups whose MFMA loop is in the longer / shorter half = the two kinds of tile
+    med = (ph[:, 2].max() + ph[:, 2].min()) / 2
+    for kind, sel in (("long-k tiles", ph[:, 2] >= med), ("short-k tiles", ph[:, 2] < med)):
+        if sel.sum():
+            print(f"   {kind}: {int(sel.sum())} WGs; start {pc(us[sel, 0])} | load->LDS {pc(ph[sel, 1])} | MFMA loop {pc(ph[sel, 2])} | store drain {pc(ph[sel, 3])} | end {pc(us[sel, 3])}")
     # by kind: the launch puts one kind of tile first; split the workgroups at the largest jump of MFMA-loop length
     order = np.argsort(ph[:, 2])
     print("   MFMA-loop length histogram (us):", np.histogram(ph[:, 2], bins=8)[0].tolist(), np.histogram(ph[:, 2], bins=8)[1].round(1).tolist())

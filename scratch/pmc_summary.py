@@ -7,7 +7,9 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(base + "/*/pmc_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         agg[r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
-KEYS = {"score_fused": "score_kernel<128, 4, false, false, 4, 0>", "score_bwd": "score_kernel<128, 5, false, false, 4, 0>",
+# (score_bwd: the exact-f32 dc pass runs 8-wave workgroups since r02 - r03's summary looked for the 4-wave name and found none)
+KEYS = {"score_fused": "score_kernel<128, 4, false, false, 4, 0>", "score_bwd": "score_kernel<128, 5, false, false, 8, 0>",
+        "tower_fwd2": "tower_fwd2_kernel<",
         "score_fused_bf16x3": "score_kernel<128, 4, false, false, 8, 1>", "score_bwd_bf16x3": "score_kernel<128, 5, false, false, 8, 1>",
         "gather": "gather_kernel<4", "sparse_apply": "sparse_apply_kernel<0>", "sparse_plan": "part_sort_kernel<",
         "optimizer": "optimizer_ids_kernel<0",

@@ -195,6 +195,183 @@ struct GemmBatch {
   int splits;
 };
 
+// ---- dW tiles WITHOUT LDS operand tiles (r04) ------------------------------------------------------------------------------
+// dW[k][n] = sum_b x[b][k] * dz[b][n] over the batch rows of one split.  Both operands are ROW-contiguous in the reduction index
+// (x is [b][k], dz is [b][n]), which is exactly v_mfma_f32_32x32x2_f32's operand layout: lane l supplies A[row l%32][k-slot l/32]
+// and B[k-slot l/32][col l%32] - one batch row per lane half, 32 consecutive k (n) across the lanes.  So a wave feeds its MFMAs
+// straight from global memory: an 8-byte load per lane and operand (half-wave = 256 contiguous bytes of one batch row) gives a
+// lane the values of output rows 2 ln, 2 ln + 1 (columns 2 ln, 2 ln + 1): four MFMAs per two batch rows cover a 64 x 64 tile as
+// 2 x 2 INTERLEAVED 32 x 32 blocks (block (i, j) = rows 2r + i, columns 2c + j).  No staging, no transpose, no workgroup barrier
+// in the reduction loop; the four waves of the workgroup split the split's batch rows four ways and meet once, through LDS, in a
+// fixed order ((w0 + w2) + (w1 + w3)).  The LDS-tile form this replaces ran a chain of load -> ds_write -> barrier -> 16 MFMAs per
+// 32 batch rows: r04 stamps, layer 1 of cfg3: the dW workgroups' MFMA loops took 11.8-17.6 us for 3.8 us of MFMA time per wave,
+// and the dx workgroups of the same launch finished their second tile only when those had retired.
+// Needs M % 64 == 0 and N % 64 == 0 (every tower layer of the BASELINE configs but cfg1's 32 x 32); TT_DW_DIRECT=0 keeps the tiles.
+#ifndef TT_DW_DIRECT
+#define TT_DW_DIRECT 1
+#endif
+#ifndef TT_DW_PF_DEEP
+#define TT_DW_PF_DEEP 16         // ... where no lookup is fused into the rows (no id ring, no mask bits: the registers are there)
+#endif
+#ifndef TT_DX_PRIO
+#define TT_DX_PRIO 2
+#endif
+#ifndef TT_DW_PF
+#define TT_DW_PF 8               // iterations (2 batch rows each) of operand loads in flight per wave
+#endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// TWO: a second table's row is summed into every gathered row (the hashed category feature); its ring is paid for with a
+// shallower one (4 rounds in flight instead of 8: the lookup kernels have no registers to spare at 4 workgroups per CU).
+template <int GK, bool TWO, int PFD = TT_DW_PF>
+__device__ __forceinline__ void dw_tile_direct(const GemmArgs& p, const int zsplit, const int bx, const int by, float* smem,
+                                               int32_t* gids) {
+  constexpr bool GATHER = GK != 0;
+  static_assert(GATHER || !TWO, "a second table only with the fused lookup");
+  constexpr int PF = TWO ? PFD / 2 : PFD;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, ln = lane & 31;
+  const int64_t m0 = (int64_t)bx * BM;        // first output row (k of the layer)
+  const int64_t n0 = (int64_t)by * BN;        // first output column
+  const int64_t kbeg = (int64_t)zsplit * p.k_per_split;
+  int64_t kend = kbeg + p.k_per_split;
+  if (kend > p.K) kend = p.K;
+  const int klen = kend > kbeg ? (int)(kend - kbeg) : 0;
+  if constexpr (GATHER) {
+    for (int i = tid; i < klen; i += 256) {
+      const int64_t i1 = p.a_ids[kbeg + i];
+      gids[i] = (i1 >= 0 && i1 < p.a_rows) ? (int32_t)i1 : -1;
+      if constexpr (TWO) {
+        const int64_t i2 = p.a_ids2[kbeg + i];
+        gids[GK + i] = (i2 >= 0 && i2 < p.a_rows2) ? (int32_t)i2 : -1;
+      }
+    }
+    __syncthreads();
+  }
+  STAMP(0);
+  // this wave's batch rows: a quarter of the split, in pairs (lane half h takes row 2 it + h of the quarter).  The direct form
+  // only takes splits whose length is a multiple of 64 rows (the caller checks): every wave then has a whole number of ring
+  // rounds, every row exists - no clamping, no zero masks, and the loop body is ONE basic block (with a per-slot `if (it < nit)`
+  // hipcc waits `vmcnt(0)` at the loop header, i.e. for the loads it issued a moment ago; "load, then zero if past the end"
+  // puts a select - and a full wait - right behind every load: both seen in the r04 ISA).
+  const int q = klen >> 2;                                     // rows per wave
+  const int nit = q >> 1;                                      // a multiple of PF
+  const uint32_t r0h = (uint32_t)(wave * q + h);               // this lane half's first row, relative to kbeg
+  const uint32_t lda = (uint32_t)p.lda, ldb = (uint32_t)p.ldb;
+  const float* Bb = p.B + kbeg * p.ldb + n0;                   // (uniform bases: the lane's part is a 32-bit element offset)
+  const float* Ab = GATHER ? p.A + m0 : p.A + kbeg * p.lda + m0;
+  f32x2 ra[PF], rb[PF], ra2[TWO ? PF : 1];
+  uint32_t a1m = 0u, a2m = 0u;                                 // GATHER: bit u = ring slot u holds a real table row (of table 1 / 2)
+  auto load_raw = [&](int u, int it) {
+    const uint32_t rl = r0h + 2u * (uint32_t)it;
+    rb[u] = *reinterpret_cast<const f32x2*>(Bb + (rl * ldb + 2u * (uint32_t)ln));
+    if constexpr (GATHER) {
+      const int i1 = gids[rl];
+      const uint32_t bit = 1u << u;
+      a1m = i1 >= 0 ? (a1m | bit) : (a1m & ~bit);
+      ra[u] = *reinterpret_cast<const f32x2*>(Ab + ((uint64_t)(uint32_t)(i1 >= 0 ? i1 : 0) * lda + 2u * (uint32_t)ln));
+      if constexpr (TWO) {
+        const int i2 = gids[GK + rl];
+        a2m = i2 >= 0 ? (a2m | bit) : (a2m & ~bit);
+        ra2[u] = *reinterpret_cast<const f32x2*>(p.A2 + m0 + ((uint64_t)(uint32_t)(i2 >= 0 ? i2 : 0) * lda + 2u * (uint32_t)ln));
+      }
+    } else {
+      ra[u] = *reinterpret_cast<const f32x2*>(Ab + (rl * lda + 2u * (uint32_t)ln));
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  float cs0 = 0.f, cs1 = 0.f;
+#pragma unroll
+  for (int u = 0; u < PF; ++u) load_raw(u, u);
+  for (int t0 = 0; t0 < nit; t0 += PF) {
+    const bool more = t0 + PF < nit;                           // (uniform) the last round re-reads its own rows: never consumed
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      f32x2 a = ra[u];
+      const f32x2 b = rb[u];
+      if constexpr (GATHER) {
+        if (!((a1m >> u) & 1u)) a = f32x2{0.f, 0.f};          // a padding / out-of-range id: zero row
+        if constexpr (TWO) {
+          if ((a2m >> u) & 1u) a = a + ra2[u];                 // one f32 add per element (the oracle's row + category row)
+        }
+      }
+      load_raw(u, more ? t0 + u + PF : t0 + u);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[1], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[0], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], acc[1][1], 0, 0, 0);
+      cs0 = __fadd_rn(cs0, b[0]);                              // db: column sums of dz ride along (used by the bx == 0 tiles)
+      cs1 = __fadd_rn(cs1, b[1]);
+    }
+  }
+  STAMP(1);
+  STAMP(2);
+  // the two lane halves hold different batch rows of the same columns
+  cs0 = __fadd_rn(cs0, __shfl_xor(cs0, 32));
+  cs1 = __fadd_rn(cs1, __shfl_xor(cs1, 32));
+  // ---- the four waves' partial tiles meet in LDS: (w0 + w2) + (w1 + w3), 66 values per lane ([reg][lane]: conflict-free) ----
+  constexpr int SLOT = 66 * 64;
+  auto put = [&](float* S) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) S[((i * 2 + j) * 16 + e) * 64 + lane] = acc[i][j][e];
+    S[64 * 64 + lane] = cs0;
+    S[65 * 64 + lane] = cs1;
+  };
+  auto add = [&](const float* S) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = __fadd_rn(acc[i][j][e], S[((i * 2 + j) * 16 + e) * 64 + lane]);
+    cs0 = __fadd_rn(cs0, S[64 * 64 + lane]);
+    cs1 = __fadd_rn(cs1, S[65 * 64 + lane]);
+  };
+  if (wave >= 2) put(smem + (wave - 2) * SLOT);
+  __syncthreads();
+  if (wave < 2) add(smem + wave * SLOT);
+  __syncthreads();
+  if (wave == 1) put(smem);
+  __syncthreads();
+  if (wave == 0) add(smem);
+  __syncthreads();                                             // (everyone is done reading the slots)
+  // ---- out: wave 0's registers -> [64][64 + 4] floats in LDS -> 16 bytes per lane, all four waves storing ----
+  constexpr int LSO = BN + 4;
+  if (wave == 0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = 2 * tt::acc_row(e, h) + i;
+        *reinterpret_cast<f32x2*>(smem + row * LSO + 2 * ln) = f32x2{acc[i][0][e], acc[i][1][e]};
+      }
+  }
+  __syncthreads();
+  float* C = p.C + (int64_t)zsplit * p.slab_stride;
+#pragma unroll
+  for (int j = 0; j < BM * BN / 4 / 256; ++j) {
+    const int f = tid + 256 * j;
+    const int row = f / (BN / 4), c4 = f % (BN / 4);
+    *reinterpret_cast<f32x4*>(C + (m0 + row) * p.ldc + n0 + 4 * c4) = *reinterpret_cast<const f32x4*>(smem + row * LSO + 4 * c4);
+  }
+  if (bx == 0 && wave == 0 && lane < 32)
+    *reinterpret_cast<f32x2*>(p.db_slabs + (int64_t)zsplit * p.N + n0 + 2 * ln) = f32x2{cs0, cs1};
+#ifdef TT_GEMM_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  STAMP(3);
+#endif
+}
+
 // one 64x64 output tile (bx, by) of problem p, k-range of split zsplit.  GATHER: A is an embedding table read through
 // p.a_ids (KC: the forward GEMM of layer 0; MC: its dW GEMM, ids staged in `gids`).
 //
@@ -208,6 +385,23 @@ struct GemmBatch {
 template <bool A_KC, bool B_KC, bool COLSUM, int GK, bool DROP = false>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int zsplit, const int bx, const int by, float* smem,
                                           int32_t* gids) {
+#if TT_DW_DIRECT
+  if constexpr (!A_KC && !B_KC && COLSUM) {
+    // (workgroup-uniform) the direct form takes whole 64 x 64 tiles and 8-byte row pieces
+    // (rows straight from a dense activation - GK == 0 -: twice the ring depth, for splits that are whole rounds of it - 4 MFMAs
+    // per ring slot are 0.12 us of matrix-pipe time against a 1-2 us load round trip; only ONE depth per kernel: with both
+    // instantiated beside the dx tiles the kernel needs more than the 128 VGPRs that 4 workgroups per CU leave)
+    constexpr int RND = 8 * (GK == 0 ? TT_DW_PF_DEEP : TT_DW_PF);       // batch rows of one ring round of the four waves
+    if ((p.M & 63) == 0 && (p.N & 63) == 0 && ((p.lda | p.ldb | p.ldc) & 3) == 0 && p.db_slabs != nullptr &&
+        ((p.K | p.k_per_split) & (RND - 1)) == 0 && p.k_per_split * (p.lda > p.ldb ? p.lda : p.ldb) < ((int64_t)1 << 31)) {
+      if constexpr (GK != 0) {
+        if (p.A2 != nullptr) { dw_tile_direct<GK, true>(p, zsplit, bx, by, smem, gids); return; }
+      }
+      dw_tile_direct<GK, false, (GK == 0 ? TT_DW_PF_DEEP : TT_DW_PF)>(p, zsplit, bx, by, smem, gids);
+      return;
+    }
+  }
+#endif
   constexpr int PF = (A_KC && !B_KC) ? TT_GEMM_PF_FWD : PF_MAX;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -485,6 +679,11 @@ __global__ __launch_bounds__(256, (GK > 256 ? 3 : 4)) void gemm_bwd_kernel(BwdBa
     if (pb.dw_first) b -= n_dw;
     const int prob = b / per_x;
     b -= prob * per_x;
+    // (r04) the dx tiles - short k loops between a load round trip and a store drain, two of them per workgroup - go FIRST at
+    // the matrix pipe; the dW tiles (since r04 one long barrier-free MFMA stream per wave) fill what they leave.  At equal
+    // priority the oldest wave wins: the dW waves, dispatched first, held the pipe and the dx workgroups' second tiles ran
+    // alone at the end of the launch, latency-bound (r04 stamps: second dx tiles from 19-24 us to 27-32 us of a 32 us launch).
+    __builtin_amdgcn_s_setprio(TT_DX_PRIO);
     gemm_tile<true, true, false, 0>(pb.ax[prob], 0, b % pb.dx_gm, b / pb.dx_gm, smem, gids);
     if (pb.dx_pair) {
       __syncthreads();                               // every wave is done with the first tile's LDS buffers

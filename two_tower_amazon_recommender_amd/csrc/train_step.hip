@@ -16,7 +16,10 @@ extern "C" int tt_train_step_f32(const tt_train_step* s, tt_stream_t stream) {
   int rc;
   // two-layer towers: both layers of both towers in one launch (csrc/tower.hip); TT_FUSED_TOWER=0 keeps the two launches (A/B)
   static const bool fused_tower = std::getenv("TT_FUSED_TOWER") == nullptr || std::atoi(std::getenv("TT_FUSED_TOWER")) != 0;
-  const bool fwd2 = fused_tower && L == 2 && tt_tower_fwd2_supported(s->batch, s->dims[0], s->dims[1], s->dims[2]);
+  // (r04: towers of MORE than two layers - the reference's own [512, 256, 128], configs/data_config.yaml:56-57 - run their last
+  // two layers, ReLU hidden + linear output: the fused kernel's pattern, as the fused launch and the layers below one by one)
+  const bool fwd2 = fused_tower && L >= 2 && tt_tower_fwd2_supported(s->batch, s->dims[L - 2], s->dims[L - 1], s->dims[L]);
+  const int Lf = fwd2 ? L - 2 : L;                 // layers that run as their own launch
   // r04, measured and left OFF (TT_DENSE_RIDERS=1 switches it on): the dense update of layer l's parameters riding in the backward
   // launch of layer l - 1 (tt_dense_bwd_batched_update_f32: its gradient slabs are complete and nothing below reads its weights),
   // so that the optimizer launch - whose HBM burst is the embedding rows' - keeps only the segments of layer 0.  Same arithmetic.
@@ -43,7 +46,7 @@ extern "C" int tt_train_step_f32(const tt_train_step* s, tt_stream_t stream) {
   static std::atomic<uint32_t> generation{0};
   tt_dense_fwd_args f0[2] = {s->fwd[0][0], s->fwd[0][1]};
   tt_sparse_table_ids tabs[3] = {s->tables[0], s->tables[1], s->tables[2]};
-  if (want_lists && fwd2 && s->id_bucket_ws != nullptr && f0[0].lookup.ids != nullptr && f0[1].lookup.ids != nullptr &&
+  if (want_lists && fwd2 && L == 2 && s->id_bucket_ws != nullptr && f0[0].lookup.ids != nullptr && f0[1].lookup.ids != nullptr &&
       f0[0].lookup.ids == tabs[0].ids && f0[1].lookup.ids == tabs[1].ids && f0[0].lookup.table_rows == tabs[0].rows &&
       f0[1].lookup.table_rows == tabs[1].rows) {
     const int64_t per = tt_id_buckets_workspace_bytes();
@@ -65,17 +68,17 @@ extern "C" int tt_train_step_f32(const tt_train_step* s, tt_stream_t stream) {
       }
     }
   }
-  if (fwd2) {
-    const bool drop = s->dropout_rate > 0.f;
-    rc = tt_tower_fwd2_batched_f32(f0, s->fwd[1], 2, s->batch, s->dims[0], s->dims[1], s->dims[2], drop ? s->dropout_rate : 0.f,
-                                   s->dropout_seed, drop ? s->dropout_row0 * (uint64_t)s->dims[1] : 0ull, stream);
-    if (rc != TT_OK) return rc;
-  }
-  for (int l = 0; l < L && !fwd2; ++l) {
+  for (int l = 0; l < Lf; ++l) {
     const bool hidden = l < L - 1;
     const bool drop = hidden && s->dropout_rate > 0.f;
-    rc = tt_dense_fwd_batched_f32(s->fwd[l], 2, s->batch, s->dims[l], s->dims[l + 1], hidden ? 1 : 0, drop ? s->dropout_rate : 0.f,
+    rc = tt_dense_fwd_batched_f32(l == 0 ? f0 : s->fwd[l], 2, s->batch, s->dims[l], s->dims[l + 1], hidden ? 1 : 0, drop ? s->dropout_rate : 0.f,
                                   s->dropout_seed, drop ? s->dropout_row0 * (uint64_t)s->dims[l + 1] : 0ull, stream);
+    if (rc != TT_OK) return rc;
+  }
+  if (fwd2) {
+    const bool drop = s->dropout_rate > 0.f;
+    rc = tt_tower_fwd2_batched_f32(L == 2 ? f0 : s->fwd[L - 2], s->fwd[L - 1], 2, s->batch, s->dims[L - 2], s->dims[L - 1], s->dims[L],
+                                   drop ? s->dropout_rate : 0.f, s->dropout_seed, drop ? s->dropout_row0 * (uint64_t)s->dims[L - 1] : 0ull, stream);
     if (rc != TT_OK) return rc;
   }
   const float* q = s->fwd[L - 1][0].y;

@@ -171,24 +171,28 @@ def towers_forward(ut: "Tower", it: "Tower", dropout=None, lookups=None):
     """Both towers layer by layer, one launch per layer (the towers have identical shapes).
     dropout = (rate, seed, first_global_row) in training, None at inference.
     lookups = (user lookup, item lookup): layer 0 gathers its input rows from the embedding tables itself."""
-    if ut.n_layers == 2 and ops.tower_fwd2_supported(ut.acts[1].shape[0], ut.dims[0], ut.dims[1], ut.dims[2]):
-        # both layers of both towers in ONE launch: the hidden tile never leaves the CU between the layers (csrc/tower.hip)
-        d = None
-        if dropout is not None and dropout[0] > 0.0:
-            rate, seed, row0 = dropout
-            d = (rate, seed, (TID_DROPOUT_BASE, TID_DROPOUT_BASE + 1), row0 * ut.dims[1])
-        ops.tower_fwd2((ut.acts[0], it.acts[0]), (ut.w[0], it.w[0]), (ut.b[0], it.b[0]), (ut.acts[1], it.acts[1]),
-                       (ut.bits[1], it.bits[1]), (ut.w[1], it.w[1]), (ut.b[1], it.b[1]), (ut.acts[2], it.acts[2]),
-                       dropout=d, lookups=lookups)
-        return ut.acts[-1], it.acts[-1]
-    for l in range(ut.n_layers):
-        hidden = l < ut.n_layers - 1
+    L = ut.n_layers
+    # the last two layers (ReLU hidden + linear output) of both towers in ONE launch when their shapes allow it: the hidden tile
+    # never leaves the CU between them (csrc/tower.hip); two-layer towers are that launch alone (with the lookup inside), deeper
+    # ones - the reference's [512, 256, 128] - run the layers below one by one first
+    fused = L >= 2 and ops.tower_fwd2_supported(ut.acts[1].shape[0], ut.dims[L - 2], ut.dims[L - 1], ut.dims[L])
+    for l in range(L - 2 if fused else L):
+        hidden = l < L - 1
         d = None
         if dropout is not None and hidden and dropout[0] > 0.0:
             rate, seed, row0 = dropout
             d = (rate, seed, (TID_DROPOUT_BASE + 2 * l, TID_DROPOUT_BASE + 2 * l + 1), row0 * ut.dims[l + 1])
         ops.dense_fwd2((ut.acts[l], it.acts[l]), (ut.w[l], it.w[l]), (ut.b[l], it.b[l]), (ut.acts[l + 1], it.acts[l + 1]),
                        relu=hidden, dropout=d, lookups=lookups if l == 0 else None, relu_bits=(ut.bits[l + 1], it.bits[l + 1]))
+    if fused:
+        a = L - 2
+        d = None
+        if dropout is not None and dropout[0] > 0.0:
+            rate, seed, row0 = dropout
+            d = (rate, seed, (TID_DROPOUT_BASE + 2 * a, TID_DROPOUT_BASE + 2 * a + 1), row0 * ut.dims[a + 1])
+        ops.tower_fwd2((ut.acts[a], it.acts[a]), (ut.w[a], it.w[a]), (ut.b[a], it.b[a]), (ut.acts[a + 1], it.acts[a + 1]),
+                       (ut.bits[a + 1], it.bits[a + 1]), (ut.w[a + 1], it.w[a + 1]), (ut.b[a + 1], it.b[a + 1]),
+                       (ut.acts[a + 2], it.acts[a + 2]), dropout=d, lookups=lookups if a == 0 else None)
     return ut.acts[-1], it.acts[-1]
 
 
