@@ -1156,7 +1156,8 @@ def test_retrieval_task_batch_metrics_topk_accuracy(dev, nq, nc, d, off, opts):
     for m in ms:
         assert (hi < m.k).mean() - 1e-12 <= m.result() <= (lo < m.k).mean() + 1e-12
     assert ms[1].result() >= ms[0].result() > 0.0
-    # compute_batch_metrics=False leaves the metric alone; weights give the Keras weighted mean
+    # compute_batch_metrics=False leaves the metric alone; sample weights do NOT reach the batch metrics (TFRS calls
+    # metric.update_state(labels, scores): only the loss and loss_metrics are weighted - ADVICE r03)
     before = ms[0].result()
     task(T(q, dev), T(c, dev), compute_batch_metrics=False, **kw)
     assert ms[0].result() == before
@@ -1164,7 +1165,9 @@ def test_retrieval_task_batch_metrics_topk_accuracy(dev, nq, nc, d, off, opts):
     w = synth.uniform_f32(81, 6, nq, 0.5, 1.5)
     Retrieval(temperature=0.1, batch_metrics=[m2])(T(q, dev), T(c, dev), sample_weight=T(w, dev), diag_offset=off)
     r3 = torch.ops.twotower.retrieval_batch_rank(T(q, dev), T(c, dev), None, None, 10.0, off).cpu().numpy()
-    assert abs(m2.result() - float(((r3 < 3) * w.astype(np.float64)).sum() / w.astype(np.float64).sum())) < 1e-9
+    assert abs(m2.result() - float((r3 < 3).mean())) < 1e-9
+    with pytest.raises(NotImplementedError):                       # TFRS evaluates them on the scores AFTER hard-negative mining
+        Retrieval(temperature=0.1, batch_metrics=[TopKCategoricalAccuracy(3)], num_hard_negatives=5)
 
 
 # ----------------------------------------------------------------------------------- a6/a7 id encoding on the GPU

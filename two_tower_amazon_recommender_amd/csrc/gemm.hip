@@ -211,8 +211,8 @@ struct GemmBatch {
 #define TT_DW_DIRECT 1
 #endif
 #ifndef TT_DW_PF_DEEP
-#define TT_DW_PF_DEEP 16         // ... where no lookup is fused into the rows (no id ring, no mask bits: the registers are there)
-#endif
+#define TT_DW_PF_DEEP 8          // ring depth where no lookup is fused into the rows.  16 fits the registers but ties (towers 87.6-87.8
+#endif                           // vs 87.8-88.1 us, r04) and would give dense and looked-up rows different eligibility (splits of 128 vs 64 rows)
 #ifndef TT_DX_PRIO
 #define TT_DX_PRIO 2
 #endif
