@@ -146,9 +146,12 @@ __device__ TT_TAIL_ATTR void finish_run_piece(f32x4* __restrict__ table, f32x4* 
 #endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   int ticket = 0;
-  // (the ticket as an agent-scope RELEASE add: on gfx950 the same instruction as the relaxed one behind the vmcnt(0) above -
-  // the piece sums left as write-through stores and have been acknowledged -, but the ordering no longer rests on that alone)
-  if (l == 0) ticket = __hip_atomic_fetch_add(&p_flag[jh], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  // (the ticket stays a RELAXED add behind the `s_waitcnt vmcnt(0)` above: the piece sums left as write-through sc1 stores and
+  // have been acknowledged.  r04 tried the textbook form - __hip_atomic_fetch_add(..., __ATOMIC_RELEASE, agent), ADVICE r03 -:
+  // hipcc puts the release in front of it as `buffer_wbl2 sc1`, the write-back of every dirty L2 line of the XCD that r03
+  // had removed, and the 1M-id lines went straight back to r02's: 347 / 519 / 522 / 644 us -> 694 / 909 / 2018 / 2229 us
+  // (profiles/r04_sparse_ticket_ab.jsonl).  gfx942 / gfx950 only: the library builds for nothing else.)
+  if (l == 0) ticket = atomicAdd(&p_flag[jh], 1);
   ticket = __shfl(ticket, (int)(threadIdx.x & 63u & ~(unsigned)(lpr - 1)));
   if (ticket != npieces - 1) return;
   // last arriver: every piece of the run is published
