@@ -11,7 +11,7 @@ In-batch negatives are GLOBAL by default (candidates all-gathered, dC reduce-sca
 single-device loss on the global batch); ``--negatives local`` scores each rank's queries against its
 own candidates only and says so in ``config.workload``.
 value = global batch * steps / max-over-ranks time.  The line carries the scorer's ``roofline`` on the per-GPU slab
-(B_local x B_global) from live hipEvent brackets on rank 0, and per-collective stream time from an untimed detail pass.
+(B_local x B_global) from live dispatch timestamps (hipExtLaunchKernelGGL event pair, r04) on rank 0, and per-collective stream time from an untimed detail pass.
 """
 import json
 import os
@@ -195,7 +195,9 @@ def run_distributed(args, rank, world, dev):
         # collective of a step: what the step would take if nothing but the model's terms changed.
         work_model = None
         try:
-            n1 = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_n1_reference.json")))[name]
+            prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+            ref = next(f for f in ("r04_n1_reference.json", "r03_n1_reference.json") if os.path.exists(os.path.join(prof_dir, f)))
+            n1 = json.load(open(os.path.join(prof_dir, ref)))[name]
             factor = (nc / batch) * (batch / n1["batch_per_gpu"]) ** 2      # Bq*Bc*D against the N = 1 launch's
             other = n1["ms_per_step"] - n1["scorer_ms"]
             if name != "cfg3":
@@ -206,7 +208,7 @@ def run_distributed(args, rank, world, dev):
                           "ms_expected_from_n1": n1["scorer_ms"] * factor + other + coll_ms,
                           "note": "a model: N = 1 kernel times rescaled + measured per-collective stream time; exposed waits "
                                   "between ranks are what the difference to ms_per_step shows"}
-        except (OSError, KeyError, ValueError, ZeroDivisionError, TypeError):
+        except (OSError, KeyError, ValueError, ZeroDivisionError, TypeError, StopIteration):
             pass
         out = {
             "metric": "user-item pairs/sec (train step) + embedding-gather HBM GB/s, 1/2/4/8 MI355X",
@@ -229,7 +231,7 @@ def run_distributed(args, rank, world, dev):
             "other_negatives": None if alt is None else {
                 "negatives": other, "value": world * batch * alt[0] / alt[1], "unit": "pairs/s", "ms_per_step": alt[1] / alt[0] * 1e3,
                 "steps": alt[0], "note": "same run, same steps, in-batch negatives switched; NOT the headline value"},
-            "timing_note": f"hipEvent brackets inside the timed region: score_fused on rank 0, every {stride}th step; "
+            "timing_note": f"dispatch timestamps inside the timed region: score_fused on rank 0, every {stride}th step; "
                            f"collectives: stream time per call, untimed detail pass of {detail_steps} steps",
             "loss_per_pair": loss.item() / (world * batch),
         }
