@@ -628,8 +628,14 @@ def test_two_tower_model_facade(dev):
     cfg = TwoTowerConfig(n_users=500, n_items=400, embedding_dim=32, tower_dims=[32], batch_size=128, optimizer="sgd")
     m = TwoTowerModel(cfg, dev, seed=3)
     u, i = m.trainer.synthetic_batch(3, 0)
+    # tfrs.Model.train_step's dict: total_loss = loss + the Dense kernels' L2 terms, evaluated on the weights the step started from
+    l2_before = float(m.trainer.l2_penalty().item())
     out = m.train_step({"user_idx": u, "item_idx": i})
     assert out["loss"].item() > 0
+    assert l2_before > 0 and abs(out["regularization_loss"].item() - l2_before) <= 1e-5 * l2_before
+    assert abs(out["total_loss"].item() - (out["loss"].item() + l2_before)) <= 1e-5 * abs(out["total_loss"].item())
+    plain = m.train_step({"user_idx": u, "item_idx": i}, report_regularization=False)
+    assert plain["regularization_loss"] is None and torch.equal(plain["total_loss"], plain["loss"])
     val = m.test_step({"user_id_encoded": u, "item_id_encoded": i})      # the preprocessor's column names work too
     assert val["loss"].item() > 0
     with pytest.raises(KeyError):
@@ -646,6 +652,33 @@ def test_two_tower_model_facade(dev):
     assert torch.equal(la, lb) and torch.equal(a.trainer.cat_table, b.trainer.cat_table)
     with pytest.raises(KeyError):
         a.train_step({"user_idx": u, "item_idx": i})
+
+
+def test_retrieval_task_validates_in_its_training_precision_and_reuses_one_workspace(dev):
+    """Retrieval(precision="bf16x3") under no_grad runs the validation op in bf16x3 too (r03: it silently validated in f32), and
+    the custom ops' scorer workspace is kept at the LARGEST size seen per (kind, device, stream) - a loop alternating two batch
+    shapes does not re-allocate - until release_workspaces()."""
+    from two_tower_amazon_recommender_amd import torch_ops
+    from two_tower_amazon_recommender_amd.tasks import Retrieval
+    torch_ops.release_workspaces()
+    q = torch.from_numpy(synth.uniform_f32(91, 1, 1024 * 128, -0.3, 0.6).reshape(1024, 128)).to(dev)
+    c = torch.from_numpy(synth.uniform_f32(91, 2, 1024 * 128, -0.3, 0.6).reshape(1024, 128)).to(dev)
+    t32, tbx = Retrieval(temperature=0.1), Retrieval(temperature=0.1, precision="bf16x3")
+    with torch.no_grad():
+        v32, vbx = t32(q, c), tbx(q, c)
+    direct = torch.ops.twotower.retrieval_loss_value(q, c, None, None, None, 10.0, 0, 0, "bf16x3")[0]
+    assert torch.equal(vbx, direct)                                  # the task passed its precision on
+    assert abs(vbx.item() - v32.item()) <= 1e-4 * abs(v32.item())    # same bar as the training form
+    qg = q.clone().requires_grad_(True)
+    assert abs(tbx(qg, c).item() - vbx.item()) <= 1e-5 * abs(vbx.item())
+    big = [b for b in torch_ops._WS_CACHE.values()]
+    ptrs = {b.data_ptr() for b in big}
+    with torch.no_grad():
+        for n in (256, 1024, 512, 1024, 256):
+            t32(q[:n], c[:n])
+    assert {b.data_ptr() for b in torch_ops._WS_CACHE.values()} == ptrs      # no re-allocation for the smaller shapes
+    torch_ops.release_workspaces()
+    assert not torch_ops._WS_CACHE and not torch_ops._PLAN_CACHE
 
 
 @pytest.mark.parametrize("negatives,nb", [("local", 0), ("global", 0), ("local", 30)])
