@@ -139,6 +139,16 @@ def rocprof_avg_us(*needles):
         return None
 
 
+def rocprof_lookup_share_us():
+    """K1's share of the layer-0 launches from the COMMITTED rocprofv3 A/B (lookup fused vs materialised input, same box,
+    alternating: profiles/r04_lookup_share.json) - not measured in this run; the live figure beside it is a difference of
+    two detail-pass means and moves by +-1 us from run to run."""
+    try:
+        return float(json.load(open(os.path.join(ROOT, "profiles", "r04_lookup_share.json")))["lookup_share_us"])
+    except (OSError, KeyError, ValueError, TypeError):
+        return None
+
+
 def pmc_traffic(tag):
     """HBM bytes per launch of kernel `tag` from the COMMITTED rocprofv3 --pmc summary (separate passes,
     MI355X_MICROARCH.md §HBM corrections applied) — not measured in this run: the line says so in `traffic_source`."""
@@ -457,6 +467,7 @@ def main():
         if plan_on_main:
             gs_bytes += plan_bytes
     rp_opt = rocprof_avg_us("optimizer_ids_kernel") if (args.config == "cfg3" and args.optimizer == "sgd" and fused_sort) else None
+    rp_lookup = rocprof_lookup_share_us() if (args.config == "cfg3" and args.optimizer == "sgd" and fused_sort and lookup_fused) else None
     out = {
         "metric": "user-item pairs/sec (train step) + embedding-gather HBM GB/s, 1/2/4/8 MI355X",
         "value": batch / (dt / args.steps), "unit": "pairs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -507,6 +518,11 @@ def main():
                          "rocprof_optimizer_launch_us": rp_opt,
                          "frac_with_rocprof_launch": (gs_bytes / ((rp_opt + max(lookup_us or 0.0, 0.0)) * 1e-6) / 1e9 / HBM_PEAK_GBS) if rp_opt else None,
                          "rocprof_source": f"{KSTATS_FILE} (committed rocprofv3 duration of the optimizer launch; not re-measured in this run)",
+                         "lookup_share_rocprof_ab_us": rp_lookup,
+                         "frac_with_rocprof_ab_share": (gs_bytes / ((per_step("optimizer") * 1e3 + rp_lookup) * 1e-6) / 1e9 / HBM_PEAK_GBS) if rp_lookup else None,
+                         "lookup_share_source": "profiles/r04_lookup_share.json (committed rocprofv3 A/B of the layer-0 launches, lookup fused vs "
+                                                "materialised input, same box, alternating; not re-measured in this run) - frac_with_rocprof_ab_share = "
+                                                "this run's optimizer launch + that share",
                          "unfused_dense_update_us": (mean(unfused["dense_update"]) * 1e3) if unfused.get("dense_update") else None,
                          "sparse_plan_us": plan_ms * 1e3,
                          "sparse_plan_stream": "inside the optimizer launch (un-fused detail pass figure above)" if fused_sort
