@@ -131,15 +131,22 @@ __device__ __forceinline__ int img_off(int row, int ch) { return 256 * row + 16 
 #ifndef TT_S_PREFETCH
 #define TT_S_PREFETCH 2       // BWD_S: tiles of stored dot products in flight ahead of the one being worked on (1 or 2)
 #endif
+#ifndef TT_ABL_BWDS_NOSTAGE
+#define TT_ABL_BWDS_NOSTAGE 0
+#endif
 #ifndef TT_LOOP_LAMBDA
 #define TT_LOOP_LAMBDA 0
 #endif
 #ifndef TT_TILES_PER_BARRIER
 #define TT_TILES_PER_BARRIER 2
 #endif
+#ifndef TT_TILES_PER_BARRIER_BWDS
+#define TT_TILES_PER_BARRIER_BWDS TT_TILES_PER_BARRIER      // the dc pass (one 8-wave workgroup per CU: room for a ring of 8 buffers)
+#endif
 template <int D, int MODE, int PREC>
 constexpr int tiles_per_barrier() {
-  return (PREC == 0 && D <= 128 && (MODE == MODE_BWD || MODE == MODE_FUSED || MODE == MODE_FUSED_S || MODE == MODE_BWD_S))
+  if (PREC == 0 && D <= 128 && MODE == MODE_BWD_S) return TT_TILES_PER_BARRIER_BWDS;
+  return (PREC == 0 && D <= 128 && (MODE == MODE_BWD || MODE == MODE_FUSED || MODE == MODE_FUSED_S))
              ? TT_TILES_PER_BARRIER : 1;
 }
 
@@ -734,11 +741,16 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? ((MODE ==
       const f32x16 X = xs_t;
       float coef[16];
       epilogue(T, t, X, coef);
+#if TT_ABL_BWDS_NOSTAGE      // (timing-only ablation, results wrong: no K-tile staging and no barrier in the dc pass)
+      if (t + 2 < ntiles) load_S(t + 2, xs_t);
+      gemm2(T, coef);
+#else
       if constexpr (PREC == 0) { if (t + TPB < ntiles) load_tile(t + TPB); }
       if (t + 2 < ntiles) load_S(t + 2, xs_t);
       gemm2(T, coef);
       if (t + TPB < ntiles) store_tile((t + TPB) % NBUF);
       if ((t % TPB) == TPB - 1) __syncthreads();
+#endif
     };
     for (int t = 0; t < ntiles; t += 2) {
       tile_step(t, xa);
