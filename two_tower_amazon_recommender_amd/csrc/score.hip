@@ -159,6 +159,17 @@ template <int D, int MODE, int PREC>
 constexpr bool split_d() {
   return PREC == 1 && D == 256 && (MODE == MODE_BWD || MODE == MODE_FUSED || MODE == MODE_FUSED_S);
 }
+// exact f32 at dim 256, online-softmax passes WITH accidental-hit ids / hard negatives: the stationary fragment (128 VGPRs) +
+// the gradient block (128) + the tile in flight (32) + the id / threshold state no longer fit 512 registers (r03: 40 / 56 /
+// 132 B of scratch per lane).  The LAST k-groups of the fragment - 5 with ids, 8 with thresholds, 10 with both - live in LDS, one
+// 16-byte slot per lane, written once and read back by the same lane (one ds_read_b128 per group and tile): 20 / 40 VGPRs less.
+template <int D, int MODE, bool HAS_IDS, bool HAS_HN, int PREC>
+constexpr int rf_lds_groups() {
+  if (PREC == 0 && D == 256 && (MODE == MODE_FUSED || MODE == MODE_FUSED_S) && (HAS_IDS || HAS_HN))
+    return (HAS_IDS && HAS_HN) ? 10 : (HAS_HN ? 8 : 5);
+  if (PREC == 0 && D == 128 && MODE == MODE_BWD && HAS_IDS && HAS_HN) return 2;      // (20 B of scratch at 2 waves per SIMD)
+  return 0;
+}
 template <int D, int MODE, int PREC, int WAVES>
 constexpr int rows_per_wg() { return (split_d<D, MODE, PREC>() ? WAVES / 2 : WAVES) * 32; }
 
@@ -217,7 +228,10 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? ((MODE ==
   static_assert(!(SPLIT && RLO_LDS), "wave-pair exchange buffer and the LDS lo fragments share one LDS region");
   static_assert(!SPLIT || TPB == 1, "the wave-pair exchange relies on one workgroup barrier per tile");
   constexpr int NBUF = STAG ? 3 : 2 * TPB;
-  f32x4 rf[PREC == 0 ? NG : 1];
+  constexpr int RFL = rf_lds_groups<D, MODE, HAS_IDS, HAS_HN, PREC>();      // k-groups of the stationary fragment kept in LDS
+  constexpr int RFR = PREC == 0 ? NG - RFL : 1;                             // ... and in registers
+  f32x4 rf[RFR];
+  f32x4* rfl = reinterpret_cast<f32x4*>(smem + NBUF * BUF_F) + (wave * (RFL > 0 ? RFL : 1)) * 64 + lane;   // [group][lane], this wave's
   bf16x8 rp[PREC == 0 ? 1 : (RLO_LDS ? 2 : 3)][PREC == 0 ? 1 : KS];
   bf16x8* rlo = reinterpret_cast<bf16x8*>(smem + NBUF * BUF_F) + (wave * KS) * 64 + lane;
   if constexpr (FROM_S) {
@@ -225,7 +239,14 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? ((MODE ==
   } else if constexpr (PREC == 0) {
     const f32x4* R4 = reinterpret_cast<const f32x4*>(p.R + (r_ok ? r : 0) * D) + h;
 #pragma unroll
-    for (int g = 0; g < NG; ++g) rf[g] = r_ok ? R4[2 * g] : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < NG; ++g) {
+      const f32x4 v = r_ok ? R4[2 * g] : f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (RFL > 0) {
+        if (g >= RFR) rfl[(g - RFR) * 64] = v; else rf[g < RFR ? g : 0] = v;   // (read back by this lane only: no barrier needed)
+      } else {
+        rf[g] = v;
+      }
+    }
   } else {
     const f32x4* R4 = reinterpret_cast<const f32x4*>(p.R + (r_ok ? r : 0) * D) + 2 * h + 32 * hw;
     const float live = r_ok ? 1.f : 0.f;            // rows past n_r read row 0 and are zeroed (all loads unconditional)
@@ -433,10 +454,12 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 ? 2 : (D <= 128 ? ((MODE ==
       for (int g = 0; g < NG; ++g) {
         f32x4 a_nxt = a_cur;
         if (g + 1 < NG) a_nxt = *reinterpret_cast<const f32x4*>(arow + 8 * (g + 1));
-        X = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0], rf[g][0], X, 0, 0, 0);
-        X = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[1], rf[g][1], X, 0, 0, 0);
-        X = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[2], rf[g][2], X, 0, 0, 0);
-        X = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[3], rf[g][3], X, 0, 0, 0);
+        f32x4 rg;
+        if constexpr (RFL > 0) { if (g >= RFR) rg = rfl[(g - RFR) * 64]; else rg = rf[g < RFR ? g : 0]; } else rg = rf[g];
+        X = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0], rg[0], X, 0, 0, 0);
+        X = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[1], rg[1], X, 0, 0, 0);
+        X = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[2], rg[2], X, 0, 0, 0);
+        X = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[3], rg[3], X, 0, 0, 0);
         a_cur = a_nxt;
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -1249,12 +1272,13 @@ int launch_score(const ScoreArgs& a_in, bool has_ids, hipStream_t stream) {
   const int64_t nrb = (a_in.n_r + RPW - 1) / RPW;
   const int64_t blocks = nrb * a_in.nsplit;
   // bf16x3 with 8 waves: a third tile buffer (staggered wave halves) + the R_lo fragments of the 8 waves
-  const int lds = Geo<D, PREC>::LDS_BYTES * tiles_per_barrier<D, MODE, PREC>() +
+  const int lds_base = Geo<D, PREC>::LDS_BYTES * tiles_per_barrier<D, MODE, PREC>() +
                   ((PREC == 1 && W == 8) ? (TT_BX3_STAGGER ? Geo<D, PREC>::BUF_F * 4 : 0) + W * Geo<D, PREC>::KS * 64 * 16 : 0) +
                   (split_d<D, MODE, PREC>() ? W * 4096 : 0);          // + the pair's dot-product exchange
   const bool has_hn = (a_in.h_r != nullptr) || (a_in.h_c != nullptr);
   const ScoreArgs& a = a_in;
-  auto go = [&](auto kern) -> int {
+  auto go = [&](auto kern, int rfl_groups = 0) -> int {
+    const int lds = lds_base + W * rfl_groups * 64 * 16;        // + the LDS-resident k-groups of the stationary fragment
     if (lds > 64 * 1024) {   // above the 64 KiB default the limit must be raised (cheap, idempotent)
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return tt::fail(TT_ERR_LAUNCH, "hipFuncSetAttribute(LDS %d) failed", lds);
@@ -1264,9 +1288,9 @@ int launch_score(const ScoreArgs& a_in, bool has_ids, hipStream_t stream) {
     tt::launch(tag, kern, dim3((unsigned)blocks), dim3(W * 64), (unsigned)lds, stream, a);
     return tt::check_launch(tag);
   };
-  if (has_ids && has_hn) return go(score_kernel<D, MODE, true, true, W, PREC>);
-  if (has_ids) return go(score_kernel<D, MODE, true, false, W, PREC>);
-  if (has_hn) return go(score_kernel<D, MODE, false, true, W, PREC>);
+  if (has_ids && has_hn) return go(score_kernel<D, MODE, true, true, W, PREC>, rf_lds_groups<D, MODE, true, true, PREC>());
+  if (has_ids) return go(score_kernel<D, MODE, true, false, W, PREC>, rf_lds_groups<D, MODE, true, false, PREC>());
+  if (has_hn) return go(score_kernel<D, MODE, false, true, W, PREC>, rf_lds_groups<D, MODE, false, true, PREC>());
   return go(score_kernel<D, MODE, false, false, W, PREC>);
 }
 

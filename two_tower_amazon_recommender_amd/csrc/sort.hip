@@ -112,21 +112,40 @@ __global__ __launch_bounds__(1024) void lds_sort_kernel(SortBatch batch) {
     // ---- rank inside the wave.  All ballots first (VALU/SALU only), then the leaders' counter bumps as LDS atomics
     // issued back to back: the LDS executes one wave's instructions in order, so round r sees the bumps of rounds < r
     // without a round trip per round; the old value reaches the other peers through one ds_bpermute each. ----
-    uint32_t dg[ITEMS], rk[ITEMS], lead[ITEMS], old[ITEMS];
+    // SLIM (ITEMS > 8, the 16384-id chunks): one element at a time from digit to slot - the LDS atomic's round trip is paid per
+    // element instead of once per pass and the digit is recomputed where it is needed - so that only key / position / slot are
+    // live across the pass: with the three-loop form this instantiation spilled 56 B per lane inside the 128-VGPR budget of a
+    // 1024-thread workgroup (r03 did the same to the hot-range sort of csrc/part_sort.h).  Same ranks, same result.
+    constexpr bool SLIM = ITEMS > 8;
+    auto digit = [&](int r) -> uint32_t { return (key[r] >> shift) & (RADIX - 1); };
+    uint32_t dg[SLIM ? 1 : ITEMS], rk[SLIM ? 1 : ITEMS], lead[SLIM ? 1 : ITEMS], old[ITEMS];
+    if constexpr (SLIM) {
 #pragma unroll
-    for (int r = 0; r < ITEMS; ++r) {
-      dg[r] = (key[r] >> shift) & (RADIX - 1);
-      const uint64_t peers = tt::match_any<DBITS>(dg[r]);
-      rk[r] = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
-      lead[r] = (uint32_t)__ffsll((unsigned long long)peers) - 1u;
-      old[r] = (uint32_t)__popcll(peers);                  // the leader's increment
+      for (int r = 0; r < ITEMS; ++r) {
+        const uint32_t d = digit(r);
+        const uint64_t peers = tt::match_any<DBITS>(d);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+        uint32_t o = (uint32_t)__popcll(peers);                // the leader's increment
+        if (rank == 0u) o = atomicAdd(&mycnt[d], o);
+        old[r] = (uint32_t)__shfl((int)o, (int)((uint32_t)__ffsll((unsigned long long)peers) - 1u)) + rank;   // rank inside this wave
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < ITEMS; ++r) {
+        dg[r] = digit(r);
+        const uint64_t peers = tt::match_any<DBITS>(dg[r]);
+        rk[r] = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+        lead[r] = (uint32_t)__ffsll((unsigned long long)peers) - 1u;
+        old[r] = (uint32_t)__popcll(peers);                  // the leader's increment
+      }
+#pragma unroll
+      for (int r = 0; r < ITEMS; ++r) {
+        if (rk[r] == 0u) old[r] = atomicAdd(&mycnt[dg[r]], old[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < ITEMS; ++r) old[r] = (uint32_t)__shfl((int)old[r], (int)lead[r]) + rk[r];   // rank inside this wave
     }
-#pragma unroll
-    for (int r = 0; r < ITEMS; ++r) {
-      if (rk[r] == 0u) old[r] = atomicAdd(&mycnt[dg[r]], old[r]);
-    }
-#pragma unroll
-    for (int r = 0; r < ITEMS; ++r) old[r] = (uint32_t)__shfl((int)old[r], (int)lead[r]) + rk[r];   // rank inside this wave
+    auto bucket = [&](int r) -> uint32_t { if constexpr (SLIM) return mycnt[digit(r)]; else return mycnt[dg[r]]; };
     __syncthreads();
     // ---- exclusive scan, digit-major / wave-minor; the base of the digit is folded into the per-wave offsets ----
     uint32_t v[MAXW], total = 0u;
@@ -158,13 +177,11 @@ __global__ __launch_bounds__(1024) void lds_sort_kernel(SortBatch batch) {
     __syncthreads();
     // ---- move ----
     if (p + 1 < t.npass) {
-      uint32_t dst[ITEMS];
-#pragma unroll
-      for (int r = 0; r < ITEMS; ++r) dst[r] = mycnt[dg[r]] + old[r];
 #pragma unroll
       for (int r = 0; r < ITEMS; ++r) {
-        keys[dst[r]] = key[r];
-        poss[dst[r]] = (uint16_t)pos[r];
+        const uint32_t dst = bucket(r) + old[r];
+        keys[dst] = key[r];
+        poss[dst] = (uint16_t)pos[r];
       }
       __syncthreads();
 #pragma unroll
@@ -177,7 +194,7 @@ __global__ __launch_bounds__(1024) void lds_sort_kernel(SortBatch batch) {
       // last pass: straight to global (8-byte / 4-byte scattered stores; n <= 16384 of them)
 #pragma unroll
       for (int r = 0; r < ITEMS; ++r) {
-        const uint32_t dst = mycnt[dg[r]] + old[r];
+        const uint32_t dst = bucket(r) + old[r];
         if (dst < (uint32_t)n) {
           t.sorted_ids[dst] = (int64_t)key[r];
           t.order[dst] = (int32_t)pos[r];
