@@ -269,7 +269,9 @@ class TwoTowerTrainer:
         # the embedding rows through the ids again: up to 256 columns that costs less than materialising them (cfg3: 13.6 us
         # of gather against +3.6 us in the GEMMs; cfg4 1.875 vs 1.881 ms), at 512 columns it costs more (cfg5: the layer-0
         # launches 99 us longer, the gather 55 us; step 15.28 vs 15.24 ms) - r03 A/B
-        self.fuse_lookup = os.environ.get("TT_FUSE_LOOKUP", "1" if cfg.tower_dims[0] < 512 else "0") != "0"
+        # (r04: at small batches the gather launch's fixed cost decides - the reference's own config, [512, 256, 128] at batch 1024:
+        # 0.1631-0.1638 ms fused against 0.1644-0.1654 with the gather launch)
+        self.fuse_lookup = os.environ.get("TT_FUSE_LOOKUP", "1" if (cfg.tower_dims[0] < 512 or cfg.batch_size <= 2048) else "0") != "0"
         self.fuse_sort = os.environ.get("TT_FUSE_SORT", "1") != "0"   # the optimizer launch sorts the ids itself (no plan launch)
         self.fuse_optimizer = True               # sparse + dense optimizer in one launch (False: dense_update, sparse_update2 [, cat])
         # the whole step behind ONE C call (tt_train_step_f32: the same launches - eight at cfg3 -, enqueued in C - one FFI crossing per step
