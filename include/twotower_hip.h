@@ -255,7 +255,8 @@ int tt_dense_bwd_scaled_f32(const float* x, const float* w, const float* dz,
  *   pairs  [groups][cap] uint64: bits 0..31 local key, 32..47 batch position, 48..63 generation (entries of another
  *          generation - a forward pass whose optimizer step never ran - are ignored)
  * groups / width / cap must be the ones tt_optimizer_ids_geometry reports for the step (else the optimizer ignores the lists).
- * Lists exist for n_ids <= 16384, dim <= 128.  One descriptor per table; tt_id_buckets_workspace_bytes() bytes hold one.   */
+ * Lists exist for n_ids <= 16384, dim <= 128; filled by tt_tower_fwd2_batched_f32 and by tt_dense_fwd_batched_f32 (layer 0 with a
+ * lookup).  One descriptor per table; tt_id_buckets_workspace_bytes() bytes hold one.                                          */
 typedef struct tt_id_buckets {
   uint32_t* counts; uint64_t* pairs;
   int32_t groups; uint32_t width; int32_t cap; uint32_t gen;

@@ -345,12 +345,14 @@ def test_optimizer_step_from_raw_ids_matches_plan_then_step_bit_for_bit(dev, opt
 
 
 @pytest.mark.parametrize("opt", ["sgd", "adagrad"])
-@pytest.mark.parametrize("n,dim,rows,kind", [(8192, 128, (5_000_000, 100_000), "U"), (8192, 128, (100_000, 3_000), "Z"),
-                                             (16384, 128, (1_000_000, 50_000), "Z"), (4096, 64, (20_000, 2_000), "U"),
-                                             (9000, 128, (1000, 1000), "heavy"), (1000, 32, (777, 40), "U")])
-def test_row_range_id_lists_from_the_forward_lookup_change_nothing(dev, opt, n, dim, rows, kind):
-    """r04 (ABI v9, tt_id_buckets): the fused tower forward appends every id it looks up to the list of the row range the
-    optimizer launch's sorting workgroup owns, and that launch reads its list instead of scanning all the ids.  Same tables,
+@pytest.mark.parametrize("n,dim,rows,kind,fwd", [(8192, 128, (5_000_000, 100_000), "U", "tower2"), (8192, 128, (100_000, 3_000), "Z", "tower2"),
+                                                 (16384, 128, (1_000_000, 50_000), "Z", "layer"), (4096, 64, (20_000, 2_000), "U", "layer"),
+                                                 (9000, 128, (1000, 1000), "heavy", "tower2"), (1000, 32, (777, 40), "U", "layer"),
+                                                 (1000, 32, (777, 40), "U", "tower2")])
+def test_row_range_id_lists_from_the_forward_lookup_change_nothing(dev, opt, n, dim, rows, kind, fwd):
+    """r04 (ABI v9, tt_id_buckets): the forward lookup - the fused two-layer tower forward, or layer 0's own launch - appends every
+    id it looks up to the list of the row range the optimizer launch's sorting workgroup owns, and that launch reads its list
+    instead of scanning all the ids.  Same tables,
     accumulators and dense parameters, bit for bit, as the launch that scans - for uniform ids (every workgroup finishes
     without ranks), Zipf and heavy-hitter ids (lists that overflow fall back to the scan; ranges with an id three times or
     more take the ranked path, whose global slot offset is then counted from the ids), padding / out-of-range ids, and with
@@ -400,8 +402,13 @@ def test_row_range_id_lists_from_the_forward_lookup_change_nothing(dev, opt, n, 
     oob = torch.zeros(1, dtype=torch.int32, device=dev)
 
     def forward(id_list, gen):
-        lks = [ops.make_lookup(tb[t], id_list[t], oob_flag=oob, buckets=bk.desc(t, gen)) for t in range(2)]
-        ops.tower_fwd2([None, None], w0, b0, hs, bits, w1, b0, ys, lookups=lks)
+        # "tower2": the fused two-layer forward (two-layer towers); "layer": layer 0's own launch (single-layer and deeper towers)
+        lks = [ops.make_lookup(tb[t], id_list[t], oob_flag=oob, buckets=None if gen is None else bk.desc(t, gen)) for t in range(2)]
+        if fwd == "tower2":
+            ops.tower_fwd2([None, None], w0, b0, hs, bits, w1, b0, ys, lookups=lks)
+        else:
+            ops.dense_fwd2((None, None), w0, b0, hs, relu=True, lookups=lks, relu_bits=bits)
+            ops.dense_fwd2(hs, w1, b0, ys, relu=False)
 
     if kind == "U" and n <= 4096:
         # a STALE generation first: a forward pass over other ids whose optimizer step never runs
@@ -420,8 +427,7 @@ def test_row_range_id_lists_from_the_forward_lookup_change_nothing(dev, opt, n, 
         assert int(bk.counts(t).abs().sum().item()) == 0, "counters must be left at zero"
     assert torch.equal(wa, wb)
     # the lists do not disturb the forward pass itself (tb == ta now: the same tables with and without a descriptor)
-    lks = [ops.make_lookup(ta[t], ids[t], oob_flag=oob) for t in range(2)]
-    ops.tower_fwd2([None, None], w0, b0, hs, bits, w1, b0, ys, lookups=lks)
+    forward(ids, None)
     y_plain = [y.clone() for y in ys]
     forward(ids, 8)
     assert torch.equal(y_plain[0], ys[0]) and torch.equal(y_plain[1], ys[1])

@@ -85,6 +85,10 @@ struct GemmArgs {
   const int64_t* a_ids2;
   int64_t a_rows2;
   int32_t* oob_flag;
+  // row-range id lists for the optimizer launch of the same step (tt_id_buckets; forward GEMM of layer 0 with the fused lookup):
+  // the by == 0 tile of every row block appends its 64 rows' ids, as csrc/tower.hip's fused kernel does
+  uint32_t* bk_counts; uint64_t* bk_pairs;
+  uint32_t bk_width, bk_magic, bk_groups, bk_cap, bk_gen;
 };
 
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -438,6 +442,25 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int zsplit, c
     }
     __syncthreads();
   }
+  // r04: the row-range id lists (forward of layer 0 with the fused lookup; the by == 0 tile of each row block, wave 0 alone: one
+  // load of the 64 ids - an L1 hit -, ONE returning atomic instruction for the slots, ONE 8-byte store instruction at the end)
+  [[maybe_unused]] uint32_t bslot = 0u, bgrp = 0u, blk = 0u;
+  [[maybe_unused]] bool bemit = false;
+  [[maybe_unused]] const int64_t brow = m0 + lane;
+  if constexpr (GATHER && A_KC) {
+    if (p.bk_pairs != nullptr && by == 0 && wave == 0) {                       // (wave-uniform)
+      const int64_t bid = p.a_ids[brow < p.M ? brow : m0];
+      bemit = brow < p.M && bid >= 0 && bid < p.a_rows;
+      if (bemit) {
+        const uint32_t key = (uint32_t)bid;
+        uint32_t q = __umulhi(key, p.bk_magic);
+        q -= (q * p.bk_width > key) ? 1u : 0u;
+        bgrp = q < p.bk_groups ? q : p.bk_groups - 1u;
+        blk = key - bgrp * p.bk_width;
+        bslot = __hip_atomic_fetch_add(p.bk_counts + (size_t)bgrp * tt::kBucketCountStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
   auto load_a = [&](f32x4 (&st)[NST], int t) {
     const int64_t k0 = kbeg + (int64_t)t * BK;
     if constexpr (GATHER && A_KC) load_rows_kc(st, p.A, off1, p.A2, off2, k0, kend, tid);
@@ -604,6 +627,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int zsplit, c
   if constexpr (COLSUM) {
     if (bx == 0 && tid < BN && n0 + tid < p.N) p.db_slabs[(int64_t)zsplit * p.N + n0 + tid] = colsum;
   }
+  if constexpr (GATHER && A_KC) {
+    if (bemit && bslot < p.bk_cap)                       // (a full list keeps counting: the optimizer falls back to its scan)
+      p.bk_pairs[(size_t)bgrp * p.bk_cap + bslot] = (uint64_t)blk | ((uint64_t)((uint32_t)brow & 0xffffu) << 32) | ((uint64_t)(p.bk_gen & 0xffffu) << 48);
+  }
 #ifdef TT_GEMM_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   STAMP(3);
@@ -759,6 +786,14 @@ extern "C" int tt_dense_fwd_batched_f32(const tt_dense_fwd_args* probs, int32_t 
     a[i].relu_bits = q.relu_bits;
     int rc = set_lookup(a[i], q.lookup, q.x, m, "tt_dense_fwd_f32");
     if (rc != TT_OK) return rc;
+    const tt_id_buckets& bk = q.lookup.buckets;
+    if (q.lookup.ids != nullptr && bk.pairs != nullptr) {
+      TT_REQUIRE(bk.counts != nullptr && bk.groups >= 1 && bk.width >= 1u && bk.cap >= 1 && m <= 65536,
+                 "tt_dense_fwd_f32: lookup.buckets: counts / groups / width / cap must be set (and m <= 65536)");
+      a[i].bk_counts = bk.counts; a[i].bk_pairs = bk.pairs; a[i].bk_width = bk.width; a[i].bk_groups = (uint32_t)bk.groups;
+      a[i].bk_cap = (uint32_t)bk.cap; a[i].bk_gen = bk.gen;
+      a[i].bk_magic = (uint32_t)((((uint64_t)1 << 32) / bk.width) + 1u);
+    }
     if (drop_rate > 0.f) {
       a[i].drop_p24 = (uint32_t)((double)drop_rate * 16777216.0 + 0.5);
       a[i].drop_scale = 1.0f / (1.0f - drop_rate);

@@ -46,7 +46,8 @@ extern "C" int tt_train_step_f32(const tt_train_step* s, tt_stream_t stream) {
   static std::atomic<uint32_t> generation{0};
   tt_dense_fwd_args f0[2] = {s->fwd[0][0], s->fwd[0][1]};
   tt_sparse_table_ids tabs[3] = {s->tables[0], s->tables[1], s->tables[2]};
-  if (want_lists && fwd2 && L == 2 && s->id_bucket_ws != nullptr && f0[0].lookup.ids != nullptr && f0[1].lookup.ids != nullptr &&
+  // (the lookup that fills them is the fused two-layer forward's when the towers have two layers, else layer 0's own launch)
+  if (want_lists && (Lf > 0 || L == 2) && s->id_bucket_ws != nullptr && f0[0].lookup.ids != nullptr && f0[1].lookup.ids != nullptr &&
       f0[0].lookup.ids == tabs[0].ids && f0[1].lookup.ids == tabs[1].ids && f0[0].lookup.table_rows == tabs[0].rows &&
       f0[1].lookup.table_rows == tabs[1].rows) {
     const int64_t per = tt_id_buckets_workspace_bytes();
