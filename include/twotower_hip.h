@@ -46,6 +46,9 @@ typedef void* tt_stream_t;
 
 int tt_abi_version(void);
 const char* tt_last_error(void);
+/* sizeof of the structs below as this library was built (0 tt_train_step, 1 tt_dense_fwd_args, 2 tt_dense_bwd_args,
+ * 3 tt_sparse_table_ids, 4 tt_dense_seg, 5 tt_id_buckets, 6 tt_dense_lookup; else -1): a binding checks its mirrors with it. */
+int64_t tt_abi_struct_bytes(int32_t which);
 
 /* ---------------------------------------------------------------------------------------
  * Built-in kernel timing (SURVEY.md §5 "Tracing / profiling": the reference has none).

@@ -66,3 +66,38 @@ def test_train_step_struct_is_validated_before_any_launch():
     assert lib.tt_train_step_f32(C.byref(st), None) == _lib.TT_ERR_INVALID_ARG
     assert lib.tt_tower_fwd2_supported(8192, 128, 256, 128) == 1 and lib.tt_tower_fwd2_supported(8192, 128, 512, 256) == 0
     assert lib.tt_tower_fwd2_supported(8192, 36, 128, 128) == 0 and lib.tt_tower_fwd2_supported(8192, 1024, 128, 128) == 0
+
+
+def test_ctypes_mirrors_have_the_library_struct_sizes():
+    """ABI v9 grew three structs (tt_dense_lookup, tt_sparse_table_ids, tt_train_step): a mirror that lags the header would
+    shift every later field silently - the library reports its own sizeof for each."""
+    import ctypes as C
+    lib = _lib.load()
+    for which, mirror in enumerate((_lib.TrainStep, _lib.DenseFwdArgs, _lib.DenseBwdArgs, _lib.SparseTableIds, _lib.DenseSeg,
+                                    _lib.IdBuckets, _lib.DenseLookup)):
+        assert lib.tt_abi_struct_bytes(which) == C.sizeof(mirror), (which, mirror.__name__)
+    assert lib.tt_abi_struct_bytes(99) == -1
+
+
+def test_row_range_geometry_is_a_host_query():
+    """tt_optimizer_ids_geometry / tt_id_buckets_workspace_bytes (ABI v9) answer on the host: the row ranges the fused optimizer
+    launch cuts a step's tables into - what the forward lookup must cut its id lists by - and whether the shape takes lists."""
+    import ctypes as C
+    lib = _lib.load()
+    segs = (_lib.DenseSeg * 4)()
+    for i, count in enumerate((128 * 256, 256, 128 * 256, 256)):          # layer 0 of two 128 -> 256 towers
+        segs[i].count, segs[i].slab_stride, segs[i].n_slabs = count, count, 32
+    rows = (C.c_int64 * 2)(5_000_000, 10_000_000)
+    groups, width, cap = (C.c_int32 * 2)(), (C.c_uint32 * 2)(), C.c_int32(-1)
+    assert lib.tt_optimizer_ids_geometry(rows, 2, 128, 8192, segs, 4, groups, width, C.byref(cap)) == _lib.TT_OK
+    assert list(groups) == [119, 119]                                     # (256 CUs - 18 dense blocks) / 2 tables
+    assert [w * g >= r for w, g, r in zip(width, groups, rows)] == [True, True] and cap.value == 128
+    assert lib.tt_optimizer_ids_geometry(rows, 2, 64, 4096, segs, 4, groups, width, C.byref(cap)) == _lib.TT_OK
+    assert list(groups) == [64, 64] and cap.value == 256                  # ~64 ids per range; 16 lanes per row: 4 x 64 pairs
+    assert lib.tt_optimizer_ids_geometry(rows, 2, 256, 8192, segs, 4, groups, width, C.byref(cap)) == _lib.TT_OK
+    assert cap.value == 0                                                 # dim 256: rows wider than a 32-lane group, no lists
+    assert lib.tt_optimizer_ids_geometry(rows, 2, 128, 32768, segs, 4, groups, width, C.byref(cap)) == _lib.TT_OK
+    assert cap.value == 0                                                 # beyond the one-launch optimizer's 16384 ids
+    assert lib.tt_optimizer_ids_geometry(rows, 0, 128, 8192, segs, 4, groups, width, C.byref(cap)) == _lib.TT_ERR_INVALID_ARG
+    per = lib.tt_id_buckets_workspace_bytes()
+    assert per == 256 * 256 + 256 * 256 * 8 and per % 256 == 0           # a counter per 256-byte line + 256 lists of 256 entries

@@ -102,6 +102,7 @@ _p, _i64, _i32, _u64, _f = C.c_void_p, C.c_int64, C.c_int32, C.c_uint64, C.c_flo
 SIGNATURES = {
     "tt_abi_version": (C.c_int, []),
     "tt_last_error": (C.c_char_p, []),
+    "tt_abi_struct_bytes": (_i64, [_i32]),
     "tt_profile_enable": (C.c_int, [C.c_char_p, _i32]),
     "tt_profile_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_float), _i32, C.POINTER(_i32)]),
     "tt_profile_set_stride": (C.c_int, [_i32]),

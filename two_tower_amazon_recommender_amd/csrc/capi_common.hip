@@ -136,4 +136,18 @@ extern "C" int tt_profile_read(const char* tag, float* ms, int32_t cap, int32_t*
 }
 
 extern "C" int tt_abi_version(void) { return TT_ABI_VERSION; }
+// sizeof of the ABI's structs, so that a binding can check its mirrors (which = 0 tt_train_step, 1 tt_dense_fwd_args,
+// 2 tt_dense_bwd_args, 3 tt_sparse_table_ids, 4 tt_dense_seg, 5 tt_id_buckets, 6 tt_dense_lookup; anything else: -1)
+extern "C" int64_t tt_abi_struct_bytes(int32_t which) {
+  switch (which) {
+    case 0: return (int64_t)sizeof(tt_train_step);
+    case 1: return (int64_t)sizeof(tt_dense_fwd_args);
+    case 2: return (int64_t)sizeof(tt_dense_bwd_args);
+    case 3: return (int64_t)sizeof(tt_sparse_table_ids);
+    case 4: return (int64_t)sizeof(tt_dense_seg);
+    case 5: return (int64_t)sizeof(tt_id_buckets);
+    case 6: return (int64_t)sizeof(tt_dense_lookup);
+    default: return -1;
+  }
+}
 extern "C" const char* tt_last_error(void) { return tt::err_buf(); }
