@@ -454,7 +454,7 @@ def main():
     plan_on_main = not trainer.plan_on_side_stream
     plan_bytes = 20 * batch * (2 + (1 if cfg.n_category_buckets else 0))     # id read + sorted id + position written, per table
     # the plan is on the step's critical path when it runs on the main stream (the default): then it is COUNTED
-    fused_sort = trainer.fuse_sort and trainer.fuse_optimizer and batch <= ops.sparse_plan_max_lds_ids()
+    fused_sort = trainer.one_launch_optimizer(batch)      # (after the timed steps: what the skew probe left the trainer on)
     plan_ms = (sum(unfused["sparse_plan"]) / detail_steps) if unfused.get("sparse_plan") else per_step("sparse_plan")
     if fused_sort:
         # no plan launch: the optimizer launch sorts each row range in LDS and applies the update itself.  Its WHOLE duration
@@ -528,6 +528,8 @@ def main():
                          "sparse_plan_stream": "inside the optimizer launch (un-fused detail pass figure above)" if fused_sort
                                                else ("main" if plan_on_main else "side"),
                          "sort_fused_into_optimizer_launch": bool(fused_sort),
+                         "skew_probe": {"largest_row_range_load": int(trainer.range_load), "limit": int(trainer.skew_limit),
+                                        "path": "one launch" if fused_sort else "plan + optimizer step"},
                          "frac_without_plan": (gs_bytes - (plan_bytes if (plan_on_main or fused_sort) else 0)) / t_gs_noplan / 1e9 / HBM_PEAK_GBS,
                          "algorithmic_bytes": gs_bytes},
         "loss_per_pair": loss / batch,

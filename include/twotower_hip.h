@@ -348,10 +348,14 @@ typedef struct tt_sparse_table {
 int tt_optimizer_step_f32(int32_t opt, const tt_sparse_table* tables, int32_t n_tables, int32_t dim, int64_t n_ids,
                           const tt_dense_seg* segs, int32_t n_segs, float lr, float eps, tt_stream_t stream);
 
-/* The same step from the RAW ids (n_ids <= tt_sparse_plan_max_lds_ids(), else TT_ERR_UNSUPPORTED): no tt_sparse_plan
- * launch and no sorted ids in HBM — the sorting workgroups of each table (one per row range) apply the update to their
- * own rows inside the one optimizer launch.  Same results, bit for bit, as tt_sparse_plan_batched +
- * tt_optimizer_step_f32 (same piece boundaries at global multiples of 64 sorted slots).                            */
+/* The same step from the RAW ids (n_ids <= tt_optimizer_ids_max_ids() = 65536, else TT_ERR_UNSUPPORTED): no
+ * tt_sparse_plan launch and no sorted ids in HBM — the sorting workgroups of each table (one per row range) apply the
+ * update to their own rows inside the one optimizer launch.  Same results, bit for bit, as tt_sparse_plan_batched +
+ * tt_optimizer_step_f32 (same piece boundaries at global multiples of 64 sorted slots).  Lists of more than
+ * tt_sparse_plan_max_lds_ids() (16384) ids take the long-list kernel (r04: ids scanned in chunks, the LDS list keeps
+ * 16384 slots; a row range that holds more ids than that - a degenerate batch - is sorted in a global scratch inside
+ * apply_ws, which tt_sparse_apply_workspace_bytes sizes for it).                                                   */
+int32_t tt_optimizer_ids_max_ids(void);
 typedef struct tt_sparse_table_ids {
   float* table; float* accum;            /* [rows, dim]; accum NULL for SGD        */
   int64_t rows;
@@ -365,6 +369,14 @@ typedef struct tt_sparse_table_ids {
 int tt_optimizer_ids_geometry(const int64_t* table_rows, int32_t n_tables, int32_t dim, int64_t n_ids,
                               const tt_dense_seg* segs, int32_t n_segs, int32_t* groups, uint32_t* width, int32_t* cap);
 int64_t tt_id_buckets_workspace_bytes(void);      /* one table's counts + pairs, 256-byte aligned inside */
+/* A trainer's skew probe (r04): out_max[t] (DEVICE, [n_tables]) = the largest number of this batch's ids that fall into ONE
+ * of table t's row ranges (the ranges of tt_optimizer_ids_geometry).  The one-launch optimizer gives a range to one
+ * workgroup: ids uniform over the rows put n_ids / groups in each, a vocabulary in order of frequency puts thousands into
+ * the first (cfg3, ids ~ rows * u^4: launch 12 -> 169 us).  Run every few dozen steps, copy the words to pinned host memory
+ * without waiting, and take tt_sparse_plan_batched + tt_optimizer_step_f32 while a range holds more than ~512 ids.
+ * ids: HOST array of n_tables device pointers.  One launch, one workgroup per table.                                    */
+int tt_id_range_load(const int64_t* const* ids, const int64_t* table_rows, int32_t n_tables, int32_t dim, int64_t n_ids,
+                     const tt_dense_seg* segs, int32_t n_segs, int32_t* out_max, tt_stream_t stream);
 int tt_optimizer_step_ids_f32(int32_t opt, const tt_sparse_table_ids* tables, int32_t n_tables, int32_t dim, int64_t n_ids,
                               const tt_dense_seg* segs, int32_t n_segs, float lr, float eps, tt_stream_t stream);
 
@@ -382,7 +394,7 @@ int tt_optimizer_step_ids_f32(int32_t opt, const tt_sparse_table_ids* tables, in
  * It exists for the HOST side: a caller that reaches the library through an FFI (ctypes: ~7 us per call) pays that once per
  * step instead of once per launch - cfg1 (B 256) is 7 launches of a few us each.  Results are identical to the separate
  * calls, bit for bit.
- * Both towers must have the same layer shapes (the batched launches); batch <= 16384 (tt_optimizer_step_ids_f32) and
+ * Both towers must have the same layer shapes (the batched launches); batch <= 65536 (tt_optimizer_step_ids_f32) and
  * <= 32768 with a fused lookup.                                                                                       */
 #define TT_MAX_TOWER_LAYERS 8
 typedef struct tt_train_step {

@@ -172,10 +172,14 @@ def _np_plan(ids, rows):
                                             (8192, 10_000_000, "U"), (8192, 5_000_000, "Z"), (8192, 30, "Z"),
                                             (8192, 100_000_000, "Z"), (16384, 100_000_000, "U"), (12345, 70_000, "Z"),
                                             (16385, 10_000_000, "Z"), (40000, 257, "U"), (32768, 48_000_000, "Z"),
-                                            (100_000, 30, "Z"), (262_144, 15_000_000, "U"), (300_000, 1000, "Z")])
+                                            (100_000, 30, "Z"), (262_144, 15_000_000, "U"), (300_000, 1000, "Z"),
+                                            (65536, 3, "U"), (50000, 1, "U"), (65536, 2_000_000_000, "U"), (20000, 2_000_000_000, "Z"),
+                                            (65536, 100_000, "Z"), (16385, 2, "U")])
 def test_sort_plan_is_a_stable_sort_for_every_size_and_key_width(dev, n, rows, variant):
-    """<= 16384 ids: the hand-written one-launch LDS radix sort (1-4 passes of 8/9-bit digits); up to 262144: 16384-id
-    chunks sorted in one launch + a rank-merge launch; above: rocPRIM."""
+    """<= 16384 ids: the hand-written one-launch LDS radix sort (1-4 passes of 8/9-bit digits); 16,385 .. 65,536 (r04): one
+    launch with key ranges cut by the data (sample quantiles; a key held more than 16384 times is sorted in the global
+    scratch: the 3-row, 2-row and 1-row tables); up to 262144: 16384-id chunks sorted in one launch + a rank-merge launch;
+    above: rocPRIM."""
     ids = synth.batch_ids(31, 3, 0, n, rows, variant)
     plan = ops.SparsePlan(n, dev).run(T(ids, dev), rows)
     sk, so = _np_plan(ids, rows)
@@ -196,6 +200,50 @@ def test_sort_plan_batched_three_tables_one_launch_with_padding_and_out_of_range
         sk, so = _np_plan(i, r)
         assert np.array_equal(p.sorted_ids.cpu().numpy(), sk)
         assert np.array_equal(p.order.cpu().numpy(), so)
+
+
+def test_sort_plan_batched_long_lists_with_padding_and_out_of_range_ids(dev):
+    """Two long lists (the data-cut one-launch plan) with -1 padding / out-of-range ids (clamped to the sentinel, sorted last - a
+    third of one list: a long run of the sentinel) next to a short list in the same call."""
+    ns, rows = [40000, 40000, 5000], [5_000_000, 777, 30]
+    ids = [synth.batch_ids(34, 3 + t, 0, n, r, "Z" if t != 1 else "U") for t, (n, r) in enumerate(zip(ns, rows))]
+    ids[0][100:14000] = -1
+    ids[0][20000] = 5_000_000 + 9
+    ids[1][7] = 777 + 5
+    ids[1][39999] = -77
+    plans = [ops.SparsePlan(n, dev) for n in ns]
+    ops.sparse_plan_batched(plans, [T(i, dev) for i in ids], rows)
+    for p, i, r in zip(plans, ids, rows):
+        sk, so = _np_plan(i, r)
+        assert np.array_equal(p.sorted_ids.cpu().numpy(), sk)
+        assert np.array_equal(p.order.cpu().numpy(), so)
+
+
+@pytest.mark.parametrize("n,dim,rows,kind", [(8192, 128, (10_000_000, 5_000_000), "U"), (8192, 128, (10_000_000, 5_000_000), "Z"),
+                                             (32768, 256, (2_000_000, 30), "Z"), (300, 32, (5, 1), "U")])
+def test_id_range_load_is_the_fullest_row_range_of_the_optimizer_geometry(dev, n, dim, rows, kind):
+    """tt_id_range_load (the trainers' skew probe) against NumPy: ids per row range of tt_optimizer_ids_geometry, out-of-range
+    and padding ids in no range; power-law ids put ~30 % of the batch into the first range."""
+    rng = np.random.default_rng(8)
+    w = T(np.zeros(1000, np.float32), dev)
+    segs = [ops.make_dense_seg(w, None, T(np.zeros((1, 1000), np.float32), dev), 1, 0.0)]
+    geo = ops.IdBuckets(list(rows), dim, n, segs, dev)
+    ids = []
+    for t, r in enumerate(rows):
+        x = (synth.ids_powerlaw(5, 3 + t, n, r) if kind == "Z" else rng.integers(0, r, n)).astype(np.int64)
+        x[rng.integers(0, n, 7)] = -1
+        x[rng.integers(0, n, 7)] = r + 1
+        ids.append(x)
+    out = torch.full((4,), -1, dtype=torch.int32, device=dev)
+    ops.id_range_load_(out, [T(x, dev) for x in ids], list(rows), dim, segs)
+    got = out.cpu().numpy()
+    for t, (x, r) in enumerate(zip(ids, rows)):
+        ok = x[(x >= 0) & (x < r)]
+        g = np.minimum(ok // geo.width[t], geo.groups[t] - 1)
+        assert got[t] == np.bincount(g, minlength=geo.groups[t]).max(), (t, got)
+    assert got[2] == -1                               # (tables beyond n_tables untouched)
+    if kind == "Z" and n == 8192:
+        assert got[0] > 0.25 * n
 
 
 def test_out_of_range_id_cannot_alias_a_valid_row(dev):
@@ -287,7 +335,13 @@ def test_sparse_heavy_hitters_are_split_into_pieces_bit_exact(dev, opt, n):
                                              (16384, 128, (1_000_000, 50_000), "Z"), (1000, 32, (777, 40), "U"),
                                              (4096, 256, (20_000, 20_000), "Z"), (9000, 128, (1000, 1000), "heavy"),
                                              (300, 64, (5, 1), "U"), (8192, 128, (100_000, 5_000), "U"),
-                                             (512, 32, (2_000, 1_500), "U"), (4096, 64, (20_000, 2_000), "U")])
+                                             (512, 32, (2_000, 1_500), "U"), (4096, 64, (20_000, 2_000), "U"),
+                                             # r04, the long-list kernel (16,385 .. 65,536 ids): cfg5's shape; ragged n; hot ranges
+                                             # sorted in LDS from the unordered list; ranges of more ids than the LDS list holds
+                                             # (tables of 5 rows / 1 row / 30 rows: sorted in the global scratch)
+                                             (32768, 256, (2_000_000, 1_000_000), "Z"), (20000, 128, (5_000_000, 100_000), "U"),
+                                             (32768, 128, (1000, 1000), "heavy"), (65536, 32, (100_000, 40), "Z"),
+                                             (40000, 64, (5, 1), "U"), (50000, 128, (300_000, 3), "heavy")])
 def test_optimizer_step_from_raw_ids_matches_plan_then_step_bit_for_bit(dev, opt, n, dim, rows, kind):
     """tt_optimizer_step_ids_f32 — the optimizer launch sorts the ids of each row range in LDS and updates those rows
     itself, no plan launch, no sorted ids in HBM — against tt_sparse_plan_batched + tt_optimizer_step_f32 (itself
@@ -339,8 +393,8 @@ def test_optimizer_step_from_raw_ids_matches_plan_then_step_bit_for_bit(dev, opt
     changed = (tb[0] != T(synth.embedding_table(7, 1, rows3[0], dim), dev)).any(1)
     assert changed.sum().item() > 0
     with pytest.raises(NotImplementedError):
-        big = ops.SparsePlan(20000, dev)
-        ops.optimizer_step_ids_(opt, [(tb[0], ab[0], torch.empty(20000, dim, device=dev), torch.zeros(20000, dtype=torch.int64, device=dev), big)],
+        big = ops.SparsePlan(70000, dev)
+        ops.optimizer_step_ids_(opt, [(tb[0], ab[0], torch.empty(70000, dim, device=dev), torch.zeros(70000, dtype=torch.int64, device=dev), big)],
                                 [ops.make_dense_seg(wb, waccb, wslab, 4, 1e-6)], 0.01, 1e-7)
 
 

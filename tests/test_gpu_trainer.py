@@ -357,6 +357,35 @@ def test_out_of_range_id_is_reported_by_the_periodic_poll_with_its_step(dev):
     tr.check_ids()                                  # flag was cleared by the raise
 
 
+def test_skew_probe_moves_the_steps_to_the_plan_path_and_back_without_changing_a_bit(dev):
+    """r04: ids that crowd a few row ranges (ids ~ rows * u^4: a vocabulary in order of frequency) make ONE workgroup of the
+    one-launch optimizer sort and apply a third of the batch.  The trainer's probe (tt_id_range_load every `flag_poll_every`
+    steps, read from pinned memory when it has landed - never waited for) sees the overloaded range and the following steps
+    take plan + optimizer step; uniform batches bring the one-launch form back.  Both paths are bit-identical, so a trainer
+    that never switches (skew_limit 0) must end in exactly the same state."""
+    cfg = TwoTowerConfig(n_users=2_000_000, n_items=1_000_000, embedding_dim=64, tower_dims=[128, 64], temperature=0.1,
+                         l2_regularization=1e-6, learning_rate=0.001, optimizer="adagrad", batch_size=8192)
+    a = TwoTowerTrainer(cfg, dev, seed=41)
+    b = TwoTowerTrainer(TwoTowerConfig(**cfg.__dict__), dev, seed=41)
+    b.skew_limit = 0
+    a.flag_poll_every = 3
+    assert a.skew_limit == 512 and a.one_launch_optimizer(cfg.batch_size)
+    paths = []
+    for step in range(16):
+        variant = "Z" if step < 8 else "U"
+        u, i = a.synthetic_batch(41, step, variant)
+        la = a.step(u, i).clone()
+        torch.cuda.synchronize()                      # (the test's own wait, so that "has landed" is deterministic)
+        paths.append(a.one_launch_optimizer(cfg.batch_size))
+        lb = b.step(u, i).clone()
+        assert torch.equal(la, lb), step
+    # probe at step 0 (power-law ids) -> read at step 1: plan path from step 1 on; probe at step 9 (uniform) -> back at step 10
+    assert paths[0] is True and not any(paths[1:9]) and all(paths[10:]), paths
+    assert a.range_load <= 512 and b.range_load == 0
+    assert torch.equal(a.user_table, b.user_table) and torch.equal(a.item_table, b.item_table)
+    assert torch.equal(a.user_accum, b.user_accum) and torch.equal(a.dense_flat, b.dense_flat)
+
+
 def test_out_of_range_id_is_reported(dev):
     cfg, tr, _ = make(dev, 100, 100, 32, [32], 256, "sgd", 5)
     u, i = tr.synthetic_batch(5, 0)

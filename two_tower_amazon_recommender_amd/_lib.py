@@ -122,6 +122,7 @@ SIGNATURES = {
     "tt_sparse_plan": (C.c_int, [_p, _i64, _i64, _p, _i64, _p, _p, _p]),
     "tt_sparse_plan_batched": (C.c_int, [_p, _i32, _p]),
     "tt_sparse_plan_max_lds_ids": (_i32, []),
+    "tt_optimizer_ids_max_ids": (_i32, []),
     "tt_sparse_apply_workspace_bytes": (_i64, [_i64, _i32]),
     "tt_sparse_sgd_f32": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _i64, _f, _p, _p]),
     "tt_sparse_adagrad_f32": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _i64, _f, _f, _p, _p]),
@@ -143,6 +144,7 @@ SIGNATURES = {
     "tt_optimizer_ids_geometry": (C.c_int, [C.POINTER(_i64), _i32, _i32, _i64, C.POINTER(DenseSeg), _i32, C.POINTER(_i32),
                                             C.POINTER(C.c_uint32), C.POINTER(_i32)]),
     "tt_id_buckets_workspace_bytes": (_i64, []),
+    "tt_id_range_load": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(_i64), _i32, _i32, _i64, C.POINTER(DenseSeg), _i32, _p, _p]),
     "tt_train_step_f32": (C.c_int, [C.POINTER(TrainStep), _p]),
     "tt_retrieval_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "tt_retrieval_fwd_workspace_bytes": (_i64, [_i64, _i64, _i32]),

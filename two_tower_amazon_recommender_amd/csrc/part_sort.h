@@ -5,6 +5,7 @@
 namespace tt {
 
 constexpr int kPartSortMaxIds = 16384;   // ids one workgroup can hold in LDS (positions are u16)
+constexpr int kPartSortBigMaxIds = 65536;   // the fused optimizer's long-list form (part_scan_append_big ...): positions still fit u16
 
 template <int DBITS>
 __device__ __forceinline__ uint64_t match_any(uint32_t d) {
@@ -61,7 +62,13 @@ __device__ __forceinline__ uint32_t bucket_of(uint32_t key, const PartTable& t) 
 
 template <int DBITS, int RMAX, bool TO_GLOBAL>
 __device__ __forceinline__ void part_local_sort(const PartTable& t, uint32_t* keys, uint16_t* poss, uint32_t* cnt, uint32_t* wtot,
-                                                uint32_t m, uint32_t offset, uint32_t base_key, int npass) {
+                                                uint32_t m, uint32_t offset, uint32_t base_key, int npass, int ppass = 0,
+                                                uint32_t diff = 0xffffffffu) {
+  // ppass > 0 (a list in NO particular order: part_sort_hot_unordered): the first ppass passes run over the digits of the batch
+  // POSITION, the rest over the key's - the result is ordered by (key, position) as if the list had started in position order.
+  // diff: bits in which the keys of the list differ at all (default: unknown = all).  A key pass over a digit that is the same
+  // in every key is skipped - a range that is ONE id thousands of times (what makes a data-cut range hot) takes the position
+  // passes only; the padding's position is all-ones for that (it ties with position 65535 at most, behind which it started).
   constexpr int RADIX = 1 << DBITS;
   constexpr int W = 16, T = 1024;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -70,16 +77,21 @@ __device__ __forceinline__ void part_local_sort(const PartTable& t, uint32_t* ke
   uint32_t key[RMAX], pos[RMAX];
 #pragma unroll
   for (int r = 0; r < RMAX; ++r) {
-    key[r] = 0xffffffffu; pos[r] = 0u;
+    key[r] = 0xffffffffu; pos[r] = ppass > 0 ? 0xffffffffu : 0u;   // (padding: last under the position passes too)
     if (r < rounds) {
       const uint32_t e = (uint32_t)((w * rounds + r) * 64 + lane);
       if (e < m) { key[r] = keys[e]; pos[r] = poss[e]; }
     }
   }
   uint32_t* mycnt = cnt + w * RADIX;
-  for (int p = 0; p < npass; ++p) {
+  int plast = npass - 1;                                    // the last pass that runs (TO_GLOBAL: it writes the output)
+  while (plast >= ppass && ((diff >> ((plast - ppass) * DBITS)) & (RADIX - 1)) == 0u) --plast;
+  if (plast < 0) plast = 0;                                 // (a list of equal keys in position order: one pass, over digit 0)
+  for (int p = 0; p <= plast; ++p) {
+    const bool by_pos = p < ppass;
+    const int shift = (by_pos ? p : p - ppass) * DBITS;
+    if (!by_pos && p < plast && ((diff >> shift) & (RADIX - 1)) == 0u) continue;
     __syncthreads();                                        // the loads above / of the previous pass are done
-    const int shift = p * DBITS;
     for (int j = lane; j < RADIX; j += 64) mycnt[j] = 0u;
     // SLIM (the 16-round instantiation: a hot row range of more than 6144 keys in a list of up to 16384): one element at a
     // time from digit to slot - the LDS atomic's round trip is paid per element instead of once per pass, and the digit is
@@ -87,7 +99,7 @@ __device__ __forceinline__ void part_local_sort(const PartTable& t, uint32_t* ke
     // of 96 (with the three-loop form this instantiation spilled 92 B per lane inside the 128-VGPR budget of a 1024-thread
     // workgroup).  The shorter instantiations keep the three loops: their atomics overlap.
     constexpr bool SLIM = RMAX > 8;
-    auto digit = [&](int r) -> uint32_t { return (key[r] >> shift) & (RADIX - 1); };
+    auto digit = [&](int r) -> uint32_t { return ((by_pos ? pos[r] : key[r]) >> shift) & (RADIX - 1); };
     uint32_t dg[SLIM ? 1 : RMAX], rk[SLIM ? 1 : RMAX], lead[SLIM ? 1 : RMAX], old[RMAX];
     if constexpr (SLIM) {
 #pragma unroll
@@ -148,7 +160,7 @@ __device__ __forceinline__ void part_local_sort(const PartTable& t, uint32_t* ke
       for (int ww = 0; ww < W; ++ww) cnt[ww * RADIX + tid] = base + v[ww];
     }
     __syncthreads();
-    if (p + 1 < npass || !TO_GLOBAL) {          // (!TO_GLOBAL: the last pass too leaves the sorted pairs in LDS)
+    if (p < plast || !TO_GLOBAL) {              // (!TO_GLOBAL: the last pass too leaves the sorted pairs in LDS)
 #pragma unroll
       for (int r = 0; r < RMAX; ++r)
         if (r < rounds) {
@@ -461,6 +473,223 @@ __device__ __forceinline__ uint32_t part_sort_body(const PartTable& t, const int
   if (m <= kPartRankMax) part_rank_small<DBITS, TO_GLOBAL>(t, cap, smem, m, offset, base_key);
   else part_sort_hot<DBITS, JMAX, TO_GLOBAL>(t, g, cap, smem, sc, m, offset, base_key);
   return m;
+}
+
+// ---- lists of more than kPartSortMaxIds ids (the fused optimizer; n <= kPartSortBigMaxIds: positions are still u16) ----
+// The LDS list keeps its 16384 slots and the ids are scanned in chunks of 16 x 1024; nothing of the scan is kept in registers
+// across chunks: a hot range (> kPartRankMax ids) is sorted from the UNORDERED list (position passes first,
+// part_sort_hot_unordered), and a range with more ids than the LDS list holds in a global scratch (part_sort_global).
+// (Tried in r04 and dropped: ranges cut BY THE DATA - every workgroup sorts the same 512 sampled ids and takes two quantiles of
+// the sample as its range.  It evens out a power-law batch (optimizer launch 1124 -> 258-322 us at 2 x 32768 ids, dim 256),
+// but 4 samples per range leave ranges of 2-3x the mean, and the slowest workgroup is the launch: uniform ids 93 -> 128-155 us;
+// as a PLAN it took 58-85 us against 53 us for r03's chunk sorts + merge - ranking 256-1024 ids by counting is 17-68 us of VALU
+// time on one CU.  What handles skew instead is the trainer's choice of path from a lagged load probe, tt_id_range_load.)
+__device__ __forceinline__ uint32_t part_range_span(const PartTable& t, const int g, uint32_t& base_key) {
+  base_key = (uint32_t)g * t.width;
+  return (g == t.groups - 1) ? (base_key <= t.sentinel ? t.sentinel - base_key + 1u : 0u) : t.width;
+}
+
+// Scan + unordered append of the range [base_key, base_key + span).  Returns m = the range's ids (may exceed cap: then only
+// the first cap appended pairs are in LDS and the caller must take the global path), offset = ids sorting below the range.
+// DROP_OOR as in part_scan_append.
+// diff = the bits in which the range's local keys differ at all (0: the range is ONE id; the radix paths skip those digits).
+template <int DBITS, bool DROP_OOR>
+__device__ __forceinline__ uint32_t part_scan_append_big(const PartTable& t, const uint32_t base_key, const uint32_t span, const int cap,
+                                                         uint32_t* smem, uint32_t& offset, uint32_t& diff) {
+  constexpr int RADIX = 1 << DBITS;
+  constexpr int W = 16, T = 1024, JC = 16;
+  uint32_t* keys = smem;
+  uint32_t* ctr = keys + cap + 64 + W * RADIX + 16 * W + 32;
+  uint16_t* poss = reinterpret_cast<uint16_t*>(ctr + 16);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const __attribute__((address_space(1))) int64_t* ids = (const __attribute__((address_space(1))) int64_t*)t.ids;
+  const int64_t num_rows = t.num_rows;
+  const int n = t.n, last = n - 1;
+  const uint32_t oor = DROP_OOR ? 0xffffffffu : t.sentinel;
+  if (tid == 0) { ctr[0] = 0u; ctr[1] = 0u; ctr[2] = 0u; ctr[3] = 0xffffffffu; }
+  __syncthreads();
+  uint32_t k_or = 0u, k_and = 0xffffffffu;
+  for (int c0 = 0; c0 < n; c0 += JC * T) {                  // (workgroup-uniform)
+    int64_t raw[JC];
+#pragma unroll
+    for (int j = 0; j < JC; ++j) {
+      const int i = c0 + j * T + tid;
+      raw[j] = ids[i < last ? i : last];
+    }
+    // (the own-range ballots are taken twice - once for the counts, once for the slots - instead of being kept: 16 wave masks
+    // are 32 SGPRs across the LDS atomic's round trip, and the kernel around this already spills SGPRs to VGPR lanes)
+    uint32_t kj[JC];
+    uint32_t below = 0u, wave_mine = 0u;
+#pragma unroll
+    for (int j = 0; j < JC; ++j) {
+      const int i = c0 + j * T + tid;
+      const int64_t id = raw[j];
+      const uint32_t k = (id >= 0 && id < num_rows) ? (uint32_t)id : oor;
+      kj[j] = i < n ? k : 0xffffffffu;                      // past n: no range (span never reaches the all-ones key)
+      wave_mine += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(kj[j] - base_key < span));
+      below += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(kj[j] < base_key));
+    }
+    uint32_t wbase = 0u;
+    if (lane == 0) {
+      wbase = atomicAdd(&ctr[0], wave_mine);
+      atomicAdd(&ctr[1], below);
+    }
+    wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+#pragma unroll
+    for (int j = 0; j < JC; ++j) {
+      const bool mine = kj[j] - base_key < span;
+      const uint64_t mk = __builtin_amdgcn_ballot_w64(mine);
+      if (mine) {
+        const uint32_t dst = wbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+        const uint32_t lk = kj[j] - base_key;
+        k_or |= lk;
+        k_and &= lk;
+        if (dst < (uint32_t)cap) {
+          keys[dst] = lk;
+          poss[dst] = (uint16_t)(c0 + j * T + tid);
+        }
+      }
+      wbase += (uint32_t)__popcll(mk);
+    }
+  }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    k_or |= (uint32_t)__shfl_xor((int)k_or, o);
+    k_and &= (uint32_t)__shfl_xor((int)k_and, o);
+  }
+  if (lane == 0) { atomicOr(&ctr[2], k_or); atomicAnd(&ctr[3], k_and); }
+  __syncthreads();
+  SSTAMP(2);
+  const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctr[0]);
+  offset = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctr[1]);
+  diff = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ctr[2] & ~ctr[3]));
+  return m;
+}
+
+// A hot range of the long-list form (kPartRankMax < m <= cap): LSD radix passes over the position digits, then the key digits.
+template <int DBITS, bool TO_GLOBAL>
+__device__ __forceinline__ void part_sort_hot_unordered(const PartTable& t, const uint32_t span, const int cap, uint32_t* smem,
+                                                        const uint32_t m, const uint32_t offset, const uint32_t base_key, const uint32_t diff) {
+  constexpr int RADIX = 1 << DBITS;
+  constexpr int W = 16, T = 1024;
+  uint32_t* keys = smem;
+  uint32_t* cnt = keys + cap + 64;
+  uint32_t* wtot = cnt + W * RADIX + 16 * W;
+  uint16_t* poss = part_poss<DBITS>(smem, cap);
+  __syncthreads();                                          // everyone has read the counters
+  const int lbits = 32 - __builtin_clz((span - 1u) | 1u);
+  const int pbits = 32 - __builtin_clz((uint32_t)(t.n - 1) | 1u);
+  const int ppass = (pbits + DBITS - 1) / DBITS, npass = ppass + (lbits + DBITS - 1) / DBITS;
+  if (m <= 2u * T) part_local_sort<DBITS, 2, TO_GLOBAL>(t, keys, poss, cnt, wtot, m, offset, base_key, npass, ppass, diff);
+  else if (m <= 6u * T) part_local_sort<DBITS, 6, TO_GLOBAL>(t, keys, poss, cnt, wtot, m, offset, base_key, npass, ppass, diff);
+  else part_local_sort<DBITS, 16, TO_GLOBAL>(t, keys, poss, cnt, wtot, m, offset, base_key, npass, ppass, diff);
+}
+
+// A range with more ids than the LDS list holds (m > cap: one id repeated more than 16384 times): its (local key << 16 |
+// position) words are appended to a global scratch and sorted there by this ONE workgroup - LSD radix, 4-bit digits, every
+// thread owns a contiguous block of the list and one column of the [16][1024] LDS histogram (count, scan in digit-major /
+// thread-minor order, stable scatter).  L2-resident scratch, ~10 passes of two reads and one write per element: a hundred
+// microseconds and more, on a path only a degenerate batch takes.  g0 / g1: m words each, private to this range (the callers
+// pass scratch + offset).  Returns the buffer that holds the sorted words; ends with a barrier.
+template <bool DROP_OOR>
+__device__ __forceinline__ uint64_t* part_sort_global(const PartTable& t, const uint32_t base_key, const uint32_t span, uint32_t* smem,
+                                                      uint64_t* g0, uint64_t* g1, const uint32_t m, const uint32_t diff) {
+  constexpr int T = 1024, JC = 16;
+  uint32_t* hist = smem;                                    // [16][T] (64 KB = the key list's 16384 slots)
+  uint32_t* wtot = smem + 16 * T;                           // [16]  (the padding behind the key list)
+  uint32_t* ctr = smem + 16 * T + 32;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const __attribute__((address_space(1))) int64_t* ids = (const __attribute__((address_space(1))) int64_t*)t.ids;
+  const int64_t num_rows = t.num_rows;
+  const int n = t.n, last = n - 1;
+  const uint32_t oor = DROP_OOR ? 0xffffffffu : t.sentinel;
+  __syncthreads();                                          // the LDS list is dead
+  if (tid == 0) ctr[0] = 0u;
+  __syncthreads();
+  for (int c0 = 0; c0 < n; c0 += JC * T) {
+    int64_t raw[JC];
+#pragma unroll
+    for (int j = 0; j < JC; ++j) {
+      const int i = c0 + j * T + tid;
+      raw[j] = ids[i < last ? i : last];
+    }
+#pragma unroll
+    for (int j = 0; j < JC; ++j) {
+      const int i = c0 + j * T + tid;
+      const int64_t id = raw[j];
+      const uint32_t k = i < n ? ((id >= 0 && id < num_rows) ? (uint32_t)id : oor) : 0xffffffffu;
+      const bool mine = k - base_key < span;
+      const uint64_t mk = __builtin_amdgcn_ballot_w64(mine);
+      uint32_t wbase = 0u;
+      if (lane == 0 && mk != 0ull) wbase = atomicAdd(&ctr[0], (uint32_t)__popcll(mk));
+      wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+      if (mine) {
+        const uint32_t dst = wbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+        g0[dst] = ((uint64_t)(k - base_key) << 16) | (uint64_t)(uint32_t)i;
+      }
+    }
+  }
+  const int lbits = 32 - __builtin_clz((span - 1u) | 1u);
+  const int pbits = 32 - __builtin_clz((uint32_t)(n - 1) | 1u);
+  const uint32_t E = (m + T - 1) / T;                       // elements per thread (<= 64)
+  const uint32_t lo = (uint32_t)tid * E < m ? (uint32_t)tid * E : m, hi = lo + E < m ? lo + E : m;
+  uint64_t* src = g0;
+  uint64_t* dst = g1;
+  const int ppass = (pbits + 3) / 4, npass = ppass + (lbits + 3) / 4;
+  constexpr int U = 8;                                      // words a thread loads before it touches its histogram column
+  for (int p = 0; p < npass; ++p) {
+    const int shift = p < ppass ? 4 * p : 16 + 4 * (p - ppass);
+    if (p >= ppass && ((diff >> (4 * (p - ppass))) & 15u) == 0u) continue;      // a digit every key of the range shares
+#pragma unroll
+    for (int d = 0; d < 16; ++d) hist[d * T + tid] = 0u;
+    __syncthreads();                                        // the appended / scattered words of every thread are visible
+    for (uint32_t e0 = lo; e0 < hi; e0 += U) {
+      uint64_t v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = src[e0 + u < hi ? e0 + u : hi - 1u];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (e0 + u < hi) hist[((uint32_t)(v[u] >> shift) & 15u) * T + tid] += 1u;       // (this thread's own column)
+    }
+    __syncthreads();
+    // exclusive scan of the 16 * T counts in index order (digit major, thread minor): thread q takes indices [16 q, 16 q + 16)
+    uint32_t x[16], total = 0u;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const uint32_t v = hist[16 * tid + k];
+      x[k] = total;
+      total += v;
+    }
+    uint32_t incl = total;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+      if (lane >= o) incl += up;
+    }
+    if (lane == 63) wtot[w] = incl;
+    __syncthreads();
+    uint32_t base = incl - total;
+    for (int ww = 0; ww < w; ++ww) base += wtot[ww];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) hist[16 * tid + k] = base + x[k];
+    __syncthreads();
+    for (uint32_t e0 = lo; e0 < hi; e0 += U) {
+      uint64_t v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = src[e0 + u < hi ? e0 + u : hi - 1u];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (e0 + u < hi) {
+          const uint32_t d = (uint32_t)(v[u] >> shift) & 15u;
+          const uint32_t at = hist[d * T + tid];
+          hist[d * T + tid] = at + 1u;
+          dst[at] = v[u];
+        }
+    }
+    uint64_t* sw = src; src = dst; dst = sw;
+  }
+  __syncthreads();
+  return src;
 }
 
 }  // namespace tt

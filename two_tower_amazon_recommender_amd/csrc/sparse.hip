@@ -37,6 +37,10 @@ struct ApplyArgs {
   float* p_sum[kMaxSparseTables];      // [nblk][dim]  first piece of a run that continues past its block (head in block j)
   float* s_sum[kMaxSparseTables];      // [nblk][dim]  piece starting exactly at slot 64*j
   int32_t* p_flag[kMaxSparseTables];   // [nblk]       arrival ticket of the deferred run whose head is in block j (0 between launches)
+  // n_ids > tt::kPartSortMaxIds only (the fused optimizer's long-list form, part_sort_global): 2 x n words, n keys, n positions
+  uint64_t* big_pairs[kMaxSparseTables];
+  uint32_t* big_keys[kMaxSparseTables];
+  uint16_t* big_pos[kMaxSparseTables];
 };
 
 // NT: the updated rows leave with nontemporal stores.  Only the fused optimizer launch's rank-free path uses them (fast_apply:
@@ -814,10 +818,70 @@ __global__ __launch_bounds__(1024) void optimizer_ids_kernel(ApplyArgs a, FusedT
   }
 }
 
+// ---- the same launch for lists of 16,385 .. 65,536 ids per table (r04; cfg5 un-sharded: 32,768) ----
+// r03 sent these through tt_sparse_plan (chunk sorts + merge: 70-82 us at cfg5) and the separate apply kernel (85 us).  Here
+// the sorting workgroups keep their 16384-slot LDS list and scan the ids in chunks (csrc/part_sort.h, the long-list section);
+// the row ranges are the same ~120 per table, so the usual range holds n/120 ~ 270 ids: rows requested per unordered pair,
+// ranked by counting, applied - the short-list kernel's general path.  A hot range (> 512 ids) is radix-sorted in LDS from the
+// unordered list; a range with more ids than the LDS list holds is sorted in the apply workspace's global scratch and applied
+// from there (correct for any batch, fast for none that has such a range: a trainer watches tt_id_range_load and takes the
+// plan + apply path while its batches are that skewed).  No row-range id lists here.  Measured (2 x 32768 ids, dim 256,
+// Adagrad, uniform ids): 93 us against 113 us for plan (53) + apply (60).
+template <int OPT, int DBITS>
+__global__ __launch_bounds__(1024) void optimizer_ids_big_kernel(ApplyArgs a, FusedTables ft, int n_tables, int dim4, int lpr_log2,
+                                                                  tt::SegTable tbl, int dense_blocks, int n_dense, float lr, float eps) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  __shared__ int s_multi;
+  const int b = (int)blockIdx.x - n_dense;
+  if (b >= 0) {
+    const int ti = (n_tables > 2 && b >= ft.first[2]) ? 2 : ((n_tables > 1 && b >= ft.first[1]) ? 1 : 0);
+    const tt::PartTable t = ti == 2 ? ft.part[2] : (ti == 1 ? ft.part[1] : ft.part[0]);
+    const int g = b - (ti == 2 ? ft.first[2] : (ti == 1 ? ft.first[1] : 0));
+    if (threadIdx.x == 0) s_multi = 0;
+    uint32_t offset, base_key, diff;
+    const uint32_t span = tt::part_range_span(t, g, base_key);
+    const uint32_t m = tt::part_scan_append_big<DBITS, true>(t, base_key, span, ft.cap, smem, offset, diff);
+    if (m == 0u) return;
+    const RowsAhead none{};
+    if (m > (uint32_t)ft.cap) {
+      uint64_t* gp = (ti == 2 ? a.big_pairs[2] : (ti == 1 ? a.big_pairs[1] : a.big_pairs[0])) + offset;
+      uint32_t* kg = (ti == 2 ? a.big_keys[2] : (ti == 1 ? a.big_keys[1] : a.big_keys[0])) + offset;
+      uint16_t* pg = (ti == 2 ? a.big_pos[2] : (ti == 1 ? a.big_pos[1] : a.big_pos[0])) + offset;
+      const uint64_t* srt = tt::part_sort_global<true>(t, base_key, span, smem, gp, gp + t.n, m, diff);
+      for (uint32_t e = threadIdx.x; e < m; e += 1024u) {
+        const uint64_t v = srt[e];
+        kg[e] = (uint32_t)(v >> 16);
+        pg[e] = (uint16_t)(v & 0xffffu);
+      }
+      __syncthreads();
+      apply_from_lds<OPT, DBITS, false, false>(a, ti, kg, pg, nullptr, m, offset, base_key, dim4, lpr_log2, lr, eps, &s_multi, none, 0u);
+      return;
+    }
+    const uint32_t* K = tt::part_keys(smem);
+    const uint16_t* P = tt::part_poss<DBITS>(smem, ft.cap);
+    if (m <= tt::kPartRankMax) {
+      RowsAhead ra;
+      request_rows<OPT>(a, ti, K, P, m, base_key, dim4, lpr_log2, ra);
+      tt::part_rank_small<DBITS, false>(t, ft.cap, smem, m, offset, base_key);
+      apply_from_lds<OPT, DBITS, true, true>(a, ti, K, P, tt::part_ranks(smem, ft.cap), m, offset, base_key, dim4, lpr_log2, lr, eps,
+                                             &s_multi, ra, 0u);
+    } else {
+      tt::part_sort_hot_unordered<DBITS, false>(t, span, ft.cap, smem, m, offset, base_key, diff);
+      apply_from_lds<OPT, DBITS, false, false>(a, ti, K, P, nullptr, m, offset, base_key, dim4, lpr_log2, lr, eps, &s_multi, none, 0u);
+    }
+    SSTAMP(6);
+  } else {
+    const int d = (int)blockIdx.x;
+    int si = 0;
+    while (si + 1 < dense_blocks && d >= ft.seg_first[si + 1]) ++si;
+    tt::dense_update_body<OPT, 1024, 16>(tbl.seg[si], d - ft.seg_first[si], ft.seg_first[si + 1] - ft.seg_first[si], 1, lr, eps);
+  }
+}
+
 int64_t align_up(int64_t x, int64_t a);
 
 struct PieceWs {
-  int64_t nblk, off_p, off_s, off_flag, total;
+  int64_t nblk, off_p, off_s, off_flag, off_pairs, off_keys, off_pos, total;
 };
 PieceWs piece_ws(int64_t n_ids, int32_t dim) {
   PieceWs w{};
@@ -826,6 +890,13 @@ PieceWs piece_ws(int64_t n_ids, int32_t dim) {
   w.off_p = align_up(w.nblk * 4, 256);
   w.off_s = w.off_p + align_up(w.nblk * (int64_t)dim * 4, 256);
   w.total = w.off_s + align_up(w.nblk * (int64_t)dim * 4, 256);
+  w.off_pairs = w.off_keys = w.off_pos = 0;
+  if (n_ids > tt::kPartSortMaxIds && n_ids <= tt::kPartSortBigMaxIds) {       // (scratch of a degenerate batch's global sort)
+    w.off_pairs = w.total;
+    w.off_keys = w.off_pairs + align_up(2 * n_ids * 8, 256);
+    w.off_pos = w.off_keys + align_up(n_ids * 4, 256);
+    w.total = w.off_pos + align_up(n_ids * 2, 256);
+  }
   return w;
 }
 
@@ -837,6 +908,11 @@ int prepare_ws(ApplyArgs& a, void* const* ws, int n_tables, int32_t dim, int64_t
     a.p_flag[t] = reinterpret_cast<int32_t*>(base + w.off_flag);
     a.p_sum[t] = reinterpret_cast<float*>(base + w.off_p);
     a.s_sum[t] = reinterpret_cast<float*>(base + w.off_s);
+    if (w.off_pairs != 0) {
+      a.big_pairs[t] = reinterpret_cast<uint64_t*>(base + w.off_pairs);
+      a.big_keys[t] = reinterpret_cast<uint32_t*>(base + w.off_keys);
+      a.big_pos[t] = reinterpret_cast<uint16_t*>(base + w.off_pos);
+    }
   }
   return TT_OK;
 }
@@ -1012,6 +1088,8 @@ int bucket_cap(int32_t dim, int64_t n_ids) {
 using tt::kBucketGroupsMax;
 }  // namespace
 
+extern "C" int32_t tt_optimizer_ids_max_ids(void) { return tt::kPartSortBigMaxIds; }
+
 extern "C" int64_t tt_id_buckets_workspace_bytes(void) {
   return (int64_t)kBucketGroupsMax * tt::kBucketCountStride * 4 + (int64_t)kBucketGroupsMax * 256 * 8;      // counters (a line each) + lists
 }
@@ -1030,9 +1108,74 @@ extern "C" int tt_optimizer_ids_geometry(const int64_t* table_rows, int32_t n_ta
   return TT_OK;
 }
 
+namespace {
+// ---- how unevenly a batch's ids fall on the row ranges (a trainer's lagged skew probe) ----
+// The fused launch gives every row range to ONE workgroup.  Ids that are uniform over the rows put n / groups ~ 64-270 ids
+// in each; ids that crowd a few ranges (a vocabulary in order of frequency: 30 % of a power-law batch lands in the first of
+// 119 ranges) put thousands into one workgroup, and that workgroup is the launch: cfg3 with ids ~ rows * u^4, 12 -> 169 us,
+// step 0.56 -> 0.75 ms (r04).  The plan + apply path spreads the SORTED list over all CUs whatever the ids (45 us there).
+// One workgroup per table counts the ids of each range in LDS and writes the largest count to out_max[t] (device memory): a
+// trainer runs this every few dozen steps, copies the word to pinned host memory without waiting, and picks the path of the
+// following steps from it (trainer.py: the one-launch form while no range holds more than kPartRankMax ids).
+struct RangeLoadArgs {
+  const int64_t* ids[kMaxSparseTables];
+  int64_t rows[kMaxSparseTables];
+  int32_t groups[kMaxSparseTables];
+  uint32_t width[kMaxSparseTables];
+  int32_t n;
+  int32_t* out_max;
+};
+
+__global__ __launch_bounds__(1024) void range_load_kernel(RangeLoadArgs a) {
+  __shared__ uint32_t cnt[tt::kBucketGroupsMax];
+  __shared__ uint32_t best;
+  const int t = blockIdx.x, tid = threadIdx.x;
+  const int groups = a.groups[t];
+  const uint32_t width = a.width[t];
+  for (int i = tid; i < groups; i += 1024) cnt[i] = 0u;
+  if (tid == 0) best = 0u;
+  __syncthreads();
+  for (int i = tid; i < a.n; i += 1024) {
+    const int64_t id = a.ids[t][i];
+    if (id >= 0 && id < a.rows[t]) {
+      uint32_t g = (uint32_t)id / width;
+      if (g >= (uint32_t)groups) g = (uint32_t)groups - 1u;
+      atomicAdd(&cnt[g], 1u);
+    }
+  }
+  __syncthreads();
+  uint32_t m = 0u;
+  for (int i = tid; i < groups; i += 1024) m = cnt[i] > m ? cnt[i] : m;
+  if (m != 0u) atomicMax(&best, m);
+  __syncthreads();
+  if (tid == 0) a.out_max[t] = (int32_t)best;
+}
+}  // namespace
+
+extern "C" int tt_id_range_load(const int64_t* const* ids, const int64_t* table_rows, int32_t n_tables, int32_t dim, int64_t n_ids,
+                                const tt_dense_seg* segs, int32_t n_segs, int32_t* out_max, tt_stream_t stream_) {
+  TT_REQUIRE(ids && table_rows && out_max, "tt_id_range_load: null pointer");
+  TT_REQUIRE(n_tables >= 1 && n_tables <= kMaxSparseTables, "tt_id_range_load: 1..%d sparse tables", kMaxSparseTables);
+  TT_REQUIRE(segs != nullptr && n_segs >= 1 && n_segs <= TT_MAX_DENSE_SEGS, "tt_id_range_load: 1..%d dense segments", TT_MAX_DENSE_SEGS);
+  TT_REQUIRE(n_ids > 0 && n_ids <= tt::kPartSortBigMaxIds && dim > 0 && dim % 4 == 0, "tt_id_range_load: bad n_ids/dim");
+  IdsGeometry ge{};
+  ids_geometry(table_rows, n_tables, n_ids, segs, n_segs, ge);
+  RangeLoadArgs a{};
+  for (int t = 0; t < n_tables; ++t) {
+    TT_REQUIRE(ids[t] != nullptr && table_rows[t] > 0 && table_rows[t] <= 0x7fffffff, "tt_id_range_load: table %d: null ids / bad rows", t);
+    TT_REQUIRE(ge.groups[t] <= kBucketGroupsMax, "tt_id_range_load: table %d: %d row ranges", t, ge.groups[t]);
+    a.ids[t] = ids[t]; a.rows[t] = table_rows[t]; a.groups[t] = ge.groups[t]; a.width[t] = ge.width[t];
+  }
+  a.n = (int32_t)n_ids;
+  a.out_max = out_max;
+  tt::launch("range_load", range_load_kernel, dim3((unsigned)n_tables), dim3(1024), 0, tt::as_stream(stream_), a);
+  return tt::check_launch("tt_id_range_load");
+}
+
 // The same optimizer step from the RAW ids: no tt_sparse_plan launch, no sorted ids / positions in HBM.  One launch: the
 // sorting workgroups of every table (n/64 per table, csrc/part_sort.h) apply the update to the rows of their own key
-// range, the dense segments are updated beside them.  n_ids <= tt_sparse_plan_max_lds_ids(); same results, bit for bit, as
+// range, the dense segments are updated beside them.  n_ids <= tt_optimizer_ids_max_ids() (65536; beyond 16384 the long-list
+// kernel, which needs the larger tt_sparse_apply_workspace_bytes of such a list); same results, bit for bit, as
 // tt_sparse_plan_batched + tt_optimizer_step_f32.
 extern "C" int tt_optimizer_step_ids_f32(int32_t opt, const tt_sparse_table_ids* tables, int32_t n_tables, int32_t dim, int64_t n_ids,
                                          const tt_dense_seg* segs, int32_t n_segs, float lr, float eps, tt_stream_t stream_) {
@@ -1040,9 +1183,10 @@ extern "C" int tt_optimizer_step_ids_f32(int32_t opt, const tt_sparse_table_ids*
   TT_REQUIRE(tables != nullptr && n_tables >= 1 && n_tables <= kMaxSparseTables, "tt_optimizer_step_ids_f32: 1..%d sparse tables", kMaxSparseTables);
   TT_REQUIRE(segs != nullptr && n_segs >= 1 && n_segs <= TT_MAX_DENSE_SEGS, "tt_optimizer_step_ids_f32: 1..%d dense segments", TT_MAX_DENSE_SEGS);
   TT_REQUIRE(n_ids > 0 && dim > 0 && dim % 4 == 0, "tt_optimizer_step_ids_f32: bad n_ids/dim");
-  if (n_ids > tt::kPartSortMaxIds)
+  if (n_ids > tt::kPartSortBigMaxIds)
     return tt::fail(TT_ERR_UNSUPPORTED, "tt_optimizer_step_ids_f32: n_ids %lld > %d (use tt_sparse_plan_batched + tt_optimizer_step_f32)",
-                    (long long)n_ids, tt::kPartSortMaxIds);
+                    (long long)n_ids, tt::kPartSortBigMaxIds);
+  const bool big = n_ids > tt::kPartSortMaxIds;              // 16,385 .. 65,536 ids: optimizer_ids_big_kernel
   ApplyArgs a{};
   FusedTables ft{};
   void* ws[kMaxSparseTables] = {};
@@ -1107,7 +1251,7 @@ extern "C" int tt_optimizer_step_ids_f32(int32_t opt, const tt_sparse_table_ids*
   while ((1 << lpr_log2) < dim4 && lpr_log2 < 6) ++lpr_log2;
   (void)max_count; (void)max_groups;
   const int64_t gx = (int64_t)ft.first[n_tables] + ft.seg_first[n_segs];
-  ft.cap = (int32_t)((n_ids + 1023) / 1024 * 1024);
+  ft.cap = big ? tt::kPartSortMaxIds : (int32_t)((n_ids + 1023) / 1024 * 1024);
   const bool nine = (max_lbits + 8) / 9 < (max_lbits + 7) / 8;     // digits of the hot-range radix passes (csrc/sort.hip)
   const bool small = n_ids <= 8 * 1024;
   const int lds = tt::part_sort_lds_bytes(ft.cap, nine ? 512 : 256);
@@ -1119,6 +1263,10 @@ extern "C" int tt_optimizer_step_ids_f32(int32_t opt, const tt_sparse_table_ids*
     tt::launch("optimizer", kern, dim3((unsigned)gx), dim3(1024), lds, stream, a, ft, n_tables, dim4, lpr_log2, tbl, n_segs, (int)ft.seg_first[n_segs], lr, eps);
     return tt::check_launch("tt_optimizer_step_ids_f32");
   };
+  if (big) {
+    if (opt == TT_OPT_SGD) return nine ? go(optimizer_ids_big_kernel<TT_OPT_SGD, 9>) : go(optimizer_ids_big_kernel<TT_OPT_SGD, 8>);
+    return nine ? go(optimizer_ids_big_kernel<TT_OPT_ADAGRAD, 9>) : go(optimizer_ids_big_kernel<TT_OPT_ADAGRAD, 8>);
+  }
   if (opt == TT_OPT_SGD) {
     if (small) return nine ? go(optimizer_ids_kernel<TT_OPT_SGD, 9, 8>) : go(optimizer_ids_kernel<TT_OPT_SGD, 8, 8>);
     return nine ? go(optimizer_ids_kernel<TT_OPT_SGD, 9, 16>) : go(optimizer_ids_kernel<TT_OPT_SGD, 8, 16>);

@@ -509,13 +509,38 @@ def optimizer_step_(opt: str, tables, segs: list[DenseSeg], lr: float, eps: floa
 
 
 def sparse_plan_max_lds_ids() -> int:
-    """Longest id list the one-launch LDS sort (and the optimizer step from raw ids) takes: 16384."""
+    """Longest id list the one-launch LDS sort takes: 16384."""
     return int(_lib.load().tt_sparse_plan_max_lds_ids())
+
+
+def optimizer_ids_max_ids() -> int:
+    """Longest id list per table the optimizer step from raw ids takes: 65536 (beyond 16384: the long-list kernel)."""
+    return int(_lib.load().tt_optimizer_ids_max_ids())
+
+
+def id_range_load_(out_max: torch.Tensor, ids_list, table_rows, dim: int, segs: list[DenseSeg]):
+    """Skew probe (``tt_id_range_load``): out_max[t] (int32, device) = the most ids of ``ids_list[t]`` in one of table t's row
+    ranges - what ONE workgroup of the one-launch optimizer would have to sort and apply.  One small launch; the caller copies
+    ``out_max`` to pinned host memory without waiting (TwoTowerTrainer.poll_ids)."""
+    n = len(ids_list)
+    _chk(out_max, torch.int32, "out_max", 1)
+    if out_max.numel() < n:
+        raise RuntimeError("id_range_load_: out_max needs one int32 per table")
+    for ids in ids_list:
+        _chk(ids, torch.int64, "ids", 1)
+        if ids.numel() != ids_list[0].numel():
+            raise RuntimeError("id_range_load_: every table needs the same number of ids")
+    ptrs = (_lib.C.c_void_p * n)(*[ids.data_ptr() for ids in ids_list])
+    rows = (_lib.C.c_int64 * n)(*[int(r) for r in table_rows])
+    arr_s = (DenseSeg * len(segs))(*segs)
+    _lib.check(_lib.load().tt_id_range_load(ptrs, rows, n, dim, ids_list[0].numel(), arr_s, len(segs), _p(out_max), _stream()),
+               "tt_id_range_load")
+    return out_max
 
 
 def optimizer_step_ids_(opt: str, tables, segs: list[DenseSeg], lr: float, eps: float = 1e-7, buckets=None):
     """The same step from the RAW ids, no sort-plan launch: ``tables`` = [(table, accum or None, grads, ids, plan), ...]
-    (``plan`` only lends its apply workspace); n_ids <= sparse_plan_max_lds_ids().  Bit-identical to
+    (``plan`` only lends its apply workspace); n_ids <= optimizer_ids_max_ids().  Bit-identical to
     ``sparse_plan_batched`` + ``optimizer_step_``."""
     dim, n_ids = tables[0][0].shape[1], tables[0][3].numel()
     arr_t = (_lib.SparseTableIds * len(tables))()

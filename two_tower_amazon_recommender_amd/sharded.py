@@ -18,8 +18,8 @@ one sparse update per step, and every exchange is ONE collective for all tables)
   C3      all-to-all of the gradient rows to the owners     (travels beside the dw GEMMs and the dense reduce)
   K2      owner sorts the received ids, sums the duplicates - inside one rank's batch and across ranks, in (source rank,
           position) order: bitwise reproducible - and applies the fused sparse SGD/Adagrad in ONE launch
-          (tt_optimizer_step_ids_f32 on the receive buffer, the dense tower update in the same launch; lists longer than
-          16384 slots: plan launch + tt_optimizer_step_f32).  No sort plan on a side stream since r03.
+          (tt_optimizer_step_ids_f32 on the receive buffer, the dense tower update in the same launch; lists of 16,385 to
+          65,536 slots: the long-list kernel of the same entry, r04; longer: plan launch + tt_optimizer_step_f32).  No sort plan on a side stream since r03.
 
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): an all-to-all uses every link at once, one peer per
 link; what costs at these sizes (a few MB) is the per-collective latency, hence three all-to-alls per step
@@ -86,7 +86,7 @@ class HipRowBackend:
     @property
     def max_fused_ids(self) -> int:
         """Longest owner-side id list the one-launch optimizer (sort + duplicate sums + update) takes."""
-        return self.ops.sparse_plan_max_lds_ids()
+        return self.ops.optimizer_ids_max_ids()
 
     def apply_ids(self, opt, table, accum, ids, grads, dense_segs, lr, eps, key=None):
         """Owner side in ONE launch, straight from the received ids (tt_optimizer_step_ids_f32): the workgroups sort the

@@ -282,6 +282,16 @@ class TwoTowerTrainer:
         self.flag_poll_every = 50                # steps between asynchronous polls of the out-of-range flag (0 = never)
         self._oob_host = self._oob_event = None
         self._oob_step = -1
+        # r04: the one-launch optimizer gives every row range of a table to ONE workgroup.  Ids uniform over the rows put
+        # batch / groups ~ 64-270 ids into each; a vocabulary in order of frequency (what StringLookup.adapt builds) puts a third
+        # of a power-law batch into the first range, and that workgroup is the launch (cfg3, ids ~ rows * u^4: 12 -> 169 us, step
+        # 0.560 -> 0.746 ms).  Every flag_poll_every steps a one-workgroup-per-table probe (tt_id_range_load) counts the batch's
+        # ids per range; its result is read from pinned memory when it has landed, never waited for, and while some range holds
+        # more than skew_limit ids the steps take the plan launch + tt_optimizer_step_f32 instead (the sorted list is spread
+        # over all CUs whatever the ids: 45 us at cfg3).  TT_SKEW_LIMIT=0: never switch.
+        self.skew_limit = int(os.environ.get("TT_SKEW_LIMIT", "512"))
+        self.range_load = 0                      # largest row-range load the last finished probe saw
+        self._skew_dev = self._skew_host = self._skew_event = None
         self.dropout_seed = 0 if seed is None else seed
         self._segs = self.user_tower.segments(cfg.l2_regularization) + self.item_tower.segments(cfg.l2_regularization)
         if seed is not None:
@@ -424,9 +434,12 @@ class TwoTowerTrainer:
         if loss_kw.get("category_ids") is not None and self.cat_plan is not None:
             plans.append(self.cat_plan); ids.append(loss_kw["category_ids"]); rows.append(self.cfg.n_category_buckets)
         # fuse_sort: no plan launch at all - the optimizer launch's workgroups sort the ids of their own row range in LDS
-        # and update exactly those rows (tt_optimizer_step_ids_f32; lists up to 16384 ids)
-        fused_sort = (self.fuse_sort and self.fuse_optimizer and user_ids.numel() <= ops.sparse_plan_max_lds_ids()
-                      and (self.cat_table is None) == (len(ids) == 2))
+        # and update exactly those rows (tt_optimizer_step_ids_f32; lists up to 65536 ids) - unless the batches are skewed
+        shape_ok = (self.fuse_sort and self.fuse_optimizer and user_ids.numel() <= ops.optimizer_ids_max_ids()
+                    and (self.cat_table is None) == (len(ids) == 2))
+        if shape_ok:
+            self._poll_skew(ids, rows)
+        fused_sort = shape_ok and not self._skewed()
         if fused_sort:
             if (self.use_composite and self.fuse_lookup and self.cfg.symmetric
                     and self.cfg.batch_size <= ops.MAX_FUSED_LOOKUP_ROWS):
@@ -663,6 +676,31 @@ class TwoTowerTrainer:
         if self.flag_poll_every and self._replays % self.flag_poll_every == 0:     # host side, outside the graph
             self.poll_ids()
         return self.loss
+
+    def one_launch_optimizer(self, n_ids: int) -> bool:
+        """Whether a step of ``n_ids`` pairs would take tt_optimizer_step_ids_f32 (sort + duplicate sums + update in the optimizer
+        launch) right now: the shape allows it and the last skew probe saw no overloaded row range."""
+        return bool(self.fuse_sort and self.fuse_optimizer and n_ids <= ops.optimizer_ids_max_ids() and not self._skewed())
+
+    def _skewed(self) -> bool:
+        return bool(self.skew_limit) and self.range_load > self.skew_limit
+
+    def _poll_skew(self, ids, rows):
+        """The skew probe, never waiting for the GPU: takes the result of the probe in flight if it has landed (checked every
+        step while one is in flight - a query of an event), and every ``flag_poll_every`` steps starts a new one on this batch's
+        ids: one small launch + a 12-byte copy to pinned memory."""
+        if not self.skew_limit or not self.fuse_sort or not self.fuse_optimizer or torch.cuda.is_current_stream_capturing():
+            return
+        if self._skew_event is not None and self._skew_event.query():
+            self.range_load, self._skew_event = int(self._skew_host.max().item()), None
+        if self._skew_event is None and self.flag_poll_every and self.step_index % self.flag_poll_every == 0:
+            if self._skew_dev is None:
+                self._skew_dev = torch.zeros(4, dtype=torch.int32, device=self.dev)
+                self._skew_host = torch.zeros(4, dtype=torch.int32).pin_memory()
+            ops.id_range_load_(self._skew_dev, ids, rows, self.cfg.embedding_dim, self._segs)
+            self._skew_host.copy_(self._skew_dev, non_blocking=True)
+            self._skew_event = torch.cuda.Event()
+            self._skew_event.record()
 
     def poll_ids(self):
         """Asynchronous check of the out-of-range flag: looks at the copy the PREVIOUS poll started (if it has landed —
