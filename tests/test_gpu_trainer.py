@@ -479,6 +479,33 @@ def test_composite_step_entry_equals_the_python_sequence_bit_for_bit(dev, opt, b
         assert torch.equal(a.user_accum, b.user_accum) and torch.equal(a.dense_accum, b.dense_accum)
 
 
+def test_sharded_owner_side_takes_the_plan_path_under_skew_and_stays_bit_identical(dev):
+    """r04: the owner side of the row-sharded step has the same probe as the plain trainer (ShardedTables._poll_skew on the
+    RECEIVED ids): power-law batches crowd the first row ranges of the combined shard, the probe sees it one lookup later and
+    the owner update takes plan() + apply(); uniform batches bring apply_ids back.  Bit-identical to the plain trainer
+    throughout (which switches by its own probe on the same batches)."""
+    from two_tower_amazon_recommender_amd.sharded import ShardedTwoTowerTrainer
+    cfg = TwoTowerConfig(n_users=2_000_000, n_items=1_000_000, embedding_dim=64, tower_dims=[128, 64], temperature=0.1,
+                         l2_regularization=1e-6, learning_rate=0.001, optimizer="adagrad", batch_size=8192)
+    tr = TwoTowerTrainer(cfg, dev, seed=43)
+    sh = ShardedTwoTowerTrainer(TwoTowerConfig(**cfg.__dict__), dev, seed=43)
+    sh.emb.probe_every = tr.flag_poll_every = 3
+    assert sh.emb.fused_apply and sh.emb.probe_segs is not None
+    seen = []
+    for step in range(12):
+        variant = "Z" if step < 6 else "U"
+        u, i = tr.synthetic_batch(43, step, variant)
+        l1 = tr.step(u, i).clone()
+        l2 = sh.step(u.clone(), i.clone()).clone()
+        torch.cuda.synchronize()
+        seen.append(sh.emb._fused_now)
+        assert torch.equal(l1, l2), step
+    assert seen[0] is True and not any(seen[1:7]) and all(seen[8:]), seen
+    assert sh.emb.range_load <= 512
+    assert torch.equal(sh.user_table, tr.user_table) and torch.equal(sh.item_table, tr.item_table)
+    assert torch.equal(sh.dense_flat, tr.dense_flat)
+
+
 @pytest.mark.parametrize("opt,variant", [("sgd", "U"), ("adagrad", "Z")])
 def test_sharded_trainer_world1_is_bit_identical_to_single_gpu_trainer(dev, opt, variant):
     """The row-sharded step (route / de-dup / exchange buffers / owner update) with one rank must reproduce the

@@ -32,6 +32,7 @@ the HIP ops; the CPU/gloo tests pass a NumPy-oracle backend defined in the test)
 from __future__ import annotations
 
 import contextlib
+import os
 
 import torch
 import torch.distributed as dist
@@ -87,6 +88,10 @@ class HipRowBackend:
     def max_fused_ids(self) -> int:
         """Longest owner-side id list the one-launch optimizer (sort + duplicate sums + update) takes."""
         return self.ops.optimizer_ids_max_ids()
+
+    def range_load(self, out, ids, num_rows, dim, dense_segs):
+        """Skew probe (tt_id_range_load): out[0] = the most owner-side ids in one row range of apply_ids' launch."""
+        self.ops.id_range_load_(out, [ids], [num_rows], dim, dense_segs)
 
     def apply_ids(self, opt, table, accum, ids, grads, dense_segs, lr, eps, key=None):
         """Owner side in ONE launch, straight from the received ids (tt_optimizer_step_ids_f32): the workgroups sort the
@@ -161,6 +166,17 @@ class ShardedTables:
         self.grad_recv = torch.empty(n, dim, device=device) if self.collectives else self.grad_send
         # owner side in one launch from the received ids (no sort plan) when the backend offers it and the list fits
         self.fused_apply = hasattr(self.backend, "apply_ids") and n <= getattr(self.backend, "max_fused_ids", 0)
+        # r04, as in TwoTowerTrainer: apply_ids gives every row range of the combined shard to one workgroup, and a vocabulary in
+        # order of frequency crowds the first ranges of every owner (local row = id // world keeps the order).  While the lagged
+        # probe (backend.range_load every probe_every steps on the received ids, read from pinned memory when it has landed)
+        # sees a range of more than skew_limit ids, the owner side takes plan() + apply().  Each rank decides for itself: the
+        # collectives of the step are the same on both paths.  probe_segs: the dense segments that ride in apply_ids' launch
+        # (they set its row ranges); None = no probing.
+        self.skew_limit, self.probe_every, self.probe_segs = int(os.environ.get("TT_SKEW_LIMIT", "512")), 50, None
+        self.range_load = 0
+        self._fused_now = self.fused_apply
+        self._skew_dev = self._skew_host = self._skew_event = None
+        self._lookups = 0
         # id buffers exist twice: lookup_prefetch() routes and exchanges the NEXT step's ids while this step computes
         self._idbufs = [self._make_idbufs(), None]
         self._cur = 0
@@ -249,10 +265,29 @@ class ShardedTables:
         """owner side: sort plan (side stream), K1 gather, C2 (rows back to the requesters)."""
         self._wait(self._w)
         be = self.backend
-        if not self.fused_apply:
+        self._poll_skew()
+        self._fused_now = self.fused_apply and not (self.skew_limit and self.range_load > self.skew_limit)
+        if not self._fused_now:
             be.plan(self.recv_ids, self.table.shape[0], key=id(self))
         be.gather(self.table, self.recv_ids, self.rows_out, self.flags[0:1])       # K1
         self._w = self._a2a(self.rows_in, self.rows_out, overlap=False)            # C2
+
+    def _poll_skew(self):
+        """Never waits for the GPU: takes the probe in flight if it has landed, starts a new one every ``probe_every`` lookups."""
+        be = self.backend
+        if not self.fused_apply or self.probe_segs is None or not self.skew_limit or not hasattr(be, "range_load"):
+            return
+        if self._skew_event is not None and self._skew_event.query():
+            self.range_load, self._skew_event = int(self._skew_host[0]), None
+        if self._skew_event is None and self.probe_every and self._lookups % self.probe_every == 0:
+            if self._skew_dev is None:
+                self._skew_dev = torch.zeros(4, dtype=torch.int32, device=self.device)
+                self._skew_host = torch.zeros(4, dtype=torch.int32).pin_memory()
+            be.range_load(self._skew_dev, self.recv_ids, self.table.shape[0], self.table.shape[1], self.probe_segs)
+            self._skew_host.copy_(self._skew_dev, non_blocking=True)
+            self._skew_event = torch.cuda.Event()
+            self._skew_event.record()
+        self._lookups += 1
 
     def lookup_wait(self):
         """The received rows are in ``rows_in`` (row of position p of table t at slot pos_flats[t][p], -1 = none): a consumer
@@ -282,10 +317,10 @@ class ShardedTables:
         """K2: fused sparse update on the owner (duplicates summed first, in (source rank, position) order).
         dense_segs (only with ``fused_apply``): dense segments updated in the same launch; returns True if they were."""
         self._wait(self._w)
-        if self.fused_apply and dense_segs:
+        if self._fused_now and dense_segs:
             self.backend.apply_ids(opt, self.table, self.accum, self.recv_ids, self.grad_recv, dense_segs, lr, eps, key=id(self))
             return True
-        if self.fused_apply:       # (no dense work to ride along: the sort plan was skipped, so run it now)
+        if self._fused_now:        # (no dense work to ride along: the sort plan was skipped, so run it now)
             self.backend.plan(self.recv_ids, self.table.shape[0], key=id(self))
         self.backend.apply(opt, self.table, self.accum, self.recv_ids, self.grad_recv, lr, eps, key=id(self))
         return False
@@ -425,6 +460,8 @@ class ShardedTwoTowerTrainer:
                     off += p.numel()
         if n_cat:
             self._segs_apply.append(ops.make_dense_seg(self.cat_table, self.cat_accum, self.cat_grad, 1, 0.0))
+        # the owner-side skew probe cuts the combined shard like the launch it stands in for: by the dense segments riding in it
+        self.emb.probe_segs = self._segs_apply if self.collectives else self._segs_reduce
         sd = cfg.tower_dims[-1]
         nc = b * w if negatives == "global" else b
         self.ws = torch.empty(ops.retrieval_workspace_bytes(b, nc, sd), dtype=torch.uint8, device=dev)
@@ -614,7 +651,7 @@ class ShardedTwoTowerTrainer:
                                         cfg.adagrad_epsilon)
         else:
             ops.dense_update_(self._segs_reduce, cfg.optimizer, cfg.learning_rate, cfg.adagrad_epsilon, apply=False)
-            if em.sync_ops_inline and em.fused_apply:
+            if em.sync_ops_inline and em._fused_now:
                 # C6 on the current stream, then ONE launch: the owner's sort + duplicate sums + sparse update (it waits
                 # for C3) with the dense update from the all-reduced gradient riding along
                 dist.all_reduce(self.dense_grad, op=dist.ReduceOp.SUM, group=self.group)                   # C6
