@@ -373,7 +373,7 @@ int64_t tt_id_buckets_workspace_bytes(void);      /* one table's counts + pairs,
  * of table t's row ranges (the ranges of tt_optimizer_ids_geometry).  The one-launch optimizer gives a range to one
  * workgroup: ids uniform over the rows put n_ids / groups in each, a vocabulary in order of frequency puts thousands into
  * the first (cfg3, ids ~ rows * u^4: launch 12 -> 169 us).  Run every few dozen steps, copy the words to pinned host memory
- * without waiting, and take tt_sparse_plan_batched + tt_optimizer_step_f32 while a range holds more than ~512 ids.
+ * without waiting, and take tt_sparse_plan_batched + tt_optimizer_step_f32 while a range holds more than ~384 ids.
  * ids: HOST array of n_tables device pointers.  One launch, one workgroup per table.                                    */
 int tt_id_range_load(const int64_t* const* ids, const int64_t* table_rows, int32_t n_tables, int32_t dim, int64_t n_ids,
                      const tt_dense_seg* segs, int32_t n_segs, int32_t* out_max, tt_stream_t stream);

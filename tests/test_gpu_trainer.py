@@ -369,7 +369,7 @@ def test_skew_probe_moves_the_steps_to_the_plan_path_and_back_without_changing_a
     b = TwoTowerTrainer(TwoTowerConfig(**cfg.__dict__), dev, seed=41)
     b.skew_limit = 0
     a.flag_poll_every = 3
-    assert a.skew_limit == 512 and a.one_launch_optimizer(cfg.batch_size)
+    assert a.skew_limit == 384 and a.one_launch_optimizer(cfg.batch_size)
     paths = []
     for step in range(16):
         variant = "Z" if step < 8 else "U"
@@ -381,7 +381,7 @@ def test_skew_probe_moves_the_steps_to_the_plan_path_and_back_without_changing_a
         assert torch.equal(la, lb), step
     # probe at step 0 (power-law ids) -> read at step 1: plan path from step 1 on; probe at step 9 (uniform) -> back at step 10
     assert paths[0] is True and not any(paths[1:9]) and all(paths[10:]), paths
-    assert a.range_load <= 512 and b.range_load == 0
+    assert a.range_load < 288 and b.range_load == 0
     assert torch.equal(a.user_table, b.user_table) and torch.equal(a.item_table, b.item_table)
     assert torch.equal(a.user_accum, b.user_accum) and torch.equal(a.dense_flat, b.dense_flat)
 
@@ -501,7 +501,7 @@ def test_sharded_owner_side_takes_the_plan_path_under_skew_and_stays_bit_identic
         seen.append(sh.emb._fused_now)
         assert torch.equal(l1, l2), step
     assert seen[0] is True and not any(seen[1:7]) and all(seen[8:]), seen
-    assert sh.emb.range_load <= 512
+    assert sh.emb.range_load < 288
     assert torch.equal(sh.user_table, tr.user_table) and torch.equal(sh.item_table, tr.item_table)
     assert torch.equal(sh.dense_flat, tr.dense_flat)
 

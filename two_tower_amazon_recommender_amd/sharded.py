@@ -172,8 +172,9 @@ class ShardedTables:
         # sees a range of more than skew_limit ids, the owner side takes plan() + apply().  Each rank decides for itself: the
         # collectives of the step are the same on both paths.  probe_segs: the dense segments that ride in apply_ids' launch
         # (they set its row ranges); None = no probing.
-        self.skew_limit, self.probe_every, self.probe_segs = int(os.environ.get("TT_SKEW_LIMIT", "512")), 50, None
+        self.skew_limit, self.probe_every, self.probe_segs = int(os.environ.get("TT_SKEW_LIMIT", "384")), 50, None
         self.range_load = 0
+        self._skew_state = False
         self._fused_now = self.fused_apply
         self._skew_dev = self._skew_host = self._skew_event = None
         self._lookups = 0
@@ -266,7 +267,11 @@ class ShardedTables:
         self._wait(self._w)
         be = self.backend
         self._poll_skew()
-        self._fused_now = self.fused_apply and not (self.skew_limit and self.range_load > self.skew_limit)
+        if self.skew_limit and self.range_load > self.skew_limit:
+            self._skew_state = True
+        elif 4 * self.range_load < 3 * self.skew_limit:
+            self._skew_state = False
+        self._fused_now = self.fused_apply and not self._skew_state
         if not self._fused_now:
             be.plan(self.recv_ids, self.table.shape[0], key=id(self))
         be.gather(self.table, self.recv_ids, self.rows_out, self.flags[0:1])       # K1

@@ -288,9 +288,14 @@ class TwoTowerTrainer:
         # 0.560 -> 0.746 ms).  Every flag_poll_every steps a one-workgroup-per-table probe (tt_id_range_load) counts the batch's
         # ids per range; its result is read from pinned memory when it has landed, never waited for, and while some range holds
         # more than skew_limit ids the steps take the plan launch + tt_optimizer_step_f32 instead (the sorted list is spread
-        # over all CUs whatever the ids: 45 us at cfg3).  TT_SKEW_LIMIT=0: never switch.
-        self.skew_limit = int(os.environ.get("TT_SKEW_LIMIT", "512"))
+        # over all CUs whatever the ids: 38 us at cfg3), and return to the one launch when the load falls below 3/4 of the limit.
+        # 384: the overloaded workgroup costs ~0.066 us per id at dim 128, the plan path ~25 us more than the balanced launch
+        # (the reference's own config, batch 1024, power-law ids, largest range 498-541: 0.2053 ms without the probe, 0.1834 at
+        # limit 512 - flapping -, 0.1694 at 384 and 256; cfg1's 177 ids must NOT switch: its Python sequence of launches is
+        # host-bound, 0.060 -> 0.090 ms).  TT_SKEW_LIMIT=0: never switch.
+        self.skew_limit = int(os.environ.get("TT_SKEW_LIMIT", "384"))
         self.range_load = 0                      # largest row-range load the last finished probe saw
+        self._skew_state = False
         self._skew_dev = self._skew_host = self._skew_event = None
         self.dropout_seed = 0 if seed is None else seed
         self._segs = self.user_tower.segments(cfg.l2_regularization) + self.item_tower.segments(cfg.l2_regularization)
@@ -683,7 +688,13 @@ class TwoTowerTrainer:
         return bool(self.fuse_sort and self.fuse_optimizer and n_ids <= ops.optimizer_ids_max_ids() and not self._skewed())
 
     def _skewed(self) -> bool:
-        return bool(self.skew_limit) and self.range_load > self.skew_limit
+        if not self.skew_limit:
+            return False
+        if self.range_load > self.skew_limit:
+            self._skew_state = True
+        elif 4 * self.range_load < 3 * self.skew_limit:
+            self._skew_state = False
+        return self._skew_state
 
     def _poll_skew(self, ids, rows):
         """The skew probe, never waiting for the GPU: takes the result of the probe in flight if it has landed (checked every
