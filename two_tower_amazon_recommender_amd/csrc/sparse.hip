@@ -162,9 +162,24 @@ __device__ TT_TAIL_ATTR void finish_run_piece(f32x4* __restrict__ table, f32x4* 
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (l == 0) p_flag[jh] = 0;                     // leave the workspace zeroed for the next call
+  // (r04: FOUR piece sums requested before the first is added - the adds stay in index order, the loads do not depend on
+  // them.  One sc1 load per round trip, as hipcc schedules the plain loop, made the last arriver of a long run a chain of
+  // dependent L2 reads: the hottest id of a 1M-id power-law batch is 18,000 slots = 281 pieces = ~250 us of a 522 us launch.
+  // Four, not eight: they reuse the registers of the walk's four gradient rows; more would cost the kernel a wave of occupancy.)
   for (int c = l; c < dim4; c += lpr) {
     f32x4 g = load_piece(P + jh * dim4 + c);
-    for (int64_t m = jh + 1; m <= jl; ++m) {
+    int64_t m = jh + 1;
+    while (m + 3 <= jl) {
+      f32x4 s[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s[u] = load_piece(S + (m + u) * dim4 + c);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g[q] = __fadd_rn(g[q], s[u][q]);
+      m += 4;
+    }
+    for (; m <= jl; ++m) {
       const f32x4 s = load_piece(S + m * dim4 + c);
 #pragma unroll
       for (int q = 0; q < 4; ++q) g[q] = __fadd_rn(g[q], s[q]);
@@ -618,7 +633,18 @@ __device__ __forceinline__ void apply_from_lds(const ApplyArgs& a, const int t, 
     const f32x4* Ss = reinterpret_cast<const f32x4*>(a.s_sum[t]);
     for (int c = l; c < dim4; c += lpr) {
       f32x4 g = Ps[jh * dim4 + c];
-      for (int64_t mb = jh + 1; mb <= jl; ++mb) {
+      int64_t mb = jh + 1;
+      while (mb + 3 <= jl) {                                    // four piece sums in flight, added in index order
+        f32x4 sv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sv[u] = Ss[(mb + u) * dim4 + c];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) g[q] = __fadd_rn(g[q], sv[u][q]);
+        mb += 4;
+      }
+      for (; mb <= jl; ++mb) {
         const f32x4 sv = Ss[mb * dim4 + c];
 #pragma unroll
         for (int q = 0; q < 4; ++q) g[q] = __fadd_rn(g[q], sv[q]);
