@@ -333,6 +333,19 @@ int tt_dense_update_f32(const tt_dense_seg* segs, int32_t n_segs, int32_t opt, i
 int tt_dense_bwd_batched_update_f32(const tt_dense_bwd_args* probs, int32_t n_probs, float dx_scale, int64_t m, int32_t k, int32_t n,
                                     const tt_dense_seg* segs, int32_t n_segs, int32_t opt, float lr, float eps, tt_stream_t stream);
 
+/* Two layers' backward passes in ONE launch (r04): `upper` = layer l (k1 -> n), `lower` = layer l-1 (k0 -> k1), upper[i].dx
+ * must BE lower[i].dz.  The same tiles as two tt_dense_bwd_batched_f32 calls, results identical bit for bit; the lower layer's
+ * tiles wait, inside the launch, for the 64-row blocks of dz they read (agent-scope release / acquire on a counter per row
+ * block in `workspace`: tt_tower_bwd2_workspace_bytes(m) bytes, 256-byte aligned, ZEROED ONCE - the launch leaves it zeroed).
+ * What it saves is the boundary between the two launches (the platform's ~4 us + one launch's tail + the other's ramp).  The
+ * wait is bounded: if it ever ran out, int32 word [4 * (m / 64)] of the workspace is set and the results of that step are wrong.
+ * Both layers need dx and dw_slabs; only the lower layer may carry the fused lookup.  tt_tower_bwd2_supported: m % 64 == 0
+ * and the batch splits of the dW GEMMs (tt_dense_bwd_num_slabs) whole numbers of 64-row blocks.                         */
+int32_t tt_tower_bwd2_supported(int64_t m, int32_t k0, int32_t k1, int32_t n);
+int64_t tt_tower_bwd2_workspace_bytes(int64_t m);
+int tt_tower_bwd2_batched_f32(const tt_dense_bwd_args* upper, const tt_dense_bwd_args* lower, int32_t n_probs, float dx_scale_upper,
+                              float dx_scale_lower, int64_t m, int32_t k0, int32_t k1, int32_t n, void* workspace, tt_stream_t stream);
+
 /* The whole optimizer of a train step in ONE launch: the fused sparse update of up to 3 embedding tables (user, item,
  * hashed category; same dim and n_ids, each with its own sort plan and apply workspace) AND the dense update of every
  * tower segment (apply = 1 semantics of tt_dense_update_f32).  Same arithmetic, bit for bit, as tt_sparse_update2_f32 /

@@ -442,6 +442,30 @@ def test_fused_launches_equal_the_separate_ones_bit_for_bit(dev, opt, variant, b
     assert torch.equal(a.user_table, c.user_table) and torch.equal(a.item_table, c.item_table) and torch.equal(a.dense_flat, c.dense_flat)
 
 
+def test_two_layer_backward_in_one_launch_is_bit_identical_and_leaves_its_counters_zeroed(dev):
+    """tt_tower_bwd2_batched_f32 (r04, OFF by default: it measures slower, profiles/r04_bwd2_ab.txt): layers 1 and 0 of both towers'
+    backward pass in one launch, the lower layer's tiles waiting inside the launch (agent-scope release / acquire on a counter per
+    64-row block) for the rows of dz they read - against one launch per layer, with dropout and the hashed category table, uniform
+    and power-law ids: every step's loss and the final state identical bit for bit, no wait ran out, counters back at zero."""
+    cfg = TwoTowerConfig(n_users=50_000, n_items=30_000, embedding_dim=64, tower_dims=[128, 64], temperature=0.1, l2_regularization=1e-6,
+                         learning_rate=0.001, optimizer="adagrad", batch_size=2048, dropout_rate=0.1, n_category_buckets=30)
+    a = TwoTowerTrainer(cfg, dev, seed=47)
+    b = TwoTowerTrainer(TwoTowerConfig(**cfg.__dict__), dev, seed=47)
+    a.use_composite = b.use_composite = False
+    assert ops.tower_bwd2_supported(cfg.batch_size, 64, 128, 64) and not ops.tower_bwd2_supported(1000, 64, 128, 64)
+    b.bwd2_ws = ops.tower_bwd2_workspace(cfg.batch_size, dev)
+    for step in range(6):
+        u, i = a.synthetic_batch(47, step, "Z" if step % 2 else "U")
+        c = a.synthetic_categories(47, step)
+        la = a.step(u, i, category_ids=c).clone()
+        lb = b.step(u, i, category_ids=c).clone()
+        assert torch.equal(la, lb), step
+    words = b.bwd2_ws.view(torch.int32)
+    assert int(words.abs().sum().item()) == 0           # counters zeroed by the last consumer, error word never set
+    assert torch.equal(a.user_table, b.user_table) and torch.equal(a.item_table, b.item_table) and torch.equal(a.cat_table, b.cat_table)
+    assert torch.equal(a.dense_flat, b.dense_flat) and torch.equal(a.dense_accum, b.dense_accum)
+
+
 @pytest.mark.parametrize("opt,buckets,precision", [("sgd", 0, "f32"), ("adagrad", 30, "f32"), ("sgd", 0, "bf16x3")])
 def test_composite_step_entry_equals_the_python_sequence_bit_for_bit(dev, opt, buckets, precision):
     """tt_train_step_f32 (one C call per step: the nine launches enqueued in C) against the same launches issued one by one

@@ -134,6 +134,9 @@ SIGNATURES = {
     "tt_dense_bwd_batched_f32": (C.c_int, [C.POINTER(DenseBwdArgs), _i32, _f, _i64, _i32, _i32, _p]),
     "tt_dense_bwd_batched_update_f32": (C.c_int, [C.POINTER(DenseBwdArgs), _i32, _f, _i64, _i32, _i32, C.POINTER(DenseSeg), _i32, _i32,
                                                   _f, _f, _p]),
+    "tt_tower_bwd2_supported": (_i32, [_i64, _i32, _i32, _i32]),
+    "tt_tower_bwd2_workspace_bytes": (_i64, [_i64]),
+    "tt_tower_bwd2_batched_f32": (C.c_int, [C.POINTER(DenseBwdArgs), C.POINTER(DenseBwdArgs), _i32, _f, _f, _i64, _i32, _i32, _i32, _p, _p]),
     "tt_tower_fwd2_supported": (_i32, [_i64, _i32, _i32, _i32]),
     "tt_tower_fwd2_batched_f32": (C.c_int, [C.POINTER(DenseFwdArgs), C.POINTER(DenseFwdArgs), _i32, _i64, _i32, _i32, _i32, _f, _u64, _u64, _p]),
     "tt_dense_bwd_num_slabs": (_i32, [_i64]),

@@ -666,25 +666,67 @@ struct BwdBatch {
   float rider_lr, rider_eps;
 };
 
-template <int GK>
-__global__ __launch_bounds__(256, (GK > 256 ? 3 : 4)) void gemm_bwd_kernel(BwdBatch pb, tt::SegTable riders) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * 2 * TILE_F];
-  __shared__ int32_t gids[kGidsInts(GK, true)];
-  if ((int)blockIdx.x < pb.rider_blocks) {               // (workgroup-uniform)
-    const int d = (int)blockIdx.x;
-    int si = 0;
-    while (si + 1 < pb.rider_segs && d >= pb.rider_first[si + 1]) ++si;
-    const int nb = pb.rider_first[si + 1] - pb.rider_first[si];
-    if (pb.rider_opt == TT_OPT_SGD) tt::dense_update_body<TT_OPT_SGD, 256, 16>(riders.seg[si], d - pb.rider_first[si], nb, 1, pb.rider_lr, pb.rider_eps);
-    else tt::dense_update_body<TT_OPT_ADAGRAD, 256, 16>(riders.seg[si], d - pb.rider_first[si], nb, 1, pb.rider_lr, pb.rider_eps);
-    return;
+// ---- two layers' backward passes in ONE launch (r04): the lower layer's tiles wait for the rows of dz they read ----
+// Layer l's dx IS layer l-1's dz.  As two launches the second starts when the last workgroup of the first has retired - the
+// platform's 4 us between two kernels plus the first one's tail and the second one's ramp (r04 stamps: the last dx tiles of a
+// backward launch end at 25-28 us of 29, most workgroups are gone by 20).  In one launch the upper layer's workgroups take the
+// first indices; a dx workgroup of the upper layer, once its tiles are stored, RELEASES a counter of its 64-row block (agent
+// scope: the XCDs' L2s are not coherent with each other - the release writes this L2's dirty lines back, the acquire below
+// invalidates the reader's), and a lower-layer tile starts by waiting until the row blocks it reads have all their column
+// tiles, then ACQUIRES.  Nothing else changes: same tiles, same order of every sum, results identical to the two launches.
+// No deadlock: a waiting workgroup has a higher index than every workgroup it waits for, and workgroups are dispatched in
+// index order (per XCD: round-robin) - when a consumer runs, its producers are running or done.  The wait is bounded all the
+// same (kDepSpinLimit polls, then the error word is set and the tile goes on with what is there: a wrong result the caller
+// sees in `err`, never a hung GPU).  The last consumer of a row block zeroes its two counters for the next launch.
+struct DepFlags {
+  uint32_t* ready;       // [nprob][row_blocks]  producers that have released the row block
+  uint32_t* done;        // [nprob][row_blocks]  consumers that have passed their wait
+  int32_t* err;          // set when a wait ran out
+  int row_blocks;        // rows / 64
+  uint32_t producers;    // releases per row block = dx workgroups per row block of the upper layer
+  uint32_t consumers;    // waits per row block = dx workgroups per row block + dW tiles per batch split of the lower layer
+};
+constexpr int kDepSpinLimit = 1 << 22;
+
+__device__ __forceinline__ void dep_release(const DepFlags& d, int prob, int row_block) {
+  __syncthreads();                                           // every wave's stores of the tile(s) are issued and counted
+  if (threadIdx.x == 0)
+#ifdef TT_DEP_NOREL
+    __hip_atomic_fetch_add(d.ready + prob * d.row_blocks + row_block, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    __hip_atomic_fetch_add(d.ready + prob * d.row_blocks + row_block, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+
+__device__ __forceinline__ void dep_wait(const DepFlags& d, int prob, int first_block, int count) {
+  if ((int)threadIdx.x < count) {
+    const int i = prob * d.row_blocks + first_block + (int)threadIdx.x;
+    int polls = 0;
+    while (__hip_atomic_load(d.ready + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < d.producers) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++polls > kDepSpinLimit) { atomicOr(d.err, 1); break; }
+    }
+    const uint32_t seen = atomicAdd(d.done + i, 1u);
+    if (seen == d.consumers - 1u) {                          // everybody who reads this row block has seen it complete
+      __hip_atomic_store(d.done + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(d.ready + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
+#ifndef TT_DEP_NOACQ
+  if (threadIdx.x < 64u) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+  __syncthreads();
+}
+
+// one workgroup of a layer's backward launch: flat index b -> (kind, problem, split, x, y).  ROLE 0: plain; 1: the upper layer
+// of a fused pair (its dx workgroups release their row block); 2: the lower layer (every tile waits for its rows of dz).
+template <int GK, int ROLE>
+__device__ __forceinline__ void bwd_block(const BwdBatch& pb, int b, float* smem, int32_t* gids, const DepFlags& dep) {
   const int per_split = pb.dw_gm * pb.dw_gn;
   const int per_w = per_split * pb.splits;
   const int per_x = pb.dx_gm * (pb.dx_pair ? pb.dx_gn / 2 : pb.dx_gn);     // dx WORKGROUPS per problem
   const int n_dw = pb.nprob * per_w, n_dx = pb.nprob * per_x;
   // longest tiles first: workgroups are dispatched in index order, so the short tiles fill the tail
-  int b = (int)blockIdx.x - pb.rider_blocks;
   const bool is_dw = pb.dw_first ? b < n_dw : b >= n_dx;
   if (is_dw) {
     if (!pb.dw_first) b -= n_dx;
@@ -701,6 +743,10 @@ __global__ __launch_bounds__(256, (GK > 256 ? 3 : 4)) void gemm_bwd_kernel(BwdBa
       grp = (j / per_split) * 8 + (b & 7);
     }
     const int prob = grp / pb.splits, split = grp % pb.splits;
+    if constexpr (ROLE == 2) {
+      const int per = (int)(pb.aw[0].k_per_split / BM);      // row blocks of one batch split (the host checks: a whole number)
+      dep_wait(dep, prob, split * per, per);
+    }
     gemm_tile<false, false, true, GK>(pb.aw[prob], split, k % pb.dw_gm, k / pb.dw_gm, smem, gids);
   } else {
     if (pb.dw_first) b -= n_dw;
@@ -711,12 +757,46 @@ __global__ __launch_bounds__(256, (GK > 256 ? 3 : 4)) void gemm_bwd_kernel(BwdBa
     // priority the oldest wave wins: the dW waves, dispatched first, held the pipe and the dx workgroups' second tiles ran
     // alone at the end of the launch, latency-bound (r04 stamps: second dx tiles from 19-24 us to 27-32 us of a 32 us launch).
     __builtin_amdgcn_s_setprio(TT_DX_PRIO);
+    if constexpr (ROLE == 2) dep_wait(dep, prob, b % pb.dx_gm, 1);
     gemm_tile<true, true, false, 0>(pb.ax[prob], 0, b % pb.dx_gm, b / pb.dx_gm, smem, gids);
     if (pb.dx_pair) {
       __syncthreads();                               // every wave is done with the first tile's LDS buffers
       gemm_tile<true, true, false, 0>(pb.ax[prob], 0, b % pb.dx_gm, b / pb.dx_gm + pb.dx_gn / 2, smem, gids);
     }
+    if constexpr (ROLE == 1) dep_release(dep, prob, b % pb.dx_gm);
   }
+}
+
+template <int GK>
+__global__ __launch_bounds__(256, (GK > 256 ? 3 : 4)) void gemm_bwd_kernel(BwdBatch pb, tt::SegTable riders) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * 2 * TILE_F];
+  __shared__ int32_t gids[kGidsInts(GK, true)];
+  if ((int)blockIdx.x < pb.rider_blocks) {               // (workgroup-uniform)
+    const int d = (int)blockIdx.x;
+    int si = 0;
+    while (si + 1 < pb.rider_segs && d >= pb.rider_first[si + 1]) ++si;
+    const int nb = pb.rider_first[si + 1] - pb.rider_first[si];
+    if (pb.rider_opt == TT_OPT_SGD) tt::dense_update_body<TT_OPT_SGD, 256, 16>(riders.seg[si], d - pb.rider_first[si], nb, 1, pb.rider_lr, pb.rider_eps);
+    else tt::dense_update_body<TT_OPT_ADAGRAD, 256, 16>(riders.seg[si], d - pb.rider_first[si], nb, 1, pb.rider_lr, pb.rider_eps);
+    return;
+  }
+  const DepFlags none{};
+  bwd_block<GK, 0>(pb, (int)blockIdx.x - pb.rider_blocks, smem, gids, none);
+}
+
+struct Bwd2Batch {
+  BwdBatch up, lo;
+  int n_up;              // workgroups of the upper layer (they take the first indices)
+  DepFlags dep;
+};
+
+template <int GK>
+__global__ __launch_bounds__(256, (GK > 256 ? 3 : 4)) void tower_bwd2_kernel(Bwd2Batch pb) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * 2 * TILE_F];
+  __shared__ int32_t gids[kGidsInts(GK, true)];
+  const int b = (int)blockIdx.x;
+  if (b < pb.n_up) bwd_block<0, 1>(pb.up, b, smem, gids, pb.dep);
+  else bwd_block<GK, 2>(pb.lo, b - pb.n_up, smem, gids, pb.dep);
 }
 
 template <bool A_KC, bool B_KC, bool COLSUM, int GK = 0, bool DROP = false>
@@ -866,17 +946,16 @@ extern "C" int tt_dense_bwd_batched_update_f32(const tt_dense_bwd_args* probs, i
 }
 
 namespace {
-int dense_bwd_batched(const tt_dense_bwd_args* probs, int32_t n_probs, float dx_scale, int64_t m, int32_t k, int32_t n,
-                      const tt_dense_seg* rsegs, int32_t n_rsegs, int32_t ropt, float rlr, float reps, bool* riders_done, tt_stream_t stream_) {
+// the dx (NT) and dW (TN, split over the batch) problems of one layer's backward pass
+int build_bwd_args(const tt_dense_bwd_args* probs, int32_t n_probs, float dx_scale, int64_t m, int32_t k, int32_t n, GemmArgs (&ax)[2],
+                   GemmArgs (&aw)[2], int& splits, bool& want_dx, bool& want_dw, bool& gather) {
   TT_REQUIRE(probs != nullptr && n_probs >= 1 && n_probs <= 2, "tt_dense_bwd_batched_f32: 1 or 2 problems");
   TT_REQUIRE(m > 0 && k > 0 && n > 0 && k % 4 == 0 && n % 4 == 0, "tt_dense_bwd_f32: need m>0, k%%4==0, n%%4==0 (m=%lld k=%d n=%d)",
              (long long)m, k, n);
-  hipStream_t stream = tt::as_stream(stream_);
-  GemmArgs ax[2] = {}, aw[2] = {};
-  const int splits = tt_dense_bwd_num_slabs(m);
-  const bool want_dx = probs[0].dx != nullptr;
-  const bool want_dw = probs[0].dw_slabs != nullptr;
-  const bool gather = probs[0].lookup.ids != nullptr;
+  splits = tt_dense_bwd_num_slabs(m);
+  want_dx = probs[0].dx != nullptr;
+  want_dw = probs[0].dw_slabs != nullptr;
+  gather = probs[0].lookup.ids != nullptr;
   for (int i = 0; i < n_probs; ++i) {
     const tt_dense_bwd_args& q = probs[i];
     TT_REQUIRE((q.lookup.ids != nullptr) == gather, "tt_dense_bwd_batched_f32: the lookup must be given for all problems or for none");
@@ -904,21 +983,40 @@ int dense_bwd_batched(const tt_dense_bwd_args* probs, int32_t n_probs, float dx_
     aw[i].oob_flag = nullptr;            // the forward pass has flagged bad ids already
     TT_REQUIRE(!gather || aw[i].k_per_split <= kMaxGatherK, "tt_dense_bwd_f32: fused lookup: batch split too long");
   }
-  int rc;
+  return TT_OK;
+}
+
+// one layer's launch description (both kinds of tiles wanted)
+void fill_bwd_batch(BwdBatch& pb, const GemmArgs (&ax)[2], const GemmArgs (&aw)[2], int n_probs, int splits) {
+  for (int i = 0; i < n_probs; ++i) { pb.ax[i] = ax[i]; pb.aw[i] = aw[i]; }
+  pb.nprob = n_probs; pb.splits = splits;
+  pb.dx_gm = (int)((ax[0].M + BM - 1) / BM); pb.dx_gn = (int)((ax[0].N + BN - 1) / BN);
+  pb.dw_gm = (int)((aw[0].M + BM - 1) / BM); pb.dw_gn = (int)((aw[0].N + BN - 1) / BN);
+  pb.dw_first = aw[0].k_per_split > ax[0].k_per_split;     // k-tiles per tile: batch/splits rows vs n columns
+  // 4 workgroups per CU are resident (LDS, VGPRs): 1024 on the chip.  When the launch has more AND a dx tile is at most
+  // half as long as a dw tile (layer 1 of cfg3: 1024 dx tiles of 4 k-tiles + 512 dw tiles of 8), the extra workgroups start
+  // when the first ones retire and the launch runs 1.5 rounds (r02 stamps: 512 workgroups started ~20 us late, end 39.7 us,
+  // median workgroup end 22.8 us).  Pairing two dx tiles per workgroup makes every workgroup equally long and all resident.
+  const int64_t dx_tiles = (int64_t)pb.dx_gm * pb.dx_gn, dw_tiles = (int64_t)pb.dw_gm * pb.dw_gn * splits;
+  pb.dx_pair = (n_probs * (dx_tiles + dw_tiles) > 1024 && pb.dx_gn % 2 == 0 && 2 * ax[0].k_per_split <= aw[0].k_per_split) ? 1 : 0;
+  if (const char* e = std::getenv("TT_GEMM_DX_PAIR")) pb.dx_pair = (std::atoi(e) != 0 && pb.dx_gn % 2 == 0) ? 1 : 0;
+}
+int64_t bwd_batch_blocks(const BwdBatch& pb) {
+  const int64_t dx_tiles = (int64_t)pb.dx_gm * pb.dx_gn, dw_tiles = (int64_t)pb.dw_gm * pb.dw_gn * pb.splits;
+  return (int64_t)pb.nprob * (dx_tiles / (pb.dx_pair ? 2 : 1) + dw_tiles);
+}
+
+int dense_bwd_batched(const tt_dense_bwd_args* probs, int32_t n_probs, float dx_scale, int64_t m, int32_t k, int32_t n,
+                      const tt_dense_seg* rsegs, int32_t n_rsegs, int32_t ropt, float rlr, float reps, bool* riders_done, tt_stream_t stream_) {
+  hipStream_t stream = tt::as_stream(stream_);
+  GemmArgs ax[2] = {}, aw[2] = {};
+  int splits = 1;
+  bool want_dx = false, want_dw = false, gather = false;
+  int rc = build_bwd_args(probs, n_probs, dx_scale, m, k, n, ax, aw, splits, want_dx, want_dw, gather);
+  if (rc != TT_OK) return rc;
   if (want_dx && want_dw) {
     BwdBatch pb{};
-    for (int i = 0; i < n_probs; ++i) { pb.ax[i] = ax[i]; pb.aw[i] = aw[i]; }
-    pb.nprob = n_probs; pb.splits = splits;
-    pb.dx_gm = (int)((ax[0].M + BM - 1) / BM); pb.dx_gn = (int)((ax[0].N + BN - 1) / BN);
-    pb.dw_gm = (int)((aw[0].M + BM - 1) / BM); pb.dw_gn = (int)((aw[0].N + BN - 1) / BN);
-    pb.dw_first = aw[0].k_per_split > ax[0].k_per_split;     // k-tiles per tile: batch/splits rows vs n columns
-    // 4 workgroups per CU are resident (LDS, VGPRs): 1024 on the chip.  When the launch has more AND a dx tile is at most
-    // half as long as a dw tile (layer 1 of cfg3: 1024 dx tiles of 4 k-tiles + 512 dw tiles of 8), the extra workgroups start
-    // when the first ones retire and the launch runs 1.5 rounds (r02 stamps: 512 workgroups started ~20 us late, end 39.7 us,
-    // median workgroup end 22.8 us).  Pairing two dx tiles per workgroup makes every workgroup equally long and all resident.
-    const int64_t dx_tiles = (int64_t)pb.dx_gm * pb.dx_gn, dw_tiles = (int64_t)pb.dw_gm * pb.dw_gn * splits;
-    pb.dx_pair = (n_probs * (dx_tiles + dw_tiles) > 1024 && pb.dx_gn % 2 == 0 && 2 * ax[0].k_per_split <= aw[0].k_per_split) ? 1 : 0;
-    if (const char* e = std::getenv("TT_GEMM_DX_PAIR")) pb.dx_pair = (std::atoi(e) != 0 && pb.dx_gn % 2 == 0) ? 1 : 0;
+    fill_bwd_batch(pb, ax, aw, n_probs, splits);
     tt::SegTable riders{};
     if (rsegs != nullptr) {                                  // one thread per 4 elements, at most 32 blocks per segment
       for (int i = 0; i < n_rsegs; ++i) {
@@ -931,7 +1029,7 @@ int dense_bwd_batched(const tt_dense_bwd_args* probs, int32_t n_probs, float dx_
       pb.rider_segs = n_rsegs; pb.rider_blocks = pb.rider_first[n_rsegs]; pb.rider_opt = ropt; pb.rider_lr = rlr; pb.rider_eps = reps;
       *riders_done = true;
     }
-    const int64_t blocks = (int64_t)n_probs * (dx_tiles / (pb.dx_pair ? 2 : 1) + dw_tiles) + pb.rider_blocks;
+    const int64_t blocks = bwd_batch_blocks(pb) + pb.rider_blocks;
     TT_REQUIRE(blocks <= 0x7fffffff && (ax[0].M + BM - 1) / BM <= 0x3fffffff, "tt_dense_bwd_f32: grid too large");
     if (gather && aw[0].k_per_split <= 256) tt::launch("dense_bwd", gemm_bwd_kernel<256>, dim3((unsigned)blocks), dim3(256), 0, stream, pb, riders);
     else if (gather) tt::launch("dense_bwd", gemm_bwd_kernel<kMaxGatherK>, dim3((unsigned)blocks), dim3(256), 0, stream, pb, riders);
@@ -946,6 +1044,67 @@ int dense_bwd_batched(const tt_dense_bwd_args* probs, int32_t n_probs, float dx_
   return launch<false, false, true>(aw, n_probs, splits, stream, "tt_dense_bwd_f32(dw)", "dense_bwd_dw");
 }
 }  // namespace
+
+// ---- two layers' backward passes in one launch (tower_bwd2_kernel above) ----
+namespace {
+int64_t bwd2_row_blocks(int64_t m) { return m / BM; }
+}
+extern "C" int32_t tt_tower_bwd2_supported(int64_t m, int32_t k0, int32_t k1, int32_t n) {
+  if (m <= 0 || k0 <= 0 || k1 <= 0 || n <= 0 || k0 % 4 || k1 % 4 || n % 4 || m % BM) return 0;
+  const int splits = tt_dense_bwd_num_slabs(m);
+  const int64_t kps = ((m + splits - 1) / splits + BK - 1) / BK * BK;
+  if (kps % BM != 0 || kps * splits != m) return 0;          // a batch split = a whole number of 64-row blocks
+  if (kps / BM > 64) return 0;                               // (one lane of wave 0 polls each of a split's row blocks)
+  return 1;
+}
+
+extern "C" int64_t tt_tower_bwd2_workspace_bytes(int64_t m) {
+  if (m <= 0) return 256;
+  return (4 * bwd2_row_blocks(m) * 4 + 256 + 255) / 256 * 256;   // ready + done for two problems, the error word; zeroed once
+}
+
+extern "C" int tt_tower_bwd2_batched_f32(const tt_dense_bwd_args* upper, const tt_dense_bwd_args* lower, int32_t n_probs,
+                                         float dx_scale_upper, float dx_scale_lower, int64_t m, int32_t k0, int32_t k1, int32_t n,
+                                         void* workspace, tt_stream_t stream_) {
+  TT_REQUIRE(upper != nullptr && lower != nullptr && workspace != nullptr, "tt_tower_bwd2_batched_f32: null pointer");
+  TT_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0, "tt_tower_bwd2_batched_f32: workspace must be 256-byte aligned");
+  if (!tt_tower_bwd2_supported(m, k0, k1, n))
+    return tt::fail(TT_ERR_UNSUPPORTED, "tt_tower_bwd2_batched_f32: shape (m %lld, %d -> %d -> %d) not supported (tt_tower_bwd2_supported)",
+                    (long long)m, k0, k1, n);
+  hipStream_t stream = tt::as_stream(stream_);
+  GemmArgs axu[2] = {}, awu[2] = {}, axl[2] = {}, awl[2] = {};
+  int su = 1, sl = 1;
+  bool dxu = false, dwu = false, gu = false, dxl = false, dwl = false, gl = false;
+  int rc = build_bwd_args(upper, n_probs, dx_scale_upper, m, k1, n, axu, awu, su, dxu, dwu, gu);
+  if (rc != TT_OK) return rc;
+  rc = build_bwd_args(lower, n_probs, dx_scale_lower, m, k0, k1, axl, awl, sl, dxl, dwl, gl);
+  if (rc != TT_OK) return rc;
+  TT_REQUIRE(dxu && dwu && dxl && dwl, "tt_tower_bwd2_batched_f32: both layers need dx and dw_slabs");
+  TT_REQUIRE(!gu, "tt_tower_bwd2_batched_f32: only the lower layer can carry the fused lookup");
+  for (int i = 0; i < n_probs; ++i)
+    TT_REQUIRE(upper[i].dx == lower[i].dz, "tt_tower_bwd2_batched_f32: problem %d: the upper layer's dx must BE the lower layer's dz", i);
+  Bwd2Batch pb{};
+  fill_bwd_batch(pb.up, axu, awu, n_probs, su);
+  fill_bwd_batch(pb.lo, axl, awl, n_probs, sl);
+  if (const char* e = std::getenv("TT_BWD2_UP_DXFIRST")) { if (std::atoi(e) != 0) pb.up.dw_first = 0; }
+  if (const char* e = std::getenv("TT_BWD2_UP_PAIR")) pb.up.dx_pair = (std::atoi(e) != 0 && pb.up.dx_gn % 2 == 0) ? 1 : 0;
+  const int64_t n_up = bwd_batch_blocks(pb.up), n_lo = bwd_batch_blocks(pb.lo);
+  TT_REQUIRE(n_up + n_lo <= 0x7fffffff, "tt_tower_bwd2_batched_f32: grid too large");
+  pb.n_up = (int)n_up;
+  const int64_t rb = bwd2_row_blocks(m);
+  uint32_t* w32 = static_cast<uint32_t*>(workspace);
+  pb.dep.ready = w32;
+  pb.dep.done = w32 + 2 * rb;
+  pb.dep.err = reinterpret_cast<int32_t*>(w32 + 4 * rb);
+  pb.dep.row_blocks = (int)rb;
+  pb.dep.producers = (uint32_t)(pb.up.dx_pair ? pb.up.dx_gn / 2 : pb.up.dx_gn);
+  pb.dep.consumers = (uint32_t)((pb.lo.dx_pair ? pb.lo.dx_gn / 2 : pb.lo.dx_gn) + pb.lo.dw_gm * pb.lo.dw_gn);
+  const unsigned blocks = (unsigned)(n_up + n_lo);
+  if (gl && awl[0].k_per_split <= 256) tt::launch("dense_bwd", tower_bwd2_kernel<256>, dim3(blocks), dim3(256), 0, stream, pb);
+  else if (gl) tt::launch("dense_bwd", tower_bwd2_kernel<kMaxGatherK>, dim3(blocks), dim3(256), 0, stream, pb);
+  else tt::launch("dense_bwd", tower_bwd2_kernel<0>, dim3(blocks), dim3(256), 0, stream, pb);
+  return tt::check_launch("tt_tower_bwd2_batched_f32");
+}
 
 extern "C" int tt_dense_bwd_f32(const float* x, const float* w, const float* dz, float* dx, const float* dx_relu_src,
                                 float* dw_slabs, float* db_slabs, int64_t m, int32_t k, int32_t n, tt_stream_t stream_) {

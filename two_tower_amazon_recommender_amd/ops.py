@@ -483,6 +483,40 @@ def dense_bwd2(xs, ws, dzs, dxs, dx_relu_srcs, dw_slabs, db_slabs, dx_scale: flo
     _lib.check(_lib.load().tt_dense_bwd_batched_f32(arr, 2, dx_scale, m, k, n, _stream()), "tt_dense_bwd_batched_f32")
 
 
+def _bwd_args(xs, ws, dzs, dxs, dx_relu_srcs, dw_slabs, db_slabs, lookups, dx_relu_bits):
+    return (_lib.DenseBwdArgs * 2)(*[_lib.DenseBwdArgs(None if lookups is not None else _p(xs[i]), _p(ws[i]), _p(dzs[i]), _p(dxs[i]),
+                                                      _p(dx_relu_srcs[i]), _p(dw_slabs[i]), _p(db_slabs[i]),
+                                                      lookups[i] if lookups is not None else _no_lookup(),
+                                                      _p(dx_relu_bits[i])) for i in range(2)])
+
+
+def tower_bwd2_supported(m: int, k0: int, k1: int, n: int) -> bool:
+    return bool(_lib.load().tt_tower_bwd2_supported(m, k0, k1, n))
+
+
+def tower_bwd2_workspace(m: int, device) -> torch.Tensor:
+    """The dependency counters of ``tower_bwd2`` (zeroed once; every launch leaves them zeroed; int32 word 4*(m//64) = error)."""
+    return torch.zeros(int(_lib.load().tt_tower_bwd2_workspace_bytes(m)), dtype=torch.uint8, device=device)
+
+
+def tower_bwd2(upper: dict, lower: dict, workspace: torch.Tensor, dx_scale_upper: float = 1.0, dx_scale_lower: float = 1.0):
+    """Backward of layers l (``upper``) and l-1 (``lower``) of both towers in ONE launch (``tt_tower_bwd2_batched_f32``); each
+    dict holds ``dense_bwd2``'s arguments: xs, ws, dzs, dxs, dx_relu_srcs, dw_slabs, db_slabs and optionally lookups, dx_relu_bits.
+    ``upper['dxs'][i]`` must BE ``lower['dzs'][i]``.  Bit-identical to the two ``dense_bwd2`` calls."""
+    none2 = (None, None)
+    lk = lower.get("lookups")
+    m, k0 = _in_shape(lower["xs"][0], None if lk is None else lk[0])
+    k1, n = upper["ws"][0].shape[0], upper["ws"][0].shape[1]
+    bu, bl = upper.get("dx_relu_bits", none2), lower.get("dx_relu_bits", none2)
+    for i in range(2):
+        _chk_bits(bu[i], m, k1, "tower_bwd2: upper dx_relu_bits")
+        _chk_bits(bl[i], m, k0, "tower_bwd2: lower dx_relu_bits")
+    au = _bwd_args(upper["xs"], upper["ws"], upper["dzs"], upper["dxs"], upper["dx_relu_srcs"], upper["dw_slabs"], upper["db_slabs"], None, bu)
+    al = _bwd_args(lower["xs"], lower["ws"], lower["dzs"], lower["dxs"], lower["dx_relu_srcs"], lower["dw_slabs"], lower["db_slabs"], lk, bl)
+    _lib.check(_lib.load().tt_tower_bwd2_batched_f32(au, al, 2, dx_scale_upper, dx_scale_lower, m, k0, k1, n, _p(workspace), _stream()),
+               "tt_tower_bwd2_batched_f32")
+
+
 def dense_update_(segs: list[DenseSeg], opt: str, lr: float, eps: float = 1e-7, apply: bool = True):
     arr = (DenseSeg * len(segs))(*segs)
     lib = _lib.load()

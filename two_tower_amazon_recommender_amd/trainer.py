@@ -196,27 +196,39 @@ def towers_forward(ut: "Tower", it: "Tower", dropout=None, lookups=None):
     return ut.acts[-1], it.acts[-1]
 
 
-def towers_backward(ut: "Tower", it: "Tower", dropout_rate: float = 0.0, on_embedding_grads=None, lookups=None):
-    """Backward of both towers, two launches per layer (dx of both, dw+db of both).
+def towers_backward(ut: "Tower", it: "Tower", dropout_rate: float = 0.0, on_embedding_grads=None, lookups=None, bwd2_ws=None):
+    """Backward of both towers, one launch per layer (dx and dw+db tiles of both towers side by side).
     With ``on_embedding_grads`` every dx is computed first, the callback runs as soon as demb is complete (the
-    sharded trainer starts the gradient exchange there) and the dw+db launches follow, beside the transfer."""
+    sharded trainer starts the gradient exchange there) and the dw+db launches follow, beside the transfer.
+    ``bwd2_ws`` (ops.tower_bwd2_workspace): layers 1 and 0 in ONE launch where the shape allows (tt_tower_bwd2_batched_f32)."""
     scale = 1.0
     if dropout_rate > 0.0:
         one = torch.ones((), dtype=torch.float32)
         scale = (one / (one - torch.tensor(dropout_rate, dtype=torch.float32))).item()
     none2 = (None, None)
 
-    def layer(l, dx: bool, dw: bool):
+    def layer_args(l, dx: bool, dw: bool):
         dxs = ((ut.dz[l - 1], it.dz[l - 1]) if l > 0 else (ut.demb, it.demb)) if dx else none2
         bits = (ut.bits[l], it.bits[l]) if (l > 0 and dx and ut.bits[l] is not None) else none2
         masks = (ut.acts[l], it.acts[l]) if (l > 0 and dx and bits[0] is None) else none2
-        ops.dense_bwd2((ut.acts[l], it.acts[l]), (ut.w[l], it.w[l]), (ut.dz[l], it.dz[l]), dxs, masks,
-                       (ut.dw_slabs[l], it.dw_slabs[l]) if dw else none2, (ut.db_slabs[l], it.db_slabs[l]) if dw else none2,
-                       dx_scale=scale if l > 0 else 1.0, lookups=lookups if l == 0 else None, dx_relu_bits=bits)
+        return dict(xs=(ut.acts[l], it.acts[l]), ws=(ut.w[l], it.w[l]), dzs=(ut.dz[l], it.dz[l]), dxs=dxs, dx_relu_srcs=masks,
+                    dw_slabs=(ut.dw_slabs[l], it.dw_slabs[l]) if dw else none2, db_slabs=(ut.db_slabs[l], it.db_slabs[l]) if dw else none2,
+                    lookups=lookups if l == 0 else None, dx_relu_bits=bits)
+
+    def layer(l, dx: bool, dw: bool):
+        a = layer_args(l, dx, dw)
+        ops.dense_bwd2(a["xs"], a["ws"], a["dzs"], a["dxs"], a["dx_relu_srcs"], a["dw_slabs"], a["db_slabs"],
+                       dx_scale=scale if l > 0 else 1.0, lookups=a["lookups"], dx_relu_bits=a["dx_relu_bits"])
 
     if on_embedding_grads is None:
-        for l in range(ut.n_layers - 1, -1, -1):
+        last = -1
+        if (bwd2_ws is not None and ut.n_layers >= 2
+                and ops.tower_bwd2_supported(ut.dz[0].shape[0], ut.dims[0], ut.dims[1], ut.dims[2])):
+            last = 1
+        for l in range(ut.n_layers - 1, last, -1):
             layer(l, True, True)
+        if last == 1:
+            ops.tower_bwd2(layer_args(1, True, True), layer_args(0, True, True), bwd2_ws, dx_scale_upper=scale, dx_scale_lower=1.0)
         return
     for l in range(ut.n_layers - 1, -1, -1):
         layer(l, True, False)
@@ -279,6 +291,12 @@ class TwoTowerTrainer:
         self.use_composite = os.environ.get("TT_COMPOSITE_STEP", "1") != "0"
         self._cstep = None
         self._id_bucket_ws = None
+        # layers 1 and 0 of the backward pass in ONE launch (tt_tower_bwd2_batched_f32: the lower layer's tiles wait inside the
+        # launch for the rows of dz they read); TT_BWD2=0: one launch per layer
+        self.bwd2_ws = None
+        if (os.environ.get("TT_BWD2", "0") != "0" and cfg.symmetric and len(cfg.tower_dims) >= 2
+                and ops.tower_bwd2_supported(b, d, cfg.tower_dims[0], cfg.tower_dims[1])):
+            self.bwd2_ws = ops.tower_bwd2_workspace(b, dev)
         self.flag_poll_every = 50                # steps between asynchronous polls of the out-of-range flag (0 = never)
         self._oob_host = self._oob_event = None
         self._oob_step = -1
@@ -391,7 +409,7 @@ class TwoTowerTrainer:
         ops.retrieval_fwd_bwd(q, c, 1.0 / cfg.temperature, self.ws, self.lse, self.per_row, self.loss,
                               ut.dz[-1], it.dz[-1], precision=cfg.scorer_precision, **kw)
         if cfg.symmetric:
-            towers_backward(ut, it, cfg.dropout_rate, lookups=lks if lks[0] else None)
+            towers_backward(ut, it, cfg.dropout_rate, lookups=lks if lks[0] else None, bwd2_ws=self.bwd2_ws)
         else:
             ut.backward(cfg.dropout_rate, lookup=lks[0])
             it.backward(cfg.dropout_rate, lookup=lks[1])
