@@ -68,9 +68,11 @@ def parse():
                     help="before the W warm-up steps, keep the GPU busy this long with forward-only passes over the first "
                          "batch (no parameter is touched): a fresh process starts at idle clocks and cold TLBs, and a "
                          "25-step run otherwise measures the ramp (BENCH_r01: FUSED kernel 290 us vs 269 us in steady state)")
-    ap.add_argument("--negatives", default="global", choices=["global", "local"],
-                    help="N>1: in-batch negatives over the all-gathered GLOBAL batch (parity with the single-device loss; "
-                         "default) or over each rank's own batch")
+    ap.add_argument("--negatives", default=None, choices=["global", "local"],
+                    help="N>1: in-batch negatives over the all-gathered GLOBAL batch (the loss of the single device on the global "
+                         "batch; default for cfg4 / cfg5, BASELINE's fixed global problems) or over each rank's own batch (what a "
+                         "data-parallel Keras replica computes; default for the weak-scaled cfg3 family: per-GPU work fixed as N "
+                         "grows).  The other mode is timed in the same run and reported as `other_negatives`")
     return ap.parse_args()
 
 

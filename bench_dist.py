@@ -7,9 +7,13 @@ Workloads (``--config``):
                   GLOBAL batch 16384 (16384/N per GPU), towers 128->256->128, SGD       -> "scaling": "strong"
   cfg5            BASELINE configs[4]: 54M users x 48M items, emb_dim 256, GLOBAL batch 32768, towers
                   256->512->256, fused sparse Adagrad, 30-bucket hashed category feature -> "scaling": "strong"
-In-batch negatives are GLOBAL by default (candidates all-gathered, dC reduce-scattered: the loss equals the
-single-device loss on the global batch); ``--negatives local`` scores each rank's queries against its
-own candidates only and says so in ``config.workload``.
+In-batch negatives: cfg4 / cfg5 (BASELINE's fixed global problems) score every rank's queries against the GLOBAL batch
+(candidates all-gathered, dC reduce-scattered: the loss equals the single-device loss on the global batch).
+The weak-scaled cfg3 family scores each rank's queries against its OWN batch (``local``: what a data-parallel Keras replica
+of the reference's stack computes) - since r04: "weak" means the work per GPU is fixed as N grows, and with global negatives
+every GPU's scorer would do N times the N = 1 work (B_local x N B_local logits; through r03 that was this line, its numbers
+are the ``other_negatives`` object now).  ``--negatives global|local`` overrides; the mode is named in ``config.workload``
+and the OTHER mode is timed in the same run (``other_negatives``).
 value = global batch * steps / max-over-ranks time.  The line carries the scorer's ``roofline`` on the per-GPU slab
 (B_local x B_global) from live dispatch timestamps (hipExtLaunchKernelGGL event pair, r04) on rank 0, and per-collective stream time from an untimed detail pass.
 """
@@ -83,7 +87,7 @@ def run_distributed(args, rank, world, dev):
     dist.init_process_group("nccl", device_id=dev)
     name = args.config if args.config in DIST_CONFIGS else "cfg3"
     n_users, n_items, dim, tower_dims, gbatch, opt, buckets = DIST_CONFIGS[name]
-    negatives = args.negatives
+    negatives = args.negatives or ("local" if name == "cfg3" else "global")
     if name == "cfg3":                  # weak scaling: fixed work per GPU
         n_users, n_items = int(os.environ.get("TT_USERS_PER_GPU", n_users)) * world, int(os.environ.get("TT_ITEMS_PER_GPU", n_items)) * world
         batch, scaling = 8192, "weak"
