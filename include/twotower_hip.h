@@ -460,6 +460,11 @@ int tt_train_step_f32(const tt_train_step* step, tt_stream_t stream);
  * 8192, 4.3 GB at 32768 x 32768; ABI v5 and later - a workspace sized by an older library is refused with
  * TT_ERR_WORKSPACE).  Both precisions keep them, at every dim (ABI v8; bf16x3 at dim 256 recomputed through v7).    */
 int64_t tt_retrieval_workspace_bytes(int64_t nq, int64_t nc, int32_t dim);
+/* Host query: the number of slices a scorer pass cuts its streamed side into for this shape (pass 0: stationary q - loss + dq,
+ * forward, rank; 1: stationary c - dc with the products recomputed; 2: dc from the stored products).  r04: chosen by a model of
+ * the launch (rounds of resident workgroups) instead of "double until 512 workgroups" - batch 8200 ran 0.879 ms against 0.558
+ * for 8192 because 8 of 520 workgroups ran a second round alone; every power-of-two shape keeps its r03 value.               */
+int32_t tt_retrieval_num_splits(int64_t nq, int64_t nc, int32_t dim, int32_t pass);
 /* the part of it the forward-only (tt_retrieval_fwd_f32) and separate-backward (tt_retrieval_bwd_f32) entries need: no
  * [nq][nc] logit buffer (only the fused training entries keep the raw dot products between their two passes) */
 int64_t tt_retrieval_fwd_workspace_bytes(int64_t nq, int64_t nc, int32_t dim);

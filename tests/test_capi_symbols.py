@@ -101,3 +101,31 @@ def test_row_range_geometry_is_a_host_query():
     assert lib.tt_optimizer_ids_geometry(rows, 0, 128, 8192, segs, 4, groups, width, C.byref(cap)) == _lib.TT_ERR_INVALID_ARG
     per = lib.tt_id_buckets_workspace_bytes()
     assert per == 256 * 256 + 256 * 256 * 8 and per % 256 == 0           # a counter per 256-byte line + 256 lists of 256 entries
+
+
+def test_scorer_split_count_keeps_the_power_of_two_shapes_and_fits_ragged_batches_into_whole_rounds():
+    """csrc/score.hip choose_nsplit (r04, a host function): r03 doubled the split count until the launch had 512 workgroups, which
+    is exactly one round of resident workgroups at batch 8192 - and one round plus 8 stragglers at 8200 (0.879 ms against 0.558,
+    profiles/r04_batch_sweep.jsonl).  The launch model must (a) give every power-of-two shape r03's value and (b) never leave a
+    nearly empty last round at the ragged sizes."""
+    lib = _lib.load()
+    def r03(n_r, n_c, target=512):
+        nrb, ns = (n_r + 127) // 128, 1
+        while nrb * ns < target and ns * 2 * 64 <= n_c and ns < 64:
+            ns *= 2
+        return ns
+    sizes = [64, 256, 1024, 2048, 4096, 8192, 16384, 32768, 65536]
+    for nq in sizes:
+        for nc in sizes:
+            for dim in (32, 64, 128, 256):
+                assert lib.tt_retrieval_num_splits(nq, nc, dim, 0) == r03(nq, nc), (nq, nc, dim)
+                assert lib.tt_retrieval_num_splits(nq, nc, dim, 1) == r03(nc, nq), (nq, nc, dim)
+                assert lib.tt_retrieval_num_splits(nq, nc, dim, 2) == r03(nc, nq), (nq, nc, dim)
+    for b in (8200, 8256, 8000, 6000, 4100, 10000, 12288, 16000, 3000, 1000):
+        for p, rows, slots in ((0, 128, 512), (2, 256, 256)):
+            ns = lib.tt_retrieval_num_splits(b, b, 128, p)
+            wgs = -(-b // rows) * ns
+            rounds = -(-wgs // slots)
+            assert 1 <= ns <= 64 and ns * 64 <= b
+            assert wgs > 0.85 * rounds * slots or rounds == 1, (b, p, ns, wgs, rounds)     # the last round is (nearly) full
+    assert lib.tt_retrieval_num_splits(8200, 8200, 128, 0) == 15 and lib.tt_retrieval_num_splits(0, 5, 128, 0) == 0

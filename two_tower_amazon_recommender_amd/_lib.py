@@ -150,6 +150,7 @@ SIGNATURES = {
     "tt_id_range_load": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(_i64), _i32, _i32, _i64, C.POINTER(DenseSeg), _i32, _p, _p]),
     "tt_train_step_f32": (C.c_int, [C.POINTER(TrainStep), _p]),
     "tt_retrieval_workspace_bytes": (_i64, [_i64, _i64, _i32]),
+    "tt_retrieval_num_splits": (_i32, [_i64, _i64, _i32, _i32]),
     "tt_retrieval_fwd_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "tt_retrieval_rank_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "tt_retrieval_fwd_f32": (C.c_int, [_p, _p, _i64, _i64, _i32, _i64, _f, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p]),

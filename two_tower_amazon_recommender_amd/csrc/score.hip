@@ -1202,12 +1202,33 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const f32x4* __restri
 #ifndef TT_BWDS_WGS
 #define TT_BWDS_WGS 512       // workgroups the BWD_S pass (dc from the stored dot products) aims for
 #endif
-int choose_nsplit(int64_t n_r, int64_t n_c, int target_wgs = TT_SCORE_WGS) {
+int choose_nsplit_pow2(int64_t n_r, int64_t n_c, int target_wgs = TT_SCORE_WGS) {
   const int64_t nrb = (n_r + 32 * TT_SCORE_WAVES - 1) / (32 * TT_SCORE_WAVES);
   int ns = 1;
   // 512 workgroups = two per CU measured best at B = 8192 (256: 291 us, 512: 272 us, 1024: 283 us, 2048: 294 us per launch)
   while (nrb * ns < target_wgs && (int64_t)ns * 2 * 64 <= n_c && ns < 64) ns *= 2;
   return ns;
+}
+
+// r04: the split count by a model of the launch instead of "double until 512 workgroups".  A scorer workgroup runs for the WHOLE
+// launch (its row block against 1/ns of the columns), and `slots` of them are resident at once (two 4-wave or one 8-wave
+// workgroup per CU): n_r = 8192 gives 64 row blocks x 8 splits = exactly 512 - and n_r = 8200 gave 65 x 8 = 520, eight workgroups
+// that ran a second round alone: batch 8200 took 0.879 ms against 0.558 for 8192 (pass 1 289 -> 420 us, pass 2 173 -> 318;
+// 4100 against 4096: 0.318 vs 0.214 ms).  cost(ns) = rounds(ns) / ns x (1 + 0.005 ns): the rounds the grid needs, each 1/ns of the
+// columns long, plus the measured price of more, shorter workgroups (1024 instead of 512 at 8192: +4 %).  The minimum over ns =
+// 1..64 is the old choice for every power-of-two shape (checked over n_r, n_c in 64 .. 262144: scratch/r04_nsplit_model.py) and e.g.
+// 15 splits (975 workgroups, two nearly full rounds) for 8200.  Any ns is valid: the columns are cut at multiples of 32.
+int choose_nsplit(int64_t n_r, int64_t n_c, int rows_per_wg = 32 * TT_SCORE_WAVES, int slots = TT_SCORE_WGS) {
+  const int64_t nrb = (n_r + rows_per_wg - 1) / rows_per_wg;
+  int best = 1;
+  double best_cost = 0.0;
+  for (int ns = 1; ns <= 64; ++ns) {
+    if (ns > 1 && (int64_t)ns * 64 > n_c) break;
+    const int64_t rounds = (nrb * ns + slots - 1) / slots;
+    const double cost = (double)rounds / ns * (1.0 + 0.005 * ns);
+    if (ns == 1 || cost < best_cost - 1e-12) { best = ns; best_cost = cost; }
+  }
+  return best;
 }
 
 int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
@@ -1220,9 +1241,15 @@ struct WsLayout {
 
 WsLayout ws_layout(int64_t nq, int64_t nc, int32_t dim) {
   WsLayout w{};
-  w.ns_q = choose_nsplit(nq, nc);
-  w.ns_c = choose_nsplit(nc, nq);
-  w.ns_cs = choose_nsplit(nc, nq, TT_BWDS_WGS);
+  if (dim <= 128 && std::getenv("TT_NSPLIT_POW2") == nullptr) {
+    w.ns_q = choose_nsplit(nq, nc);
+    w.ns_c = choose_nsplit(nc, nq);
+    w.ns_cs = choose_nsplit(nc, nq, 256, 256);     // the dc pass from the stored dot products: 8-wave workgroups, one per CU
+  } else {                                         // (dim 256: other workgroup shapes per kernel form; not re-measured - r03's rule)
+    w.ns_q = choose_nsplit_pow2(nq, nc);
+    w.ns_c = choose_nsplit_pow2(nc, nq);
+    w.ns_cs = choose_nsplit_pow2(nc, nq, TT_BWDS_WGS);
+  }
   int64_t o = 0;
   w.off_bias = o; o = align_up(o + nc * 4, 256);
   w.off_aq = o;   o = align_up(o + nq * 4, 256);
@@ -1338,6 +1365,14 @@ int check_common(const char* fn, const float* q, const float* c, int64_t nq, int
 }
 
 }  // namespace
+
+// How many ways a pass of the scorer cuts its streamed side (a host query: what sizes the workspace, and what a test can pin):
+// pass 0 = stationary q (loss + dq, forward, rank), 1 = stationary c (dc, recomputing the products), 2 = dc from the stored products.
+extern "C" int32_t tt_retrieval_num_splits(int64_t nq, int64_t nc, int32_t dim, int32_t pass) {
+  if (nq <= 0 || nc <= 0 || dim <= 0 || pass < 0 || pass > 2) return 0;
+  const WsLayout w = ws_layout(nq, nc, dim);
+  return pass == 0 ? w.ns_q : (pass == 1 ? w.ns_c : w.ns_cs);
+}
 
 extern "C" int64_t tt_retrieval_workspace_bytes(int64_t nq, int64_t nc, int32_t dim) {
   if (nq <= 0 || nc <= 0 || dim <= 0) return 0;
