@@ -1245,6 +1245,9 @@ WsLayout ws_layout(int64_t nq, int64_t nc, int32_t dim) {
     w.ns_q = choose_nsplit(nq, nc);
     w.ns_c = choose_nsplit(nc, nq);
     w.ns_cs = choose_nsplit(nc, nq, 256, 256);     // the dc pass from the stored dot products: 8-wave workgroups, one per CU
+    // (experiment hooks: TT_NSPLIT_Q / TT_NSPLIT_CS force the split counts of pass 1 / the dc pass)
+    if (const char* e = std::getenv("TT_NSPLIT_Q")) { const int v = std::atoi(e); if (v >= 1 && v <= 64 && (int64_t)v * 64 <= nc) w.ns_q = v; }
+    if (const char* e = std::getenv("TT_NSPLIT_CS")) { const int v = std::atoi(e); if (v >= 1 && v <= 64 && (int64_t)v * 64 <= nq) w.ns_cs = v; }
   } else {                                         // (dim 256: other workgroup shapes per kernel form; not re-measured - r03's rule)
     w.ns_q = choose_nsplit_pow2(nq, nc);
     w.ns_c = choose_nsplit_pow2(nc, nq);
