@@ -71,7 +71,9 @@ class BatchIterator:
         # with a category column the iterator yields (user, item, category bucket) triples
         self.c = None if category_bucket is None else torch.from_numpy(np.ascontiguousarray(category_bucket)).to(device)
         self.batch_size, self.shuffle = batch_size, shuffle
-        self.gen = torch.Generator(device="cpu").manual_seed(seed)
+        # the epoch's permutation is drawn ON THE DEVICE (r04): torch.randperm of 5.9 M indices on the host took ~0.1 s of a
+        # 0.53 s epoch of 720 cfg3-sized steps - the CLI reported 11.2 M pairs/s for a step loop that runs at 14.0 M
+        self.gen = torch.Generator(device=self.u.device).manual_seed(seed)
         self.n_batches = len(user_idx) // batch_size
 
     def __len__(self):
@@ -81,7 +83,7 @@ class BatchIterator:
         n = self.u.numel()
         c = self.c
         if self.shuffle:
-            perm = torch.randperm(n, generator=self.gen).to(self.u.device)
+            perm = torch.randperm(n, generator=self.gen, device=self.u.device)
             u, i = self.u[perm], self.i[perm]
             c = None if c is None else c[perm]
         else:

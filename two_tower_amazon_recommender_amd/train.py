@@ -185,7 +185,7 @@ def main(argv=None) -> int:
         t0 = time.perf_counter()
         tot = torch.zeros((), device=trainer.dev, dtype=torch.float64)
         for batch in train_it:
-            tot += trainer.step(batch[0], batch[1], **kw(batch)).double().squeeze()
+            tot.add_(trainer.step(batch[0], batch[1], **kw(batch)).view(()))      # (one mixed-precision add: f64 += f32)
         torch.cuda.synchronize()
         trainer.check_ids()
         dt = time.perf_counter() - t0
@@ -194,7 +194,7 @@ def main(argv=None) -> int:
         if len(val_it) and (epoch + 1) % loop["validation_freq"] == 0:
             vt = torch.zeros((), device=trainer.dev, dtype=torch.float64)
             for batch in val_it:
-                vt += trainer.evaluate(batch[0], batch[1], **kw(batch)).double().squeeze()
+                vt.add_(trainer.evaluate(batch[0], batch[1], **kw(batch)).view(()))
             rec["val_loss_per_pair"] = total(vt) / (len(val_it) * cfg.batch_size * world)
             stop = stopper.update(rec["val_loss_per_pair"])
         else:
