@@ -125,7 +125,8 @@ def _retrieval_setup(ctx, inputs, output):
 def _retrieval_backward(ctx, g_loss, g_per_example, g_dq, g_dc):
     dq, dc = ctx.saved_tensors
     # the upstream gradient of the scalar loss stays on the device (no host sync)
-    return dq * g_loss, dc * g_loss, None, None, None, None, None, None, None
+    sdq, sdc = torch._foreach_mul((dq, dc), g_loss)            # (one launch for both)
+    return sdq, sdc, None, None, None, None, None, None, None
 
 
 retrieval_loss.register_autograd(_retrieval_backward, setup_context=_retrieval_setup)
@@ -204,7 +205,7 @@ def dense_bwd(x: Tensor, w: Tensor, dy: Tensor, y: Optional[Tensor]) -> Tuple[Te
     dw / db: split-K slabs over the batch summed in slab order (bitwise reproducible)."""
     x, w, dy = x.contiguous(), w.contiguous(), dy.contiguous()
     m, k, n = x.shape[0], x.shape[1], w.shape[1]
-    dz = dy if y is None else torch.where(y > 0, dy, torch.zeros((), dtype=dy.dtype, device=dy.device))
+    dz = dy if y is None else torch.ops.aten.threshold_backward(dy, y, 0.0)    # dy where y > 0 else 0: ONE kernel (gt + where: two)
     ns = ops.dense_bwd_num_slabs(m)
     dx = torch.empty_like(x)
     dw_slabs, db_slabs = x.new_empty(ns, k, n), x.new_empty(ns, n)
