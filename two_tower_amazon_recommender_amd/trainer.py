@@ -668,34 +668,53 @@ class TwoTowerTrainer:
         acc = None
         if self.cfg.optimizer == "adagrad":
             acc = [t.clone() for t in (self.user_accum[:1], self.item_accum[:1], self.dense_accum)]
-        s = torch.cuda.Stream(device=self.dev)
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            self.step(self._g_uid, self._g_iid, **self._g_kw)   # warm-up on the capture stream (ids 0: touches row 0 only)
-        torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
-        self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
-            self.step(self._g_uid, self._g_iid, **self._g_kw)
-        torch.cuda.synchronize()
-        # undo the warm-up step's update (row 0 of both tables, dense parameters)
-        self.user_table[:1].copy_(state[0]); self.item_table[:1].copy_(state[1]); self.dense_flat.copy_(state[2])
-        if acc is not None:
-            self.user_accum[:1].copy_(acc[0]); self.item_accum[:1].copy_(acc[1]); self.dense_accum.copy_(acc[2])
-        if cat_state is not None:
-            self.cat_table[:1].copy_(cat_state[0])
-            if cat_state[1] is not None:
-                self.cat_accum[:1].copy_(cat_state[1])
+        # one graph per optimizer path (r04): the skew probe runs OUTSIDE the graphs (step_graph) and picks which one to replay
+        poll, load, state_was = self.flag_poll_every, self.range_load, self._skew_state
+        self.flag_poll_every = 0                       # (no probe / flag poll inside the warm-up or the capture)
+        self._graphs = {}
+        try:
+            for skewed in ((False, True) if self.skew_limit else (False,)):
+                self.range_load = self.skew_limit + 1 if skewed else 0
+                self._skew_state = skewed
+                s = torch.cuda.Stream(device=self.dev)
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    self.step(self._g_uid, self._g_iid, **self._g_kw)   # warm-up on the capture stream (ids 0: touches row 0 only)
+                torch.cuda.current_stream().wait_stream(s)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self.step(self._g_uid, self._g_iid, **self._g_kw)
+                torch.cuda.synchronize()
+                self._graphs[skewed] = g
+                # undo the warm-up step's update (row 0 of both tables, dense parameters)
+                self.user_table[:1].copy_(state[0]); self.item_table[:1].copy_(state[1]); self.dense_flat.copy_(state[2])
+                if acc is not None:
+                    self.user_accum[:1].copy_(acc[0]); self.item_accum[:1].copy_(acc[1]); self.dense_accum.copy_(acc[2])
+                if cat_state is not None:
+                    self.cat_table[:1].copy_(cat_state[0])
+                    if cat_state[1] is not None:
+                        self.cat_accum[:1].copy_(cat_state[1])
+        finally:
+            self.flag_poll_every, self.range_load, self._skew_state = poll, load, state_was
+        self._graph = self._graphs[False]
         return self
 
     def step_graph(self, user_ids: torch.Tensor, item_ids: torch.Tensor, category_ids: torch.Tensor | None = None) -> torch.Tensor:
         self._check_categories(category_ids)
         self._g_uid.copy_(user_ids, non_blocking=True)
         self._g_iid.copy_(item_ids, non_blocking=True)
+        ids, rows = [self._g_uid, self._g_iid], [self.cfg.n_users, self.cfg.n_items]
         if category_ids is not None:
             self._g_kw["category_ids"].copy_(category_ids, non_blocking=True)
-        self._graph.replay()
-        self._replays = getattr(self, "_replays", 0) + 1
+            ids.append(self._g_kw["category_ids"]); rows.append(self.cfg.n_category_buckets)
+        self._replays = getattr(self, "_replays", 0)
+        if len(self._graphs) > 1:                      # the skew probe, outside the graphs: which optimizer path this batch replays
+            step_was, self.step_index = self.step_index, self._replays
+            self._poll_skew(ids, rows)
+            self.step_index = step_was
+        self._graphs[self._skewed() if len(self._graphs) > 1 else False].replay()
+        self._replays += 1
         if self.flag_poll_every and self._replays % self.flag_poll_every == 0:     # host side, outside the graph
             self.poll_ids()
         return self.loss
